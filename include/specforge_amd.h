@@ -1,0 +1,137 @@
+/* specforge_amd -- C-ABI of the MI355X-native EAGLE3 draft-training hot path.
+ *
+ * libsfhip.so exports exactly these symbols.  Every entry point takes raw device
+ * pointers + sizes + element strides + a hipStream_t (as void*), enqueues work on that
+ * stream and returns an int status (SF_OK == 0); sf_last_error() gives the message of
+ * the last failing call on the calling thread.  No torch types, no ownership transfer:
+ * all buffers are caller-owned and must stay alive until the stream has passed the call.
+ *
+ * The reference (sgl-project/SpecForge) is pure Python with no FFI: each entry point
+ * below names the Python function(s) of the reference it replaces (paths relative to
+ * the reference root).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * dtype codes: SF_BF16 (bf16 storage, fp32 arithmetic) is the product path; SF_F32 is
+ * accepted by the HBM-bound row kernels so they can be checked against fp32 goldens.
+ * "padded" arrays are [B, Spad] (Spad = S + ttt_length) with zero-filled tails: the TTT
+ * shift of step k is then the offset `off = k` into them.
+ */
+#ifndef SPECFORGE_AMD_H
+#define SPECFORGE_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_OK 0
+#define SF_ERR_INVALID 1 /* argument / shape / alignment check failed */
+#define SF_ERR_LAUNCH 2  /* HIP launch error */
+
+#define SF_BF16 0
+#define SF_F32 1
+
+#define SF_ABI_VERSION 1
+
+int sf_abi_version(void);
+/* 1 if this library is the SIMT-emulator test build, 0 for the gfx950 product build */
+int sf_is_emulated(void);
+const char* sf_last_error(void);
+
+/* ---- bf16 GEMM, C[M,N] = alpha*A[M,K].B[N,K]^T (+beta*C) (+R) ------------------------------
+ * replaces the ATen GEMMs behind nn.Linear: specforge/modeling/draft/llama3_eagle.py:555-566
+ * (q/k/v/o_proj), 1513-1515 (gate/up/down), 1674-1678 (fc), 1691-1693 (lm_head),
+ * specforge/modeling/target/target_head.py:31,100-101 (teacher head) and their autograd
+ * dgrad/wgrad.  c_dtype: SF_BF16 or SF_F32.  R (bf16, optional): residual added after the
+ * projection has been rounded to bf16 (llama3_eagle.py:1641,1650). */
+int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
+               int K, float alpha, float beta, const void* R, long ldr, void* stream);
+
+/* ---- fused soft-target CE step: loss + in-place dlogits + accuracy + acceptance -----------
+ * replaces specforge/core/loss.py:173-228 (LogSoftmaxLoss fwd/bwd), eagle3/model.py:161-173
+ * (accuracy), core/lk_loss.py:43-80 (acceptance rate).  Per row r=b*S+s (padded index
+ * pr=b*Spad+s+off): row_loss = pos_mask*(-sum_v p*log_softmax(x)); row_accept = pos_mask*
+ * sum_v min(p*pod_scale, softmax(x)); row_correct = loss_mask*[argmax+d2t[argmax]==tgt_id];
+ * if write_grad, logits are overwritten by grad_scale*pos_mask*(softmax*tsum - p).
+ * pod_scale_pad / tgt_ids_pad / d2t / row_pred may be NULL; tsum_pad NULL => summed in-kernel. */
+int sf_ce_fused(void* logits, int dtype, long ld, int rows, int V, const float* target, int S, int Spad, int off,
+                const int* pos_mask_pad, const int* loss_mask_pad, const long long* tgt_ids_pad,
+                const float* pod_scale_pad, const float* tsum_pad, const long long* d2t, float grad_scale,
+                int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred,
+                void* stream);
+
+/* out[i] = scale * sum(in[i*n : (i+1)*n]) in a fixed order (double accumulation): deterministic
+ * replacement of the .sum()/.mean() reductions in eagle3/model.py:161-190. */
+int sf_reduce_sum(const float* in, long n, int nsegments, float* out, float scale, void* stream);
+
+/* ---- teacher soft targets from target logits ---------------------------------------------
+ * replaces specforge/algorithms/eagle3/model.py:487-501 (_compute_target_p): argmax id
+ * (lowest index on ties), position_mask = t2d[id]*loss_mask, target_p = softmax over the
+ * draft sub-vocabulary {j + d2t[j]}, pod_scale with target_p_on_draft = target_p*pod_scale,
+ * tsum = sum(target_p).  Outputs are written at padded index b*Spad+s. */
+int sf_teacher_reduce(const void* z, int dtype, long ldz, int rows, int Vt, int Vd, const long long* d2t,
+                      const unsigned char* t2d, const int* loss_mask_pad, int S, int Spad, float* target_p_pad,
+                      float* pod_scale_pad, float* tsum_pad, long long* ids_pad, int* pos_mask_pad, void* stream);
+
+/* ---- RMSNorm (+frozen-embedding gather) ---------------------------------------------------
+ * replaces llama3_eagle.py:1561-1567 (LlamaRMSNorm.forward), 1759-1760 (embed_input_ids) and
+ * the cat() placement of 1625-1630 (y/ldy address one half of the 2H-wide layer input).
+ * ids_pad != NULL: row r reads x + ids_pad[b*Spad+s+off]*ldx (x is the embedding table). */
+int sf_rmsnorm_fwd(const void* x, int dtype, long ldx, const long long* ids_pad, int S, int Spad, int off,
+                   const void* w, float eps, int rows, int H, void* y, long ldy, float* rstd, void* stream);
+long sf_rmsnorm_bwd_workspace_floats(int rows, int H);
+/* dx (optional) = add (optional) + d/dx; dw_acc[H] (optional, fp32) = or += d/dw. */
+int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* x, long ldx, const long long* ids_pad, int S,
+                   int Spad, int off, const void* w, const float* rstd, int rows, int H, const void* add,
+                   long ldadd, void* dx, long lddx, float* dw_acc, int dw_accumulate, float* workspace,
+                   void* stream);
+
+/* ---- RoPE in place on `nheads` consecutive heads (llama3_eagle.py:133-142; positions
+ * position_ids + pos_off as in 718-734); backward = transposed rotation. */
+int sf_rope(void* x, int dtype, long ld, int rows, int nheads, int hd, const void* cos_t, const void* sin_t,
+            const long long* pos_ids, int pos_off, int max_pos, int backward, void* stream);
+
+/* ---- SwiGLU on a fused [rows, 2I] gate|up buffer (llama3_eagle.py:1518-1549) --------------- */
+int sf_swiglu_fwd(const void* gu, int dtype, long ldgu, long rows, int I, void* act, long ldact, void* stream);
+int sf_swiglu_bwd(const void* dact, int dtype, long lddact, const void* gu, long ldgu, long rows, int I, void* dgu,
+                  long lddgu, void* stream);
+
+/* out[b1][b2][c][r] = in[b1][b2][r][c]: operand transposes for dgrad/wgrad and the K^T/V^T/Q^T/dO^T
+ * images of the attention kernels (no reference equivalent: autograd transposes are views). */
+int sf_transpose(const void* in, int dtype, long in_b1, long in_b2, long in_ld, void* out, long out_b1, long out_b2,
+                 long out_ld, int nb1, int nb2, int R, int C, void* stream);
+int sf_cast_from_f32(const float* in, long ldin, void* out, int dtype, long ldout, long rows, int C, float scale,
+                     void* stream);
+
+/* ---- TTT attention (llama3_eagle.py:745-778; lse-merge blueprint 1024-1151) ----------------
+ * q/o/dout/dq: [B*S, nh*hd] views; k0/v0 and the diagonal-branch kd[i]/vd[i]: [B*S, nkv*hd]
+ * views; v0t/k0t: [B,nkv,hd,S]; qt/dot: [B,nh,hd,S]; lse/delta: [B,nh,S] fp32; kv_len: [B]
+ * valid (right-padded) key count or NULL.  hd in {64,128}. */
+int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, const void* v0t, const void* const* kd,
+                const void* const* vd, int ndiag, const int* kv_len, void* o, long ldo, float* lse, int B, int S,
+                int nh, int nkv, int hd, float scale, void* stream);
+int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo, const void* dout, long lddo,
+                    const void* const* kd, const void* const* vd, float* const* dkd, float* const* dvd, long ldk,
+                    long lddk, int ndiag, const float* lse, float* delta, float* dq_init, int B, int S, int nh,
+                    int nkv, int hd, float scale, void* stream);
+int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long lddo, const void* k0, long ldk, const void* v0,
+                   long ldv, const void* k0t, const int* kv_len, const float* lse, const float* delta,
+                   const float* dq_init, void* dq, long lddq, int B, int S, int nh, int nkv, int hd, float scale,
+                   void* stream);
+int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long lddo, const void* qt, const void* dot,
+                    const void* k0, long ldk, const void* v0, long ldv, const int* kv_len, const float* lse,
+                    const float* delta, float* dk, float* dv, long lddk, int B, int S, int nh, int nkv, int hd,
+                    float scale, void* stream);
+
+/* ---- optimizer: BF16Optimizer.step on flat buffers (specforge/optimizer.py:95-168) ---------
+ * norm_out[0] = sqrt(sum float(g)^2 + extra_sq); adamw: clip = min(1, max_norm/(norm+1e-6))
+ * (max_norm <= 0 disables), g32 = float(g)*clip*grad_prescale, torch.optim.AdamW update of the
+ * fp32 master, param = storage(master). */
+long sf_grad_norm_workspace_floats(void);
+int sf_grad_norm(const void* g, int dtype, long n, float extra_sq, float* norm_out, float* workspace, void* stream);
+int sf_adamw_step(const void* g, int dtype, float* master, float* m, float* v, void* param, long n,
+                  const float* norm, float max_norm, float lr, float beta1, float beta2, float eps, float wd,
+                  int step, float grad_prescale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECFORGE_AMD_H */

@@ -1,0 +1,102 @@
+"""Build the native libraries of specforge_amd.
+
+* ``build_hip()``  -> specforge_amd/libsfhip.so : the product library, hipcc for gfx950.
+* ``build_emu()``  -> tests/emu/libsfhip_emu.so : the same kernel sources compiled for the
+  host against the SIMT interpreter (tests/emu/sf_emu.h).  Test infrastructure only.
+
+hipcc cross-compiles without a GPU, so both build in the CPU-only container.  Objects are
+cached by source mtime under build/.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+SOURCES = ["sf_core.hip", "sf_loss.hip", "sf_pointwise.hip", "sf_gemm.hip", "sf_attn.hip"]
+HIP_LIB = os.path.join(PKG, "libsfhip.so")
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libsfhip_emu.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HOSTCXX = os.environ.get("SF_HOSTCXX", "/opt/rocm/lib/llvm/bin/clang++")
+
+
+def _deps():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(ROOT, "include", "specforge_amd.h"))
+    hdrs.append(os.path.join(ROOT, "tests", "emu", "sf_emu.h"))
+    return [h for h in hdrs if os.path.exists(h)]
+
+
+def _stale(out, srcs):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def _build(lib, objdir, compile_cmd, link_cmd, force=False):
+    os.makedirs(objdir, exist_ok=True)
+    deps = _deps()
+    jobs = []
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + deps):
+            jobs.append(compile_cmd + ["-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(_run, jobs))
+    if force or jobs or _stale(lib, objs):
+        _run(link_cmd + objs + ["-o", lib])
+    return lib
+
+
+def build_hip(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> specforge_amd/libsfhip.so"""
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-I", CSRC,
+             "-Wno-unused-result", "-ffp-contract=fast"]
+    lib = _build(HIP_LIB, os.path.join(ROOT, "build", "hip"), [HIPCC] + flags,
+                 [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"], force)
+    if verbose:
+        print("built", lib)
+    return lib
+
+
+def build_emu(force=False, asan=False, verbose=False):
+    """host clang++ -DSF_EMU -> tests/emu/libsfhip_emu.so (SIMT interpreter build)"""
+    flags = ["-DSF_EMU", "-O2", "-g", "-std=c++17", "-fPIC", "-x", "c++", "-I", CSRC,
+             "-I", os.path.join(ROOT, "tests", "emu"), "-pthread", "-Wno-unused-result"]
+    link = [HOSTCXX, "-shared", "-fPIC", "-pthread"]
+    lib, objdir = EMU_LIB, os.path.join(ROOT, "build", "emu")
+    if asan:
+        flags += ["-fsanitize=address", "-fno-omit-frame-pointer"]
+        link += ["-fsanitize=address", "-shared-libasan"]
+        lib = EMU_LIB.replace(".so", "_asan.so")
+        objdir += "_asan"
+    lib = _build(lib, objdir, [HOSTCXX] + flags, link, force)
+    if verbose:
+        print("built", lib)
+    return lib
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["hip", "emu"]
+    if "hip" in what:
+        build_hip(force="--force" in what, verbose=True)
+    if "emu" in what:
+        build_emu(force="--force" in what, verbose=True)
+    if "asan" in what:
+        build_emu(force="--force" in what, asan=True, verbose=True)

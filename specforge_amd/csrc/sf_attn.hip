@@ -1,0 +1,670 @@
+// TTT (training-time-test) attention of the EAGLE3 draft layer, forward and backward.
+//
+// Semantics = the reference's cache branch (specforge/modeling/draft/llama3_eagle.py:745-778,
+// blueprint for the lse-merge: _FlashCachedMergeFunc 1024-1151): at unroll step k a query at
+// position t attends to the step-0 keys 0..t (causal, right-padding excluded) plus ONE key per
+// later step i=1..k -- the key at its own position t ("diagonal" branch terms, never masked);
+// softmax in fp32 over those S+k columns with scale 1/sqrt(hd); GQA without repeat_kv.
+//
+// Kernels (all MFMA 32x32x16 bf16, 4 waves per workgroup, one wave owns 32 queries / keys):
+//   attn_fwd    : flash loop over 64-key tiles of block 0 computing S^T = K.Q^T so that the
+//                 softmax row of a query is lane-local, O^T += V^T.P^T with V^T read from a
+//                 pre-transposed copy; the diagonal terms are folded in as k extra online-
+//                 softmax updates in registers in the epilogue (no second pass over O).
+//   attn_bwd_pre: delta = rowsum(dO*O) and the gradients of the diagonal terms (dq_init,
+//                 dK_i, dV_i accumulated over the GQA group) -- HBM-bound row kernel.
+//   attn_bwd_dq : per 128-query block, dQ^T += K^T.dS^T over the causal key tiles.
+//   attn_bwd_dkv: per 128-key block of one kv head, loops the group's query heads and the
+//                 query tiles at/after the diagonal; dK^T += Q^T.dS, dV^T += dO^T.P; owns its
+//                 keys exclusively, so dK/dV accumulate into fp32 buffers without atomics.
+// Tiles are staged HBM -> LDS by 16-byte LDS-DMA with an XOR chunk swizzle on the source
+// address (same scheme as sf_gemm.hip).
+#include "sf_api_internal.h"
+#include "sf_util.h"
+
+namespace {
+
+#ifdef SF_EMU
+static const sf_bf16 sf_zero16a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+__device__ const sf_bf16 sf_zero16a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kNegBig = -1.0e30f;
+constexpr int kMaxDiag = 8;
+
+struct AttnFwdArgs {
+    const sf_bf16* q; long ldq;        // [B*S, nh*hd] view, row stride ldq
+    const sf_bf16* k0; long ldk;       // step-0 keys [B*S, nkv*hd] view
+    const sf_bf16* v0t;                // step-0 values transposed: [B, nkv, hd, S] contiguous
+    const sf_bf16* kd[kMaxDiag];       // diagonal-branch keys of steps 1..ndiag (views, stride ldk)
+    const sf_bf16* vd[kMaxDiag];       // diagonal-branch values
+    int ndiag;
+    const int* kv_len;                 // [B] number of valid (non-padding) keys
+    sf_bf16* o; long ldo;              // [B*S, nh*hd]
+    float* lse;                        // [B, nh, S] natural-log lse over all S+k columns
+    int B, S, nh, nkv;
+    float scale;
+};
+
+// ---- LDS tile staging -------------------------------------------------------
+// natural tile: 64 rows (keys / queries) x HD, row-major, 16-byte chunks XOR-swizzled by row&7
+template <int HD>
+SF_DEVICE void stage_rows64(char* lds, const sf_bf16* base, long ld, int row0, int nrows_valid, int wave, int lane) {
+    constexpr int CPR = HD / 8;            // chunks per row
+    constexpr int RPI = 64 / CPR;          // rows per wave-instruction (1 KiB)
+    constexpr int NI = 64 / RPI / 4;       // instructions per wave
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+        const int rr = (wave * NI + t) * RPI + lane / CPR;
+        const int pc = lane % CPR;
+        const int lc = pc ^ (rr & 7);
+        const sf_bf16* src = (row0 + rr < nrows_valid) ? base + (long)(row0 + rr) * ld + lc * 8 : sf_zero16a;
+        sf_glds16(src, lds + rr * (HD * 2) + pc * 16);
+    }
+}
+// transposed tile: HD rows (d) x 64 columns (keys / queries) from a [HD][S] matrix
+template <int HD>
+SF_DEVICE void stage_cols64(char* lds, const sf_bf16* base, int S, int col0, int wave, int lane) {
+    constexpr int NI = HD / 8 / 4;  // 8 rows of 128 B per instruction
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+        const int rr = (wave * NI + t) * 8 + (lane >> 3);
+        const int pc = lane & 7;
+        const int lc = pc ^ (rr & 7);
+        const int col = col0 + lc * 8;
+        const sf_bf16* src = (col < S) ? base + (long)rr * S + col : sf_zero16a;
+        sf_glds16(src, lds + rr * 128 + pc * 16);
+    }
+}
+// A fragment (32 rows x 16 k) from a natural tile: row = r0 + (lane&31), k = 16*ks + 8*(lane>>5)
+template <int HD>
+SF_DEVICE sf_v8s frag_rows(const char* lds, int r0, int ks, int lane) {
+    const int row = r0 + (lane & 31);
+    const int lc = 2 * ks + (lane >> 5);
+    return *reinterpret_cast<const sf_v8s*>(lds + row * (HD * 2) + ((lc ^ (row & 7)) << 4));
+}
+// A fragment from a transposed tile for the "C-layout as B operand" contraction: row d = d0+(lane&31),
+// k-slots = columns {c0 + 4*hi + 0..3} and {c0 + 8 + 4*hi + 0..3}  (c0 multiple of 16)
+SF_DEVICE sf_v8s frag_cols(const char* lds, int d0, int c0, int lane) {
+    const int row = d0 + (lane & 31);
+    const int hi = lane >> 5;
+    const int ch = c0 >> 3;  // 16-byte chunk of the first run; second run is the next chunk
+    const sf_v4s lo = *reinterpret_cast<const sf_v4s*>(lds + row * 128 + (((ch) ^ (row & 7)) << 4) + hi * 8);
+    const sf_v4s up = *reinterpret_cast<const sf_v4s*>(lds + row * 128 + (((ch + 1) ^ (row & 7)) << 4) + hi * 8);
+    return sf_v8s{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+}
+SF_DEVICE sf_v8s pack_bf16x8(const sf_v16f& p, int r0) {
+    sf_v8s o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (short)sf_f2bf(p[r0 + i]);
+    return o;
+}
+// row index inside a 32x32 MFMA result tile held by this lane in register r
+SF_DEVICE int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+SF_DEVICE float dot8(sf_v8s a, sf_v8s b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += sf_bf2f((sf_bf16)a[i]) * sf_bf2f((sf_bf16)b[i]);
+    return s;
+}
+
+// ------------------------------------------------------------------ forward
+template <int HD>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_fwd_kernel(AttnFwdArgs p) {
+    constexpr int KS = HD / 16, DB = HD / 32;
+    SF_DYN_SMEM(smem);
+    char* lds_k = smem;                 // [64][HD]
+    char* lds_vt = smem + 64 * HD * 2;  // [HD][64]
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hi = lane >> 5;
+    const int qb0 = (int)blockIdx.x * 128, h = (int)blockIdx.y, b = (int)blockIdx.z;
+    const int g = h / (p.nh / p.nkv);
+    const int S = p.S;
+    const int kvlen = p.kv_len ? p.kv_len[b] : S;
+    const int qw0 = qb0 + wave * 32;
+    const int qi = qw0 + c;                       // this lane's query position
+    const bool qok = qi < S;
+    const long qrow = (long)b * S + (qok ? qi : S - 1);
+    const float sc = p.scale * kLog2e;
+
+    sf_v8s qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const sf_v8s*>(p.q + qrow * p.ldq + h * HD + 16 * ks + 8 * hi);
+
+    sf_v16f acc_o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
+    float m = kNegBig, lpart = 0.f;
+
+    const sf_bf16* kbase = p.k0 + (long)b * S * p.ldk + g * HD;
+    const sf_bf16* vtbase = p.v0t + ((long)b * p.nkv + g) * HD * S;
+    int kend = qb0 + 128 < S ? qb0 + 128 : S;  // causal upper bound for this block
+    if (kvlen < kend) kend = kvlen;
+    const int ntiles = (kend + 63) / 64;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int key0 = kt * 64;
+        sf_syncthreads();  // previous tile fully consumed
+        stage_rows64<HD>(lds_k, kbase, p.ldk, key0, S, wave, lane);
+        stage_cols64<HD>(lds_vt, vtbase, S, key0, wave, lane);
+        sf_wait_vm0();
+        sf_syncthreads();
+        if (key0 > qw0 + 31) continue;  // whole tile above this wave's diagonal (wave-uniform)
+        const bool need_mask = (key0 + 63 > qw0) || (key0 + 63 >= kvlen);
+        sf_v16f s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s[kb] = sf_mfma32(frag_rows<HD>(lds_k, kb * 32, ks, lane), qf[ks], s[kb]);
+        }
+        float mt = kNegBig;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[kb][r] * sc;
+                if (need_mask) {
+                    const int kk = key0 + kb * 32 + crow(r, hi);
+                    if (kk > qi || kk >= kvlen) v = kNegBig;
+                }
+                s[kb][r] = v;
+                mt = fmaxf(mt, v);
+            }
+        mt = fmaxf(mt, sf_shfl_xor(mt, 32));
+        const float mn = fmaxf(m, mt);
+        const float alpha = sf_exp2(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = s[kb][r];
+                const float e = (v <= kNegBig) ? 0.f : sf_exp2(v - mn);
+                s[kb][r] = e;
+                ps += e;
+            }
+        lpart = lpart * alpha + ps;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                const sf_v8s pf = pack_bf16x8(s[kb], 8 * jp);
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+                    acc_o[d] = sf_mfma32(frag_cols(lds_vt, d * 32, kb * 32 + 16 * jp, lane), pf, acc_o[d]);
+            }
+    }
+    float l = lpart + sf_shfl_xor(lpart, 32);
+
+    // diagonal branch terms: one extra key per later TTT step at the query's own position
+    for (int i = 0; i < p.ndiag; ++i) {
+        const sf_bf16* kr = p.kd[i] + qrow * p.ldk + g * HD;
+        const sf_bf16* vr = p.vd[i] + qrow * p.ldk + g * HD;
+        float dp = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            dp += dot8(qf[ks], *reinterpret_cast<const sf_v8s*>(kr + 16 * ks + 8 * hi));
+        dp += sf_shfl_xor(dp, 32);
+        const float s2 = dp * sc;
+        const float mn = fmaxf(m, s2);
+        const float alpha = sf_exp2(m - mn);
+        const float e = sf_exp2(s2 - mn);
+        m = mn;
+        l = l * alpha + e;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const sf_v4s vv = *reinterpret_cast<const sf_v4s*>(vr + d * 32 + 8 * j + 4 * hi);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc_o[d][4 * j + t] = acc_o[d][4 * j + t] * alpha + e * sf_bf2f((sf_bf16)vv[t]);
+            }
+    }
+    if (!qok) return;
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    sf_bf16* orow = p.o + qrow * p.ldo + h * HD;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sf_v4s ov;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ov[t] = (short)sf_f2bf(acc_o[d][4 * j + t] * inv);
+            *reinterpret_cast<sf_v4s*>(orow + d * 32 + 8 * j + 4 * hi) = ov;
+        }
+    if (hi == 0) p.lse[((long)b * p.nh + h) * S + qi] = l > 0.f ? (m + log2f(l)) * kLn2 : kNegBig;
+}
+
+// ------------------------------------------------------ backward: preprocess
+struct AttnBwdPreArgs {
+    const sf_bf16* q; long ldq;
+    const sf_bf16* o; long ldo;
+    const sf_bf16* dout; long lddo;
+    const sf_bf16* kd[kMaxDiag];
+    const sf_bf16* vd[kMaxDiag];
+    float* dkd[kMaxDiag];  // fp32 accumulators [B*S, nkv*hd] (+=)
+    float* dvd[kMaxDiag];
+    long ldk, lddk;
+    int ndiag;
+    const float* lse;   // [B, nh, S]
+    float* delta;       // [B, nh, S]
+    float* dq_init;     // [B*S, nh*hd] fp32, written when ndiag > 0
+    int B, S, nh, nkv, hd;
+    float scale;
+};
+
+// one workgroup per token row; wave w handles kv groups w, w+4, ...; lane owns hd/64 consecutive d
+template <int HD>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_pre_kernel(AttnBwdPreArgs p) {
+    constexpr int E = HD / 64;  // elements per lane (1 or 2)
+    const int row = (int)blockIdx.x, lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int b = row / p.S, t = row - b * p.S;
+    const int nrep = p.nh / p.nkv;
+    for (int g = wave; g < p.nkv; g += 4) {
+        float dk[kMaxDiag][E], dv[kMaxDiag][E], kv[kMaxDiag][E], vv[kMaxDiag][E];
+#pragma unroll
+        for (int i = 0; i < kMaxDiag; ++i)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                dk[i][e] = 0.f; dv[i][e] = 0.f; kv[i][e] = 0.f; vv[i][e] = 0.f;
+                if (i < p.ndiag) {
+                    kv[i][e] = sf_bf2f(p.kd[i][(long)row * p.ldk + g * HD + lane * E + e]);
+                    vv[i][e] = sf_bf2f(p.vd[i][(long)row * p.ldk + g * HD + lane * E + e]);
+                }
+            }
+        for (int hh = 0; hh < nrep; ++hh) {
+            const int h = g * nrep + hh;
+            float qv[E], ov[E], dov[E];
+            float dl = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int col = h * HD + lane * E + e;
+                qv[e] = sf_bf2f(p.q[(long)row * p.ldq + col]);
+                ov[e] = sf_bf2f(p.o[(long)row * p.ldo + col]);
+                dov[e] = sf_bf2f(p.dout[(long)row * p.lddo + col]);
+                dl += ov[e] * dov[e];
+            }
+            dl = sf_wave_sum(dl);
+            const long li = ((long)b * p.nh + h) * p.S + t;
+            if (lane == 0) p.delta[li] = dl;
+            if (p.ndiag > 0) {
+                const float lse = p.lse[li];
+                float dq[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) dq[e] = 0.f;
+#pragma unroll
+                for (int i = 0; i < kMaxDiag; ++i) {
+                    if (i < p.ndiag) {
+                        float sdot = 0.f, pdot = 0.f;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) { sdot += qv[e] * kv[i][e]; pdot += dov[e] * vv[i][e]; }
+                        sdot = sf_wave_sum(sdot);
+                        pdot = sf_wave_sum(pdot);
+                        const float pi = sf_exp(sdot * p.scale - lse);
+                        const float ds = pi * (pdot - dl) * p.scale;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            dq[e] += ds * kv[i][e];
+                            dk[i][e] += ds * qv[e];
+                            dv[i][e] += pi * dov[e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) p.dq_init[(long)row * (p.nh * HD) + h * HD + lane * E + e] = dq[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxDiag; ++i)
+            if (i < p.ndiag) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const long idx = (long)row * p.lddk + g * HD + lane * E + e;
+                    p.dkd[i][idx] += dk[i][e];
+                    p.dvd[i][idx] += dv[i][e];
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------- backward: dQ
+struct AttnBwdArgs {
+    const sf_bf16* q; long ldq;      // natural
+    const sf_bf16* dout; long lddo;  // natural
+    const sf_bf16* qt;               // [B, nh, hd, S]   (dkv kernel)
+    const sf_bf16* dot;              // [B, nh, hd, S]   (dkv kernel)
+    const sf_bf16* k0; long ldk;     // natural
+    const sf_bf16* v0; long ldv;     // natural
+    const sf_bf16* k0t;              // [B, nkv, hd, S]  (dq kernel)
+    const int* kv_len;
+    const float* lse;                // [B, nh, S]
+    const float* delta;              // [B, nh, S]
+    const float* dq_init;            // fp32 [B*S, nh*hd] or null
+    sf_bf16* dq; long lddq;          // out (dq kernel)
+    float* dk; float* dv; long lddk; // fp32 accumulators (+=) [B*S, nkv*hd]  (dkv kernel)
+    int B, S, nh, nkv;
+    float scale;
+};
+
+template <int HD>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dq_kernel(AttnBwdArgs p) {
+    constexpr int KS = HD / 16, DB = HD / 32;
+    SF_DYN_SMEM(smem);
+    char* lds_k = smem;                  // [64][HD]
+    char* lds_v = smem + 64 * HD * 2;    // [64][HD]
+    char* lds_kt = smem + 128 * HD * 2;  // [HD][64]
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hi = lane >> 5;
+    const int qb0 = (int)blockIdx.x * 128, h = (int)blockIdx.y, b = (int)blockIdx.z;
+    const int g = h / (p.nh / p.nkv);
+    const int S = p.S;
+    const int kvlen = p.kv_len ? p.kv_len[b] : S;
+    const int qw0 = qb0 + wave * 32;
+    const int qi = qw0 + c;
+    const bool qok = qi < S;
+    const long qrow = (long)b * S + (qok ? qi : S - 1);
+    const float sc = p.scale * kLog2e;
+    const long li = ((long)b * p.nh + h) * S + (qok ? qi : S - 1);
+    const float lse2 = p.lse[li] * kLog2e;
+    const float dlt = p.delta[li];
+
+    sf_v8s qf[KS], dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = *reinterpret_cast<const sf_v8s*>(p.q + qrow * p.ldq + h * HD + 16 * ks + 8 * hi);
+        dof[ks] = *reinterpret_cast<const sf_v8s*>(p.dout + qrow * p.lddo + h * HD + 16 * ks + 8 * hi);
+    }
+    sf_v16f acc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+    const sf_bf16* kbase = p.k0 + (long)b * S * p.ldk + g * HD;
+    const sf_bf16* vbase = p.v0 + (long)b * S * p.ldv + g * HD;
+    const sf_bf16* ktbase = p.k0t + ((long)b * p.nkv + g) * HD * S;
+    int kend = qb0 + 128 < S ? qb0 + 128 : S;
+    if (kvlen < kend) kend = kvlen;
+    const int ntiles = (kend + 63) / 64;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int key0 = kt * 64;
+        sf_syncthreads();
+        stage_rows64<HD>(lds_k, kbase, p.ldk, key0, S, wave, lane);
+        stage_rows64<HD>(lds_v, vbase, p.ldv, key0, S, wave, lane);
+        stage_cols64<HD>(lds_kt, ktbase, S, key0, wave, lane);
+        sf_wait_vm0();
+        sf_syncthreads();
+        if (key0 > qw0 + 31) continue;
+        sf_v16f s[2], dp[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[kb][r] = 0.f; dp[kb][r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s[kb] = sf_mfma32(frag_rows<HD>(lds_k, kb * 32, ks, lane), qf[ks], s[kb]);
+                dp[kb] = sf_mfma32(frag_rows<HD>(lds_v, kb * 32, ks, lane), dof[ks], dp[kb]);
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = key0 + kb * 32 + crow(r, hi);
+                const bool ok = (kk <= qi) && (kk < kvlen);
+                const float pv = ok ? sf_exp2(s[kb][r] * sc - lse2) : 0.f;
+                s[kb][r] = pv * (dp[kb][r] - dlt);  // dS^T
+            }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                const sf_v8s df = pack_bf16x8(s[kb], 8 * jp);
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+                    acc[d] = sf_mfma32(frag_cols(lds_kt, d * 32, kb * 32 + 16 * jp, lane), df, acc[d]);
+            }
+    }
+    if (!qok) return;
+    sf_bf16* orow = p.dq + qrow * p.lddq + h * HD;
+    const float* irow = p.dq_init ? p.dq_init + qrow * ((long)p.nh * HD) + h * HD : nullptr;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = d * 32 + 8 * j + 4 * hi;
+            sf_v4s ov;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v = acc[d][4 * j + t] * p.scale;
+                if (irow) v += irow[col + t];
+                ov[t] = (short)sf_f2bf(v);
+            }
+            *reinterpret_cast<sf_v4s*>(orow + col) = ov;
+        }
+}
+
+// ---------------------------------------------------------- backward: dK, dV
+// LDS: Q [64][HD], dO [64][HD], Q^T [HD][64], dO^T [HD][64], lse2[64], delta[64]
+template <int HD>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
+    constexpr int KS = HD / 16, DB = HD / 32;
+    SF_DYN_SMEM(smem);
+    char* lds_q = smem;
+    char* lds_do = smem + 64 * HD * 2;
+    char* lds_qt = smem + 128 * HD * 2;
+    char* lds_dot = smem + 192 * HD * 2;
+    float* lds_lse = reinterpret_cast<float*>(smem + 256 * HD * 2);
+    float* lds_dlt = lds_lse + 64;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hi = lane >> 5;
+    const int kb0 = (int)blockIdx.x * 128, g = (int)blockIdx.y, b = (int)blockIdx.z;
+    const int S = p.S, nrep = p.nh / p.nkv;
+    const int kvlen = p.kv_len ? p.kv_len[b] : S;
+    const int kw0 = kb0 + wave * 32;
+    const int ki = kw0 + c;  // this lane's key (column of S)
+    const bool kok = ki < S;
+    const long krow = (long)b * S + (kok ? ki : S - 1);
+    const float sc = p.scale * kLog2e;
+
+    sf_v8s kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *reinterpret_cast<const sf_v8s*>(p.k0 + krow * p.ldk + g * HD + 16 * ks + 8 * hi);
+        vf[ks] = *reinterpret_cast<const sf_v8s*>(p.v0 + krow * p.ldv + g * HD + 16 * ks + 8 * hi);
+    }
+    sf_v16f acc_dk[DB], acc_dv[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_dk[d][r] = 0.f; acc_dv[d][r] = 0.f; }
+
+    const bool block_live = kb0 < kvlen;  // keys at/after kv_len never receive probability mass
+    const int qt_first = kb0 / 64;
+    const int nqt = (S + 63) / 64;
+    if (block_live)
+        for (int hh = 0; hh < nrep; ++hh) {
+            const int h = g * nrep + hh;
+            const sf_bf16* qbase = p.q + (long)b * S * p.ldq + h * HD;
+            const sf_bf16* dobase = p.dout + (long)b * S * p.lddo + h * HD;
+            const sf_bf16* qtbase = p.qt + ((long)b * p.nh + h) * HD * S;
+            const sf_bf16* dotbase = p.dot + ((long)b * p.nh + h) * HD * S;
+            const float* lsebase = p.lse + ((long)b * p.nh + h) * S;
+            const float* dltbase = p.delta + ((long)b * p.nh + h) * S;
+            for (int qt = qt_first; qt < nqt; ++qt) {
+                const int q0 = qt * 64;
+                sf_syncthreads();
+                stage_rows64<HD>(lds_q, qbase, p.ldq, q0, S, wave, lane);
+                stage_rows64<HD>(lds_do, dobase, p.lddo, q0, S, wave, lane);
+                stage_cols64<HD>(lds_qt, qtbase, S, q0, wave, lane);
+                stage_cols64<HD>(lds_dot, dotbase, S, q0, wave, lane);
+                if (tid < 64) {
+                    const int qq = q0 + tid;
+                    lds_lse[tid] = qq < S ? lsebase[qq] * kLog2e : 0.f;
+                    lds_dlt[tid] = qq < S ? dltbase[qq] : 0.f;
+                }
+                sf_wait_vm0();
+                sf_syncthreads();
+                if (q0 + 63 < kw0) continue;  // every query of the tile is before this wave's keys
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    sf_v16f s, dp;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        s = sf_mfma32(frag_rows<HD>(lds_q, qb * 32, ks, lane), kf[ks], s);
+                        dp = sf_mfma32(frag_rows<HD>(lds_do, qb * 32, ks, lane), vf[ks], dp);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ql = qb * 32 + crow(r, hi);
+                        const int qq = q0 + ql;
+                        const bool ok = (ki <= qq) && (ki < kvlen) && (qq < S);
+                        const float pv = ok ? sf_exp2(s[r] * sc - lds_lse[ql]) : 0.f;
+                        s[r] = pv;                            // P
+                        dp[r] = pv * (dp[r] - lds_dlt[ql]);   // dS
+                    }
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        const sf_v8s pf = pack_bf16x8(s, 8 * jp);
+                        const sf_v8s df = pack_bf16x8(dp, 8 * jp);
+#pragma unroll
+                        for (int d = 0; d < DB; ++d) {
+                            acc_dv[d] = sf_mfma32(frag_cols(lds_dot, d * 32, qb * 32 + 16 * jp, lane), pf, acc_dv[d]);
+                            acc_dk[d] = sf_mfma32(frag_cols(lds_qt, d * 32, qb * 32 + 16 * jp, lane), df, acc_dk[d]);
+                        }
+                    }
+                }
+            }
+        }
+    if (!kok || !block_live) return;
+    float* dkrow = p.dk + krow * p.lddk + g * HD;
+    float* dvrow = p.dv + krow * p.lddk + g * HD;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = d * 32 + 8 * j + 4 * hi;
+            sf_v4f a = *reinterpret_cast<const sf_v4f*>(dkrow + col);
+            sf_v4f bb = *reinterpret_cast<const sf_v4f*>(dvrow + col);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] += acc_dk[d][4 * j + t] * p.scale;
+                bb[t] += acc_dv[d][4 * j + t];
+            }
+            *reinterpret_cast<sf_v4f*>(dkrow + col) = a;
+            *reinterpret_cast<sf_v4f*>(dvrow + col) = bb;
+        }
+}
+
+}  // namespace
+
+#define SF_HD_DISPATCH(hd, CALL)                                  \
+    do {                                                          \
+        if ((hd) == 128) { constexpr int HD = 128; CALL; }        \
+        else if ((hd) == 64) { constexpr int HD = 64; CALL; }     \
+        else SF_CHECK_ARG(false, "head_dim must be 64 or 128");   \
+    } while (0)
+
+extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, const void* v0t, const void* const* kd,
+                           const void* const* vd, int ndiag, const int* kv_len, void* o, long ldo, float* lse, int B,
+                           int S, int nh, int nkv, int hd, float scale, void* stream) {
+    SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_fwd: bad shape");
+    SF_CHECK_ARG(S % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0, "sf_attn_fwd: S and strides must be multiples of 8");
+    SF_CHECK_ARG(ndiag >= 0 && ndiag <= kMaxDiag, "sf_attn_fwd: at most 8 diagonal branches");
+    AttnFwdArgs p;
+    memset(&p, 0, sizeof(p));
+    p.q = (const sf_bf16*)q; p.ldq = ldq;
+    p.k0 = (const sf_bf16*)k0; p.ldk = ldk;
+    p.v0t = (const sf_bf16*)v0t;
+    for (int i = 0; i < ndiag; ++i) { p.kd[i] = (const sf_bf16*)kd[i]; p.vd[i] = (const sf_bf16*)vd[i]; }
+    p.ndiag = ndiag; p.kv_len = kv_len;
+    p.o = (sf_bf16*)o; p.ldo = ldo; p.lse = lse;
+    p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.scale = scale;
+    dim3 grid((S + 127) / 128, nh, B);
+    SF_HD_DISPATCH(hd, SF_LAUNCH((attn_fwd_kernel<HD>), grid, dim3(256), 128 * HD * 2, stream, p));
+    return sf_check_launch("sf_attn_fwd");
+}
+
+extern "C" int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo, const void* dout, long lddo,
+                               const void* const* kd, const void* const* vd, float* const* dkd, float* const* dvd,
+                               long ldk, long lddk, int ndiag, const float* lse, float* delta, float* dq_init, int B,
+                               int S, int nh, int nkv, int hd, float scale, void* stream) {
+    SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_pre: bad shape");
+    SF_CHECK_ARG(ndiag >= 0 && ndiag <= kMaxDiag, "sf_attn_bwd_pre: at most 8 diagonal branches");
+    SF_CHECK_ARG(ndiag == 0 || dq_init, "sf_attn_bwd_pre: dq_init required with diagonal branches");
+    AttnBwdPreArgs p;
+    memset(&p, 0, sizeof(p));
+    p.q = (const sf_bf16*)q; p.ldq = ldq;
+    p.o = (const sf_bf16*)o; p.ldo = ldo;
+    p.dout = (const sf_bf16*)dout; p.lddo = lddo;
+    for (int i = 0; i < ndiag; ++i) {
+        p.kd[i] = (const sf_bf16*)kd[i]; p.vd[i] = (const sf_bf16*)vd[i];
+        p.dkd[i] = dkd[i]; p.dvd[i] = dvd[i];
+    }
+    p.ldk = ldk; p.lddk = lddk; p.ndiag = ndiag;
+    p.lse = lse; p.delta = delta; p.dq_init = dq_init;
+    p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.hd = hd; p.scale = scale;
+    SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_pre_kernel<HD>), dim3(B * S), dim3(256), 0, stream, p));
+    return sf_check_launch("sf_attn_bwd_pre");
+}
+
+static int fill_bwd_args(AttnBwdArgs& p, const void* q, long ldq, const void* dout, long lddo, const void* qt,
+                         const void* dot, const void* k0, long ldk, const void* v0, long ldv, const void* k0t,
+                         const int* kv_len, const float* lse, const float* delta, const float* dq_init, void* dq,
+                         long lddq, float* dk, float* dv, long lddk, int B, int S, int nh, int nkv, float scale) {
+    memset(&p, 0, sizeof(p));
+    p.q = (const sf_bf16*)q; p.ldq = ldq;
+    p.dout = (const sf_bf16*)dout; p.lddo = lddo;
+    p.qt = (const sf_bf16*)qt; p.dot = (const sf_bf16*)dot;
+    p.k0 = (const sf_bf16*)k0; p.ldk = ldk;
+    p.v0 = (const sf_bf16*)v0; p.ldv = ldv;
+    p.k0t = (const sf_bf16*)k0t;
+    p.kv_len = kv_len; p.lse = lse; p.delta = delta; p.dq_init = dq_init;
+    p.dq = (sf_bf16*)dq; p.lddq = lddq;
+    p.dk = dk; p.dv = dv; p.lddk = lddk;
+    p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.scale = scale;
+    return 0;
+}
+
+extern "C" int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long lddo, const void* k0, long ldk,
+                              const void* v0, long ldv, const void* k0t, const int* kv_len, const float* lse,
+                              const float* delta, const float* dq_init, void* dq, long lddq, int B, int S, int nh,
+                              int nkv, int hd, float scale, void* stream) {
+    SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_dq: bad shape");
+    SF_CHECK_ARG(S % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0,
+                 "sf_attn_bwd_dq: S and strides must be multiples of 8");
+    AttnBwdArgs p;
+    fill_bwd_args(p, q, ldq, dout, lddo, nullptr, nullptr, k0, ldk, v0, ldv, k0t, kv_len, lse, delta, dq_init, dq, lddq,
+                  nullptr, nullptr, 0, B, S, nh, nkv, scale);
+    dim3 grid((S + 127) / 128, nh, B);
+    SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_dq_kernel<HD>), grid, dim3(256), 192 * HD * 2, stream, p));
+    return sf_check_launch("sf_attn_bwd_dq");
+}
+
+extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long lddo, const void* qt, const void* dot,
+                               const void* k0, long ldk, const void* v0, long ldv, const int* kv_len, const float* lse,
+                               const float* delta, float* dk, float* dv, long lddk, int B, int S, int nh, int nkv,
+                               int hd, float scale, void* stream) {
+    SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_dkv: bad shape");
+    SF_CHECK_ARG(S % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddk % 4 == 0,
+                 "sf_attn_bwd_dkv: S and strides must be multiples of 8");
+    AttnBwdArgs p;
+    fill_bwd_args(p, q, ldq, dout, lddo, qt, dot, k0, ldk, v0, ldv, nullptr, kv_len, lse, delta, nullptr, nullptr, 0, dk,
+                  dv, lddk, B, S, nh, nkv, scale);
+    dim3 grid((S + 127) / 128, nkv, B);
+    SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_dkv_kernel<HD>), grid, dim3(256), 256 * HD * 2 + 512, stream, p));
+    return sf_check_launch("sf_attn_bwd_dkv");
+}

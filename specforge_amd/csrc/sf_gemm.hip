@@ -1,0 +1,199 @@
+// bf16 MFMA GEMM for the draft layer's dense projections (the only GEMM-shaped work on the
+// path: fc, q/k/v, o, gate/up, down, lm_head, teacher head -- SURVEY.md 2.2 G1-G9).
+//
+//   C[M,N] = alpha * A[M,K] . B[N,K]^T  (+ beta * C)  (+ R[M,N])       A, B bf16, fp32 accumulate
+//
+// "NT" form: both operands are K-contiguous, which is what nn.Linear's forward is
+// (x[M,K] . W[N,K]^T, llama3_eagle.py:555-566,1513-1515,1674-1693).  dgrad and wgrad are
+// brought to the same form by the caller with pre-transposed operands (sf_transpose).
+//
+// Structure (CDNA4): 128x128 output tile per 256-thread workgroup (2x2 waves, each 64x64 as
+// 4x4 mfma_f32_16x16x32_bf16 tiles, operands swapped so that a lane owns 4 consecutive
+// output columns), BK = 64, operands staged HBM -> LDS with 16-byte LDS-DMA
+// (global_load_lds_dwordx4) into a double buffer; bank conflicts are broken by an XOR
+// swizzle of the 16-byte chunk index applied on the global source address and again on
+// the ds_read_b128 address (the LDS image itself must stay lane-linear for LDS-DMA).
+// Workgroup ids are remapped so that each XCD (private L2) walks a compact group of tiles.
+#include "sf_api_internal.h"
+#include "sf_util.h"
+
+namespace {
+
+#ifdef SF_EMU
+static const sf_bf16 sf_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+__device__ const sf_bf16 sf_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kStageBytes = (BM + BN) * BK * 2;  // 32 KiB
+
+struct GemmArgs {
+    const sf_bf16* A;
+    long lda;
+    const sf_bf16* B;
+    long ldb;
+    void* C;
+    long ldc;
+    const sf_bf16* R;
+    long ldr;
+    int M, N, K;
+    float alpha, beta;
+    int tiles_m, tiles_n;
+};
+
+// XCD-aware, grouped tile order: blocks land on XCD (id % 8); give every XCD a contiguous
+// run of the tile sequence (bijective for any grid size), and order the sequence in
+// column groups of 8 tile-rows so one XCD's L2 sees few distinct A/B panels.
+SF_DEVICE void tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    const int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int g = seq / per_group;
+    const int first_m = g * GM;
+    const int gsize = (tiles_m - first_m < GM) ? (tiles_m - first_m) : GM;
+    const int in_g = seq - g * per_group;
+    tm = first_m + in_g % gsize;
+    tn = in_g / gsize;
+}
+
+template <int OUT_F32>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) gemm_nt_kernel(GemmArgs p) {
+    SF_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    int tm, tn;
+    tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nkt = (p.K + BK - 1) / BK;
+
+    sf_v4f acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
+
+    auto stage = [&](int buf, int kt) {
+        char* la = smem + buf * kStageBytes;
+        char* lb = la + BM * BK * 2;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int rr = (wave * 4 + t) * 8 + (lane >> 3);
+            const int pc = lane & 7;
+            const int kk = k0 + ((pc ^ (rr & 7)) << 3);
+            const int gm = m0 + rr, gn = n0 + rr;
+            const sf_bf16* sa = (gm < p.M && kk < p.K) ? p.A + (long)gm * p.lda + kk : sf_zero16;
+            const sf_bf16* sb = (gn < p.N && kk < p.K) ? p.B + (long)gn * p.ldb + kk : sf_zero16;
+            sf_glds16(sa, la + rr * 128 + pc * 16);
+            sf_glds16(sb, lb + rr * 128 + pc * 16);
+        }
+    };
+
+    stage(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        sf_wait_vm0();
+        sf_syncthreads();
+        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+        const char* la = smem + (kt & 1) * kStageBytes;
+        const char* lb = la + BM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            sf_v8s a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wr * 64 + i * 16 + (lane & 15);
+                const int rb = wc * 64 + i * 16 + (lane & 15);
+                const int lc = ks * 4 + (lane >> 4);
+                a[i] = *reinterpret_cast<const sf_v8s*>(la + ra * 128 + ((lc ^ (ra & 7)) << 4));
+                b[i] = *reinterpret_cast<const sf_v8s*>(lb + rb * 128 + ((lc ^ (rb & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = sf_mfma16(b[j], a[i], acc[i][j]);  // D[n][m]
+        }
+    }
+
+    // epilogue: lane owns C[m][n .. n+3], m = 16-row tile row (lane&15), n = 4*(lane>>4)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + 4 * (lane >> 4);
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r];
+            const bool full = (n + 3 < p.N);
+            if (OUT_F32) {
+                float* c = (float*)p.C + (long)m * p.ldc + n;
+                if (full) {
+                    if (p.beta != 0.f) {
+                        sf_v4f o = *reinterpret_cast<const sf_v4f*>(c);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += p.beta * o[r];
+                    }
+                    *reinterpret_cast<sf_v4f*>(c) = sf_v4f{v[0], v[1], v[2], v[3]};
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = v[r] + (p.beta != 0.f ? p.beta * c[r] : 0.f);
+                }
+            } else {
+                sf_bf16* c = (sf_bf16*)p.C + (long)m * p.ldc + n;
+                if (full) {
+                    if (p.beta != 0.f) {
+                        sf_v4s o = *reinterpret_cast<const sf_v4s*>(c);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += p.beta * sf_bf2f((sf_bf16)o[r]);
+                    }
+                    if (p.R) {  // round the projection first, then add the residual (bf16 + bf16)
+                        sf_v4s rr = *reinterpret_cast<const sf_v4s*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = sf_round_bf(v[r]) + sf_bf2f((sf_bf16)rr[r]);
+                    }
+                    sf_v4s o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (short)sf_f2bf(v[r]);
+                    *reinterpret_cast<sf_v4s*>(c) = o;
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                        float t = v[r] + (p.beta != 0.f ? p.beta * sf_bf2f(c[r]) : 0.f);
+                        if (p.R) t = sf_round_bf(t) + sf_bf2f(p.R[(long)m * p.ldr + n + r]);
+                        c[r] = sf_f2bf(t);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
+                          int K, float alpha, float beta, const void* R, long ldr, void* stream) {
+    SF_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sf_gemm_nt: negative shape");
+    SF_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sf_gemm_nt: K, lda, ldb must be multiples of 8 (16-byte rows)");
+    SF_CHECK_ARG(ldc % 4 == 0 && ldr % 4 == 0, "sf_gemm_nt: ldc, ldr must be multiples of 4");
+    SF_CHECK_ARG(c_dtype == SF_BF16 || c_dtype == SF_F32, "sf_gemm_nt: c_dtype");
+    SF_CHECK_ARG(!(R && c_dtype == SF_F32), "sf_gemm_nt: residual epilogue is bf16-only");
+    if (M == 0 || N == 0) return 0;
+    GemmArgs p;
+    p.A = (const sf_bf16*)A; p.lda = lda;
+    p.B = (const sf_bf16*)B; p.ldb = ldb;
+    p.C = C; p.ldc = ldc;
+    p.R = (const sf_bf16*)R; p.ldr = ldr;
+    p.M = M; p.N = N; p.K = K;
+    p.alpha = alpha; p.beta = beta;
+    p.tiles_m = (M + BM - 1) / BM;
+    p.tiles_n = (N + BN - 1) / BN;
+    const long nblk = (long)p.tiles_m * p.tiles_n;
+    SF_CHECK_ARG(nblk < (1L << 31), "sf_gemm_nt: grid too large");
+    if (c_dtype == SF_F32)
+        SF_LAUNCH((gemm_nt_kernel<1>), dim3((unsigned)nblk), dim3(256), 2 * kStageBytes, stream, p);
+    else
+        SF_LAUNCH((gemm_nt_kernel<0>), dim3((unsigned)nblk), dim3(256), 2 * kStageBytes, stream, p);
+    return sf_check_launch("sf_gemm_nt");
+}

@@ -1,0 +1,303 @@
+// Soft-target cross-entropy of one TTT step (forward + in-place backward + accuracy +
+// acceptance rate in ONE launch) and the teacher reduction that builds its targets.
+//
+// Replaces, for the EAGLE3 offline path of the reference:
+//   specforge/core/loss.py:49-228        LogSoftmaxLoss (Triton fwd/bwd, grad written in place)
+//   specforge/algorithms/eagle3/model.py:161-173   argmax + d2t accuracy
+//   specforge/core/lk_loss.py:43-80      acceptance rate  sum_v min(p_target_on_draft, softmax)
+//   specforge/algorithms/eagle3/model.py:487-501   _compute_target_p (teacher softmax / lse / argmax)
+//
+// HBM-bound: one workgroup per token row.  Algorithmic traffic per row of the fused CE:
+// logits 2*V (bf16, read; second read is an L2/MALL hit) + target_p 4*V (fp32, read once)
+// + dlogits 2*V (bf16, written in place) = 8*V bytes.
+#include "sf_api_internal.h"
+#include "sf_util.h"
+
+namespace {
+
+struct ArgMax {
+    float v;
+    int i;
+};
+SF_DEVICE ArgMax am_pick(ArgMax a, ArgMax b) {  // larger value; ties -> lower index (torch.argmax)
+    if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+    return a;
+}
+SF_DEVICE ArgMax am_wave(ArgMax a) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        ArgMax o;
+        o.v = sf_shfl_xor(a.v, m);
+        o.i = sf_shfl_xor(a.i, m);
+        a = am_pick(a, o);
+    }
+    return a;
+}
+// online (max, sum-exp) pair merge
+SF_DEVICE void md_merge(float& m, float& d, float m2, float d2) {
+    float mn = fmaxf(m, m2);
+    float a = (m == SF_NEG_BIG) ? 0.f : d * sf_exp(m - mn);
+    float b = (m2 == SF_NEG_BIG) ? 0.f : d2 * sf_exp(m2 - mn);
+    m = mn;
+    d = a + b;
+}
+
+// ---------------------------------------------------------------- fused CE
+// Row r = b*S + s reads its soft target / masks / ids at padded index b*Spad + s + off
+// (the TTT shift of step `off`: specforge/algorithms/eagle3/model.py:364-433 slices
+// target_p[:, idx:idx+S] and shifts ids/masks left with zero fill -- zero-padded tails
+// make the shift an offset).
+template <typename T>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2)
+ce_fused_kernel(T* logits, long ld, int V, const float* target, int S, int Spad, int off,
+                const int* pos_mask_pad, const int* loss_mask_pad, const long long* tgt_ids_pad,
+                const float* pod_scale_pad, const float* tsum_pad, const long long* d2t, float grad_scale,
+                int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred) {
+    SF_SHARED float red[32];
+    SF_SHARED int redi[16];
+    const int r = (int)blockIdx.x;
+    const int b = r / S, s = r - b * S;
+    const long pr = (long)b * Spad + s + off;
+    T* x = logits + (long)r * ld;
+    const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+    const int V8 = V >> 3;
+
+    // pass 1: online max / sum-exp / argmax over the draft vocabulary
+    float m = SF_NEG_BIG, d = 0.f;
+    ArgMax am{SF_NEG_BIG, 0x7fffffff};
+    for (int c = tid; c < V8; c += nt) {
+        float v[8];
+        SfVec8<T>::ld(x + c * 8, v);
+        float cm = v[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) cm = fmaxf(cm, v[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (v[i] > am.v) { am.v = v[i]; am.i = c * 8 + i; }
+        float mn = fmaxf(m, cm);
+        float acc = (m == SF_NEG_BIG) ? 0.f : d * sf_exp(m - mn);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += sf_exp(v[i] - mn);
+        m = mn;
+        d = acc;
+    }
+    for (int j = V8 * 8 + tid; j < V; j += nt) {  // tail (V % 8)
+        float v = SfElem<T>::ld(x + j);
+        if (v > am.v) { am.v = v; am.i = j; }
+        md_merge(m, d, v, 1.f);
+    }
+    // workgroup merge
+    for (int k = 32; k >= 1; k >>= 1) {
+        float m2 = sf_shfl_xor(m, k), d2 = sf_shfl_xor(d, k);
+        md_merge(m, d, m2, d2);
+    }
+    am = am_wave(am);
+    const int w = tid >> 6, nw = nt >> 6;
+    if (sf_lane() == 0) { red[w] = m; red[8 + w] = d; red[16 + w] = am.v; redi[w] = am.i; }
+    sf_syncthreads();
+    m = red[0]; d = red[8];
+    am.v = red[16]; am.i = redi[0];
+    for (int i = 1; i < nw; ++i) {
+        md_merge(m, d, red[i], red[8 + i]);
+        am = am_pick(am, ArgMax{red[16 + i], redi[i]});
+    }
+    const float lse = m + sf_log(d);
+    const int pm = pos_mask_pad[pr];
+
+    float loss = 0.f, acc_min = 0.f;
+    if (pm != 0) {
+        const float* tp = target + pr * (long)V;
+        const float podc = pod_scale_pad ? pod_scale_pad[pr] : 0.f;
+        float tsum;
+        if (tsum_pad) {
+            tsum = tsum_pad[pr];
+        } else {  // drop-in LogSoftmaxLoss: sum of the target row (core/loss.py:113-170 pass 1)
+            float t = 0.f;
+            for (int j = tid; j < V; j += nt) t += tp[j];
+            tsum = sf_block_sum(t, red);
+            sf_syncthreads();
+        }
+        const float gs = grad_scale * (float)pm;
+        for (int c = tid; c < V8; c += nt) {
+            float v[8], p[8], g[8];
+            SfVec8<T>::ld(x + c * 8, v);
+            SfVec8<float>::ld(tp + c * 8, p);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float lp = v[i] - lse;
+                float sm = sf_exp(lp);
+                loss -= p[i] * lp;
+                acc_min += fminf(p[i] * podc, sm);
+                g[i] = (sm * tsum - p[i]) * gs;
+            }
+            if (write_grad) SfVec8<T>::st(x + c * 8, g);
+        }
+        for (int j = V8 * 8 + tid; j < V; j += nt) {
+            float v = SfElem<T>::ld(x + j), p = tp[j];
+            float lp = v - lse, sm = sf_exp(lp);
+            loss -= p * lp;
+            acc_min += fminf(p * podc, sm);
+            if (write_grad) SfElem<T>::st(x + j, (sm * tsum - p) * gs);
+        }
+        loss = sf_block_sum(loss, red) * (float)pm;
+        acc_min = sf_block_sum(acc_min, red) * (float)pm;
+    } else if (write_grad) {  // masked row: zero gradient (core/loss.py:160-170)
+        float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int c = tid; c < V8; c += nt) SfVec8<T>::st(x + c * 8, z);
+        for (int j = V8 * 8 + tid; j < V; j += nt) SfElem<T>::st(x + j, 0.f);
+    }
+    if (tid == 0) {
+        const int lm = loss_mask_pad[pr];
+        long long pred_t = (long long)am.i + (d2t ? d2t[am.i] : 0);
+        row_loss[r] = loss;
+        row_accept[r] = acc_min;
+        row_correct[r] = (tgt_ids_pad && pred_t == tgt_ids_pad[pr]) ? (float)lm : 0.f;
+        if (row_pred) row_pred[r] = am.i;
+    }
+}
+
+// deterministic sum of n floats (fixed order, double accumulation): out[0] = sum
+SF_GLOBAL void reduce_sum_kernel(const float* in, long n, float* out, float scale) {
+    SF_SHARED double part[256];
+    const int tid = (int)threadIdx.x;
+    double acc = 0.0;
+    for (long i = tid; i < n; i += 256) acc += (double)in[i];
+    part[tid] = acc;
+    sf_syncthreads();
+    for (int sft = 128; sft >= 1; sft >>= 1) {
+        if (tid < sft) part[tid] += part[tid + sft];
+        sf_syncthreads();
+    }
+    if (tid == 0) out[blockIdx.x] = (float)(part[0] * (double)scale);
+}
+
+// ------------------------------------------------------------ teacher reduce
+// One row of teacher logits z[Vt] -> argmax id, position mask, softmax over the draft
+// sub-vocabulary (target_p), and pod_scale = sum_d exp(z_d - logsumexp(z)) / so that
+// target_p_on_draft = target_p * pod_scale (eagle3/model.py:487-501).
+template <typename T>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2)
+teacher_reduce_kernel(const T* z, long ldz, int Vt, int Vd, const long long* d2t, const unsigned char* t2d,
+                      const int* loss_mask_pad, int S, int Spad, float* target_p_pad, float* pod_scale_pad,
+                      float* tsum_pad, long long* ids_pad, int* pos_mask_pad) {
+    SF_SHARED float red[32];
+    SF_SHARED int redi[16];
+    const int r = (int)blockIdx.x;
+    const int b = r / S, s = r - b * S;
+    const long pr = (long)b * Spad + s;
+    const T* x = z + (long)r * ldz;
+    const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+    const int V8 = Vt >> 3;
+    float m = SF_NEG_BIG, d = 0.f;
+    ArgMax am{SF_NEG_BIG, 0x7fffffff};
+    for (int c = tid; c < V8; c += nt) {
+        float v[8];
+        SfVec8<T>::ld(x + c * 8, v);
+        float cm = v[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) cm = fmaxf(cm, v[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (v[i] > am.v) { am.v = v[i]; am.i = c * 8 + i; }
+        float mn = fmaxf(m, cm);
+        float acc = (m == SF_NEG_BIG) ? 0.f : d * sf_exp(m - mn);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += sf_exp(v[i] - mn);
+        m = mn;
+        d = acc;
+    }
+    for (int j = V8 * 8 + tid; j < Vt; j += nt) {
+        float v = SfElem<T>::ld(x + j);
+        if (v > am.v) { am.v = v; am.i = j; }
+        md_merge(m, d, v, 1.f);
+    }
+    for (int k = 32; k >= 1; k >>= 1) {
+        float m2 = sf_shfl_xor(m, k), d2 = sf_shfl_xor(d, k);
+        md_merge(m, d, m2, d2);
+    }
+    am = am_wave(am);
+    const int w = tid >> 6, nw = nt >> 6;
+    if (sf_lane() == 0) { red[w] = m; red[8 + w] = d; red[16 + w] = am.v; redi[w] = am.i; }
+    sf_syncthreads();
+    m = red[0]; d = red[8];
+    am.v = red[16]; am.i = redi[0];
+    for (int i = 1; i < nw; ++i) {
+        md_merge(m, d, red[i], red[8 + i]);
+        am = am_pick(am, ArgMax{red[16 + i], redi[i]});
+    }
+    const float lse_full = m + sf_log(d);
+    sf_syncthreads();
+    // draft sub-vocabulary: max, then exp-sum, then normalise (torch.softmax order)
+    float md = SF_NEG_BIG;
+    for (int j = tid; j < Vd; j += nt) md = fmaxf(md, SfElem<T>::ld(x + j + d2t[j]));
+    md = sf_block_max(md, red);
+    float* tp = target_p_pad + pr * (long)Vd;
+    float sd = 0.f;
+    for (int j = tid; j < Vd; j += nt) {
+        float e = sf_exp(SfElem<T>::ld(x + j + d2t[j]) - md);
+        tp[j] = e;
+        sd += e;
+    }
+    sd = sf_block_sum(sd, red);
+    const float inv = 1.0f / sd;
+    float ts = 0.f;
+    for (int j = tid; j < Vd; j += nt) {
+        float p = tp[j] * inv;
+        tp[j] = p;
+        ts += p;
+    }
+    ts = sf_block_sum(ts, red);
+    if (tid == 0) {
+        pod_scale_pad[pr] = sd * sf_exp(md - lse_full);
+        tsum_pad[pr] = ts;
+        ids_pad[pr] = (long long)am.i;
+        pos_mask_pad[pr] = (t2d[am.i] ? 1 : 0) * loss_mask_pad[pr];
+    }
+}
+
+}  // namespace
+
+extern "C" int sf_ce_fused(void* logits, int dtype, long ld, int rows, int V, const float* target, int S, int Spad,
+                           int off, const int* pos_mask_pad, const int* loss_mask_pad, const long long* tgt_ids_pad,
+                           const float* pod_scale_pad, const float* tsum_pad, const long long* d2t, float grad_scale,
+                           int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred,
+                           void* stream) {
+    SF_CHECK_ARG(rows >= 0 && V > 0 && S > 0 && Spad >= S && off >= 0 && off + S <= Spad, "sf_ce_fused: bad shape");
+    SF_CHECK_ARG(dtype == SF_BF16 || dtype == SF_F32, "sf_ce_fused: dtype");
+    SF_CHECK_ARG(ld % 8 == 0 && V % 8 == 0, "sf_ce_fused: ld and V must be multiples of 8");
+    if (rows == 0) return 0;
+    if (dtype == SF_BF16)
+        SF_LAUNCH((ce_fused_kernel<sf_bf16>), dim3(rows), dim3(256), 0, stream, (sf_bf16*)logits, ld, V, target, S, Spad,
+                  off, pos_mask_pad, loss_mask_pad, tgt_ids_pad, pod_scale_pad, tsum_pad, d2t, grad_scale, write_grad,
+                  row_loss, row_correct, row_accept, row_pred);
+    else
+        SF_LAUNCH((ce_fused_kernel<float>), dim3(rows), dim3(256), 0, stream, (float*)logits, ld, V, target, S, Spad,
+                  off, pos_mask_pad, loss_mask_pad, tgt_ids_pad, pod_scale_pad, tsum_pad, d2t, grad_scale, write_grad,
+                  row_loss, row_correct, row_accept, row_pred);
+    return sf_check_launch("sf_ce_fused");
+}
+
+extern "C" int sf_reduce_sum(const float* in, long n, int nsegments, float* out, float scale, void* stream) {
+    SF_CHECK_ARG(n >= 0 && nsegments >= 1, "sf_reduce_sum: bad shape");
+    // segment i sums in[i*n : (i+1)*n]
+    for (int i = 0; i < nsegments; ++i)
+        SF_LAUNCH(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, in + (long)i * n, n, out + i, scale);
+    return sf_check_launch("sf_reduce_sum");
+}
+
+extern "C" int sf_teacher_reduce(const void* z, int dtype, long ldz, int rows, int Vt, int Vd, const long long* d2t,
+                                 const unsigned char* t2d, const int* loss_mask_pad, int S, int Spad,
+                                 float* target_p_pad, float* pod_scale_pad, float* tsum_pad, long long* ids_pad,
+                                 int* pos_mask_pad, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && Vt > 0 && Vd > 0 && S > 0 && Spad >= S, "sf_teacher_reduce: bad shape");
+    SF_CHECK_ARG(ldz % 8 == 0, "sf_teacher_reduce: ldz must be a multiple of 8");
+    if (rows == 0) return 0;
+    if (dtype == SF_BF16)
+        SF_LAUNCH((teacher_reduce_kernel<sf_bf16>), dim3(rows), dim3(256), 0, stream, (const sf_bf16*)z, ldz, Vt, Vd,
+                  d2t, t2d, loss_mask_pad, S, Spad, target_p_pad, pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad);
+    else if (dtype == SF_F32)
+        SF_LAUNCH((teacher_reduce_kernel<float>), dim3(rows), dim3(256), 0, stream, (const float*)z, ldz, Vt, Vd, d2t,
+                  t2d, loss_mask_pad, S, Spad, target_p_pad, pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad);
+    else
+        SF_CHECK_ARG(false, "sf_teacher_reduce: dtype");
+    return sf_check_launch("sf_teacher_reduce");
+}

@@ -1,0 +1,133 @@
+// Platform layer of the specforge_amd kernels.
+//
+// Product build (hipcc --offload-arch=gfx950): thin inline wrappers over the gfx950
+// builtins -- MFMA, LDS-DMA (global_load_lds), wave shuffles, s_barrier.
+// Test build (-DSF_EMU, host compiler): the same names map onto tests/emu/sf_emu.h,
+// a fiber-based SIMT interpreter used to debug kernel index logic on a machine
+// without a GPU.  There is no third path and nothing here selects between them at
+// run time.
+#pragma once
+#include <stdint.h>
+
+typedef short sf_v8s __attribute__((ext_vector_type(8)));   // 8 x bf16 bits
+typedef short sf_v4s __attribute__((ext_vector_type(4)));   // 4 x bf16 bits
+typedef float sf_v4f __attribute__((ext_vector_type(4)));
+typedef float sf_v16f __attribute__((ext_vector_type(16)));
+typedef unsigned short sf_bf16;  // raw bf16 bits
+
+#ifdef SF_EMU
+// ------------------------------------------------------------------ emulator
+#include "sf_emu.h"
+#define SF_GLOBAL
+#define SF_DEVICE inline
+#define SF_HD inline
+#define SF_SHARED static thread_local
+#define SF_LAUNCH_BOUNDS(t, w)
+using sfemu::dim3;
+#define threadIdx (sfemu::cur_tid())
+#define blockIdx (sfemu::cur_bid())
+#define blockDim (sfemu::cur_bdim())
+#define gridDim (sfemu::cur_gdim())
+typedef void* sfStream_t;
+#define SF_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    sfemu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+#define SF_DYN_SMEM(name) char* name = sfemu::dyn_smem_base()
+static inline const char* sf_launch_error() { return nullptr; }
+
+SF_DEVICE void sf_syncthreads() { sfemu::block_barrier(); }
+SF_DEVICE int sf_lane() { return sfemu::lane_id(); }
+template <typename T> SF_DEVICE T sf_shfl_xor(T v, int m) { return sfemu::shfl_xor(v, m); }
+template <typename T> SF_DEVICE T sf_shfl(T v, int l) { return sfemu::shfl(v, l); }
+SF_DEVICE sf_v4f sf_mfma16(sf_v8s a, sf_v8s b, sf_v4f c) { return sfemu::mfma_16x16x32_bf16(a, b, c); }
+SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) { return sfemu::mfma_32x32x16_bf16(a, b, c); }
+SF_DEVICE void sf_glds16(const void* g, void* l) { sfemu::global_load_lds16(g, l); }
+SF_DEVICE void sf_wait_vm0() {}
+SF_DEVICE void sf_setprio_hi() {}
+SF_DEVICE void sf_setprio_lo() {}
+template <typename T> SF_DEVICE T sf_atomic_add(T* p, T v) { return sfemu::atomic_add(p, v); }
+SF_DEVICE float sf_exp(float x) { return expf(x); }
+SF_DEVICE float sf_exp2(float x) { return exp2f(x); }
+SF_DEVICE float sf_log(float x) { return logf(x); }
+SF_DEVICE float sf_rsqrt(float x) { return 1.0f / sqrtf(x); }
+
+#else
+// -------------------------------------------------------------------- gfx950
+#include <hip/hip_runtime.h>
+#define SF_GLOBAL __global__
+#define SF_DEVICE __device__ __forceinline__
+#define SF_HD __host__ __device__ __forceinline__
+#define SF_SHARED __shared__
+#define SF_LAUNCH_BOUNDS(t, w) __launch_bounds__(t, w)
+typedef hipStream_t sfStream_t;
+#define SF_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+#define SF_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+static inline const char* sf_launch_error() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? nullptr : hipGetErrorString(e);
+}
+
+SF_DEVICE void sf_syncthreads() { __syncthreads(); }
+SF_DEVICE int sf_lane() { return (int)(threadIdx.x & 63u); }
+template <typename T> SF_DEVICE T sf_shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
+template <typename T> SF_DEVICE T sf_shfl(T v, int l) { return __shfl(v, l, 64); }
+SF_DEVICE sf_v4f sf_mfma16(sf_v8s a, sf_v8s b, sf_v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// LDS-DMA, 16 B per lane: LDS dst = wave-uniform base + 16*lane (caller's pointer must obey that)
+SF_DEVICE void sf_glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+SF_DEVICE void sf_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+SF_DEVICE void sf_setprio_hi() { __builtin_amdgcn_s_setprio(1); }
+SF_DEVICE void sf_setprio_lo() { __builtin_amdgcn_s_setprio(0); }
+template <typename T> SF_DEVICE T sf_atomic_add(T* p, T v) { return atomicAdd(p, v); }
+SF_DEVICE float sf_exp(float x) { return expf(x); }
+SF_DEVICE float sf_exp2(float x) { return exp2f(x); }
+SF_DEVICE float sf_log(float x) { return logf(x); }
+SF_DEVICE float sf_rsqrt(float x) { return rsqrtf(x); }
+#endif
+
+// ------------------------------------------------------------- bf16 helpers
+SF_HD float sf_bf2f(sf_bf16 h) {
+    union { uint32_t u; float f; } x;
+    x.u = (uint32_t)h << 16;
+    return x.f;
+}
+// round-to-nearest-even, NaN stays NaN (same as torch's float->bfloat16)
+SF_HD sf_bf16 sf_f2bf(float f) {
+    union { uint32_t u; float f; } x;
+    x.f = f;
+    uint32_t u = x.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (sf_bf16)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (sf_bf16)(u >> 16);
+}
+SF_HD float sf_round_bf(float f) { return sf_bf2f(sf_f2bf(f)); }
+
+// element type traits for kernels templated on bf16 / fp32 storage
+template <typename T> struct SfElem;
+template <> struct SfElem<sf_bf16> {
+    static SF_HD float ld(const sf_bf16* p) { return sf_bf2f(*p); }
+    static SF_HD void st(sf_bf16* p, float v) { *p = sf_f2bf(v); }
+    static SF_HD float rnd(float v) { return sf_round_bf(v); }
+};
+template <> struct SfElem<float> {
+    static SF_HD float ld(const float* p) { return *p; }
+    static SF_HD void st(float* p, float v) { *p = v; }
+    static SF_HD float rnd(float v) { return v; }
+};
+
+// block-wide reductions over 256-thread (or any multiple-of-64) workgroups
+SF_DEVICE float sf_wave_sum(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v += sf_shfl_xor(v, m);
+    return v;
+}
+SF_DEVICE float sf_wave_max(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, sf_shfl_xor(v, m));
+    return v;
+}

@@ -1,0 +1,452 @@
+// HBM-bound row kernels of the draft layer: RMSNorm (+embedding gather, +concat placement)
+// forward/backward, RoPE forward/backward (in place), SwiGLU forward/backward, batched
+// tile transpose, fp32->storage cast, and the fused clip + AdamW optimizer step.
+//
+// Replaces, for the EAGLE3 offline path of the reference:
+//   specforge/modeling/draft/llama3_eagle.py:1561-1567  LlamaRMSNorm.forward (torch.compile)
+//   specforge/modeling/draft/llama3_eagle.py:133-142    apply_rotary_pos_emb (torch.compile)
+//   specforge/modeling/draft/llama3_eagle.py:1518-1549  LlamaMLP act_fn(gate) * up
+//   specforge/modeling/draft/llama3_eagle.py:1759-1760  embed_input_ids (frozen gather, fused into the norm)
+//   specforge/optimizer.py:95-168                       BF16Optimizer.step (norm, clip, AdamW, bf16 copy)
+// plus the autograd backward of each.  All loads/stores are 16-byte vectors (8 bf16).
+#include "sf_api_internal.h"
+#include "sf_util.h"
+
+namespace {
+
+constexpr int kNormVecs = 4;  // 256 threads x 4 x 8 = 8192 columns max
+
+// ------------------------------------------------------------------ RMSNorm
+// y[r, :] = w * round_T(x[r, :] * rstd[r]); optional row gather x_row = table[ids_pad[b*Spad+s+off]]
+template <typename T>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2)
+rmsnorm_fwd_kernel(const T* x, long ldx, const long long* ids_pad, int S, int Spad, int off, const T* w, float eps,
+                   int H, T* y, long ldy, float* rstd_out) {
+    SF_SHARED float red[16];
+    const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const T* xr;
+    if (ids_pad) {
+        const int b = r / S, s = r - b * S;
+        xr = x + ids_pad[(long)b * Spad + s + off] * ldx;
+    } else {
+        xr = x + (long)r * ldx;
+    }
+    float c[kNormVecs][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNormVecs; ++i) {
+        const int col = (tid + i * 256) * 8;
+        if (col < H) {
+            SfVec8<T>::ld(xr + col, c[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += c[i][j] * c[i][j];
+        }
+    }
+    ss = sf_block_sum(ss, red);
+    const float rstd = sf_rsqrt(ss / (float)H + eps);
+    if (tid == 0 && rstd_out) rstd_out[r] = rstd;
+    T* yr = y + (long)r * ldy;
+#pragma unroll
+    for (int i = 0; i < kNormVecs; ++i) {
+        const int col = (tid + i * 256) * 8;
+        if (col < H) {
+            float wv[8], o[8];
+            SfVec8<T>::ld(w + col, wv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = wv[j] * SfElem<T>::rnd(c[i][j] * rstd);
+            SfVec8<T>::st(yr + col, o);
+        }
+    }
+}
+
+// dx = rstd * (g - xhat * mean(g*xhat)), g = dy*w, xhat = round_T(x*rstd); dw_partial += dy*xhat.
+// dx (optional) gets `add` (optional residual-stream gradient) summed in.
+template <typename T>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2)
+rmsnorm_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, const long long* ids_pad, int S, int Spad, int off,
+                   const T* w, const float* rstd_in, int H, int R, int rows_per_block, const T* add, long ldadd, T* dx,
+                   long lddx, float* dw_partial) {
+    SF_SHARED float red[16];
+    const int tid = (int)threadIdx.x;
+    float dwacc[kNormVecs][8];
+    float wv[kNormVecs][8];
+#pragma unroll
+    for (int i = 0; i < kNormVecs; ++i) {
+        const int col = (tid + i * 256) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dwacc[i][j] = 0.f; wv[i][j] = 0.f; }
+        if (col < H) SfVec8<T>::ld(w + col, wv[i]);
+    }
+    const int r0 = (int)blockIdx.x * rows_per_block;
+    for (int r = r0; r < r0 + rows_per_block && r < R; ++r) {
+        const T* xr;
+        if (ids_pad) {
+            const int b = r / S, s = r - b * S;
+            xr = x + ids_pad[(long)b * Spad + s + off] * ldx;
+        } else {
+            xr = x + (long)r * ldx;
+        }
+        const float rstd = rstd_in[r];
+        float g[kNormVecs][8], xh[kNormVecs][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < kNormVecs; ++i) {
+            const int col = (tid + i * 256) * 8;
+            if (col < H) {
+                float xv[8], dv[8];
+                SfVec8<T>::ld(xr + col, xv);
+                SfVec8<T>::ld(dy + (long)r * lddy + col, dv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xh[i][j] = SfElem<T>::rnd(xv[j] * rstd);
+                    g[i][j] = dv[j] * wv[i][j];
+                    dot += g[i][j] * xh[i][j];
+                    dwacc[i][j] += dv[j] * xh[i][j];
+                }
+            }
+        }
+        if (dx) {
+            dot = sf_block_sum(dot, red);
+            const float cmean = dot / (float)H;
+#pragma unroll
+            for (int i = 0; i < kNormVecs; ++i) {
+                const int col = (tid + i * 256) * 8;
+                if (col < H) {
+                    float o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - xh[i][j] * cmean);
+                    if (add) {
+                        float a[8];
+                        SfVec8<T>::ld(add + (long)r * ldadd + col, a);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] += a[j];
+                    }
+                    SfVec8<T>::st(dx + (long)r * lddx + col, o);
+                }
+            }
+        }
+    }
+    if (dw_partial) {
+#pragma unroll
+        for (int i = 0; i < kNormVecs; ++i) {
+            const int col = (tid + i * 256) * 8;
+            if (col < H) SfVec8<float>::st(dw_partial + (long)blockIdx.x * H + col, dwacc[i]);
+        }
+    }
+}
+
+// acc[col] (+)= sum_b partial[b][col]   (deterministic: fixed order)
+SF_GLOBAL void colsum_accum_kernel(const float* partial, int nb, int H, float* acc, int accumulate) {
+    const int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (col >= H) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partial[(long)b * H + col];
+    acc[col] = accumulate ? acc[col] + s : s;
+}
+
+// --------------------------------------------------------------------- RoPE
+// In place on `nheads` consecutive heads of width hd starting at column 0 of row r (row stride ld).
+// forward : y1 = x1*c1 - x2*s1 ; y2 = x2*c2 + x1*s2     (q*cos + rotate_half(q)*sin, neox halves)
+// backward: dx1 = dy1*c1 + dy2*s2 ; dx2 = dy2*c2 - dy1*s1
+template <typename T>
+SF_GLOBAL void rope_kernel(T* x, long ld, int nheads, int hd, const T* cos_t, const T* sin_t, const long long* pos_ids,
+                           int pos_off, int max_pos, int backward) {
+    const int r = (int)blockIdx.x;
+    long pos = pos_ids[r] + pos_off;
+    if (pos < 0) pos = 0;
+    if (pos >= max_pos) pos = max_pos - 1;
+    const T* cr = cos_t + pos * hd;
+    const T* sr = sin_t + pos * hd;
+    const int half = hd >> 1, upr = half >> 3;  // 8-wide units per head-half
+    T* xr = x + (long)r * ld;
+    for (int u = (int)threadIdx.x; u < nheads * upr; u += (int)blockDim.x) {
+        const int h = u / upr, j = (u - h * upr) * 8;
+        T* p1 = xr + h * hd + j;
+        T* p2 = p1 + half;
+        float x1[8], x2[8], c1[8], c2[8], s1[8], s2[8], o1[8], o2[8];
+        SfVec8<T>::ld(p1, x1);
+        SfVec8<T>::ld(p2, x2);
+        SfVec8<T>::ld(cr + j, c1);
+        SfVec8<T>::ld(cr + half + j, c2);
+        SfVec8<T>::ld(sr + j, s1);
+        SfVec8<T>::ld(sr + half + j, s2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (!backward) {
+                o1[i] = SfElem<T>::rnd(x1[i] * c1[i]) + SfElem<T>::rnd(-x2[i] * s1[i]);
+                o2[i] = SfElem<T>::rnd(x2[i] * c2[i]) + SfElem<T>::rnd(x1[i] * s2[i]);
+            } else {
+                o1[i] = x1[i] * c1[i] + x2[i] * s2[i];
+                o2[i] = x2[i] * c2[i] - x1[i] * s1[i];
+            }
+        }
+        SfVec8<T>::st(p1, o1);
+        SfVec8<T>::st(p2, o2);
+    }
+}
+
+// ------------------------------------------------------------------- SwiGLU
+template <typename T>
+SF_GLOBAL void swiglu_fwd_kernel(const T* gu, long ldgu, int I, long rows, T* act, long ldact) {
+    const long upr = I >> 3, total = rows * upr;
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (long)gridDim.x * blockDim.x) {
+        const long r = u / upr;
+        const int j = (int)(u - r * upr) * 8;
+        float g[8], up[8], o[8];
+        SfVec8<T>::ld(gu + r * ldgu + j, g);
+        SfVec8<T>::ld(gu + r * ldgu + I + j, up);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float sg = 1.0f / (1.0f + sf_exp(-g[i]));
+            o[i] = SfElem<T>::rnd(g[i] * sg) * up[i];
+        }
+        SfVec8<T>::st(act + r * ldact + j, o);
+    }
+}
+template <typename T>
+SF_GLOBAL void swiglu_bwd_kernel(const T* dact, long lddact, const T* gu, long ldgu, int I, long rows, T* dgu, long lddgu) {
+    const long upr = I >> 3, total = rows * upr;
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (long)gridDim.x * blockDim.x) {
+        const long r = u / upr;
+        const int j = (int)(u - r * upr) * 8;
+        float g[8], up[8], da[8], dg[8], du[8];
+        SfVec8<T>::ld(gu + r * ldgu + j, g);
+        SfVec8<T>::ld(gu + r * ldgu + I + j, up);
+        SfVec8<T>::ld(dact + r * lddact + j, da);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float sg = 1.0f / (1.0f + sf_exp(-g[i]));
+            float silu = g[i] * sg;
+            dg[i] = da[i] * up[i] * (sg * (1.0f + g[i] * (1.0f - sg)));
+            du[i] = da[i] * SfElem<T>::rnd(silu);
+        }
+        SfVec8<T>::st(dgu + r * lddgu + j, dg);
+        SfVec8<T>::st(dgu + r * lddgu + I + j, du);
+    }
+}
+
+// ---------------------------------------------------------------- transpose
+// out[b1][b2][c][r] = in[b1][b2][r][c]   (R rows x C cols, 2-level batch, unit inner strides)
+template <typename T>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2)
+transpose_kernel(const T* in, long in_b1, long in_b2, long in_ld, T* out, long out_b1, long out_b2, long out_ld, int R,
+                 int C, int nb2) {
+    SF_SHARED T tile[64][72];
+    const int bz = (int)blockIdx.z;
+    const int b1 = bz / nb2, b2 = bz - b1 * nb2;
+    const T* src = in + b1 * in_b1 + b2 * in_b2;
+    T* dst = out + b1 * out_b1 + b2 * out_b2;
+    const int r0 = (int)blockIdx.y * 64, c0 = (int)blockIdx.x * 64, tid = (int)threadIdx.x;
+    for (int v = tid; v < 512; v += 256) {
+        const int rr = v >> 3, cc = (v & 7) * 8;
+        float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r0 + rr < R && c0 + cc < C) SfVec8<T>::ld(src + (long)(r0 + rr) * in_ld + c0 + cc, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) SfElem<T>::st(&tile[rr][cc + j], t[j]);
+    }
+    sf_syncthreads();
+    for (int v = tid; v < 512; v += 256) {
+        const int cc = v >> 3, rr = (v & 7) * 8;  // output row = input col
+        if (c0 + cc < C && r0 + rr < R) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = SfElem<T>::ld(&tile[rr + j][cc]);
+            SfVec8<T>::st(dst + (long)(c0 + cc) * out_ld + r0 + rr, t);
+        }
+    }
+}
+
+// out[r, c] = (T) in[r, c] * scale    (fp32 accumulators -> storage dtype, strided)
+template <typename T>
+SF_GLOBAL void cast_from_f32_kernel(const float* in, long ldin, T* out, long ldout, long rows, int C, float scale) {
+    const long upr = C >> 3, total = rows * upr;
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (long)gridDim.x * blockDim.x) {
+        const long r = u / upr;
+        const int j = (int)(u - r * upr) * 8;
+        float t[8];
+        SfVec8<float>::ld(in + r * ldin + j, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] *= scale;
+        SfVec8<T>::st(out + r * ldout + j, t);
+    }
+}
+
+// ---------------------------------------------------------------- optimizer
+// partial[b] = sum over this block's slice of float(g)^2
+template <typename T>
+SF_GLOBAL void sumsq_kernel(const T* g, long n, float* partial) {
+    SF_SHARED float red[16];
+    float acc = 0.f;
+    const long n8 = n >> 3;
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < n8; u += (long)gridDim.x * blockDim.x) {
+        float t[8];
+        SfVec8<T>::ld(g + u * 8, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += t[i] * t[i];
+    }
+    if (blockIdx.x == 0)
+        for (long j = n8 * 8 + threadIdx.x; j < n; j += blockDim.x) {
+            float v = SfElem<T>::ld(g + j);
+            acc += v * v;
+        }
+    acc = sf_block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+SF_GLOBAL void norm_finish_kernel(const float* partial, int nb, float* norm_out, float extra_sq) {
+    SF_SHARED double part[256];
+    const int tid = (int)threadIdx.x;
+    double acc = 0.0;
+    for (int i = tid; i < nb; i += 256) acc += (double)partial[i];
+    part[tid] = acc;
+    sf_syncthreads();
+    for (int sft = 128; sft >= 1; sft >>= 1) {
+        if (tid < sft) part[tid] += part[tid + sft];
+        sf_syncthreads();
+    }
+    if (tid == 0) norm_out[0] = (float)sqrt(part[0] + (double)extra_sq);
+}
+// BF16Optimizer.step on flat buffers (optimizer.py:95-168): clip = min(1, max_norm/(norm+1e-6)),
+// g32 = float(g)*clip, torch.optim.AdamW update of the fp32 master, param = T(master).
+template <typename T>
+SF_GLOBAL void adamw_kernel(const T* g, float* master, float* m, float* v, T* param, long n, const float* norm,
+                            float max_norm, float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                            float bc2_sqrt, float grad_prescale) {
+    float clip = 1.0f;
+    if (max_norm > 0.f) clip = fminf(1.0f, max_norm / (norm[0] + 1e-6f));
+    const float gsc = clip * grad_prescale;
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float g32 = SfElem<T>::ld(g + i) * gsc;
+        float p = master[i] * (1.0f - lr * wd);
+        float mi = m[i] * beta1 + g32 * (1.0f - beta1);
+        float vi = v[i] * beta2 + g32 * g32 * (1.0f - beta2);
+        float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p = p - step_size * (mi / denom);
+        master[i] = p;
+        m[i] = mi;
+        v[i] = vi;
+        SfElem<T>::st(param + i, p);
+    }
+}
+
+inline int grid_for(long units, int block = 256, int cap = 256 * 8) {
+    long g = (units + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+#define SF_DISPATCH_T(dtype, CALL)                          \
+    do {                                                    \
+        if ((dtype) == SF_BF16) { typedef sf_bf16 T; CALL; } \
+        else if ((dtype) == SF_F32) { typedef float T; CALL; } \
+        else SF_CHECK_ARG(false, "unsupported dtype");      \
+    } while (0)
+
+extern "C" int sf_rmsnorm_fwd(const void* x, int dtype, long ldx, const long long* ids_pad, int S, int Spad, int off,
+                              const void* w, float eps, int rows, int H, void* y, long ldy, float* rstd, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && H > 0 && H % 8 == 0 && H <= 256 * 8 * kNormVecs, "sf_rmsnorm_fwd: H must be a multiple of 8, <= 8192");
+    SF_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0, "sf_rmsnorm_fwd: strides must be multiples of 8");
+    SF_CHECK_ARG(!ids_pad || (S > 0 && Spad >= S + off), "sf_rmsnorm_fwd: gather shape");
+    if (rows == 0) return 0;
+    SF_DISPATCH_T(dtype, SF_LAUNCH((rmsnorm_fwd_kernel<T>), dim3(rows), dim3(256), 0, stream, (const T*)x, ldx, ids_pad, S,
+                                   Spad, off, (const T*)w, eps, H, (T*)y, ldy, rstd));
+    return sf_check_launch("sf_rmsnorm_fwd");
+}
+
+extern "C" long sf_rmsnorm_bwd_workspace_floats(int rows, int H) {
+    const int rpb = 16;
+    return (long)((rows + rpb - 1) / rpb) * H;
+}
+
+extern "C" int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* x, long ldx, const long long* ids_pad,
+                              int S, int Spad, int off, const void* w, const float* rstd, int rows, int H,
+                              const void* add, long ldadd, void* dx, long lddx, float* dw_acc, int dw_accumulate,
+                              float* workspace, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && H > 0 && H % 8 == 0 && H <= 256 * 8 * kNormVecs, "sf_rmsnorm_bwd: H must be a multiple of 8, <= 8192");
+    SF_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && ldadd % 8 == 0, "sf_rmsnorm_bwd: strides");
+    SF_CHECK_ARG(!dw_acc || workspace, "sf_rmsnorm_bwd: workspace required for dw");
+    if (rows == 0) return 0;
+    const int rpb = 16, nb = (rows + rpb - 1) / rpb;
+    SF_DISPATCH_T(dtype, SF_LAUNCH((rmsnorm_bwd_kernel<T>), dim3(nb), dim3(256), 0, stream, (const T*)dy, lddy, (const T*)x,
+                                   ldx, ids_pad, S, Spad, off, (const T*)w, rstd, H, rows, rpb, (const T*)add, ldadd,
+                                   (T*)dx, lddx, dw_acc ? workspace : (float*)nullptr));
+    if (dw_acc)
+        SF_LAUNCH(colsum_accum_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nb, H, dw_acc,
+                  dw_accumulate);
+    return sf_check_launch("sf_rmsnorm_bwd");
+}
+
+extern "C" int sf_rope(void* x, int dtype, long ld, int rows, int nheads, int hd, const void* cos_t, const void* sin_t,
+                       const long long* pos_ids, int pos_off, int max_pos, int backward, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && nheads > 0 && hd % 16 == 0 && ld % 8 == 0 && max_pos > 0, "sf_rope: bad shape");
+    if (rows == 0) return 0;
+    SF_DISPATCH_T(dtype, SF_LAUNCH((rope_kernel<T>), dim3(rows), dim3(256), 0, stream, (T*)x, ld, nheads, hd, (const T*)cos_t,
+                                   (const T*)sin_t, pos_ids, pos_off, max_pos, backward));
+    return sf_check_launch("sf_rope");
+}
+
+extern "C" int sf_swiglu_fwd(const void* gu, int dtype, long ldgu, long rows, int I, void* act, long ldact, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && I > 0 && I % 8 == 0 && ldgu % 8 == 0 && ldact % 8 == 0, "sf_swiglu_fwd: bad shape");
+    if (rows == 0) return 0;
+    SF_DISPATCH_T(dtype, SF_LAUNCH((swiglu_fwd_kernel<T>), dim3(grid_for(rows * (I / 8))), dim3(256), 0, stream, (const T*)gu,
+                                   ldgu, I, rows, (T*)act, ldact));
+    return sf_check_launch("sf_swiglu_fwd");
+}
+
+extern "C" int sf_swiglu_bwd(const void* dact, int dtype, long lddact, const void* gu, long ldgu, long rows, int I,
+                             void* dgu, long lddgu, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && I > 0 && I % 8 == 0 && ldgu % 8 == 0 && lddact % 8 == 0 && lddgu % 8 == 0, "sf_swiglu_bwd: bad shape");
+    if (rows == 0) return 0;
+    SF_DISPATCH_T(dtype, SF_LAUNCH((swiglu_bwd_kernel<T>), dim3(grid_for(rows * (I / 8))), dim3(256), 0, stream,
+                                   (const T*)dact, lddact, (const T*)gu, ldgu, I, rows, (T*)dgu, lddgu));
+    return sf_check_launch("sf_swiglu_bwd");
+}
+
+extern "C" int sf_transpose(const void* in, int dtype, long in_b1, long in_b2, long in_ld, void* out, long out_b1,
+                            long out_b2, long out_ld, int nb1, int nb2, int R, int C, void* stream) {
+    SF_CHECK_ARG(nb1 >= 1 && nb2 >= 1 && R >= 0 && C >= 0 && R % 8 == 0 && C % 8 == 0, "sf_transpose: R and C must be multiples of 8");
+    SF_CHECK_ARG(in_ld % 8 == 0 && out_ld % 8 == 0 && in_b1 % 8 == 0 && in_b2 % 8 == 0 && out_b1 % 8 == 0 && out_b2 % 8 == 0,
+                 "sf_transpose: strides must be multiples of 8");
+    if (R == 0 || C == 0) return 0;
+    SF_CHECK_ARG((long)nb1 * nb2 <= 65535, "sf_transpose: too many batches");
+    dim3 grid((C + 63) / 64, (R + 63) / 64, nb1 * nb2);
+    SF_DISPATCH_T(dtype, SF_LAUNCH((transpose_kernel<T>), grid, dim3(256), 0, stream, (const T*)in, in_b1, in_b2, in_ld,
+                                   (T*)out, out_b1, out_b2, out_ld, R, C, nb2));
+    return sf_check_launch("sf_transpose");
+}
+
+extern "C" int sf_cast_from_f32(const float* in, long ldin, void* out, int dtype, long ldout, long rows, int C, float scale,
+                                void* stream) {
+    SF_CHECK_ARG(rows >= 0 && C >= 0 && C % 8 == 0 && ldin % 8 == 0 && ldout % 8 == 0, "sf_cast_from_f32: bad shape");
+    if (rows == 0 || C == 0) return 0;
+    SF_DISPATCH_T(dtype, SF_LAUNCH((cast_from_f32_kernel<T>), dim3(grid_for(rows * (C / 8))), dim3(256), 0, stream, in, ldin,
+                                   (T*)out, ldout, rows, C, scale));
+    return sf_check_launch("sf_cast_from_f32");
+}
+
+extern "C" long sf_grad_norm_workspace_floats(void) { return 1024; }
+
+// norm_out[0] = sqrt(sum float(g)^2 + extra_sq)
+extern "C" int sf_grad_norm(const void* g, int dtype, long n, float extra_sq, float* norm_out, float* workspace, void* stream) {
+    SF_CHECK_ARG(n >= 0 && workspace && norm_out, "sf_grad_norm: bad args");
+    const int nb = (int)((n / 8 + 255) / 256 < 1 ? 1 : ((n / 8 + 255) / 256 > 1024 ? 1024 : (n / 8 + 255) / 256));
+    SF_DISPATCH_T(dtype, SF_LAUNCH((sumsq_kernel<T>), dim3(nb), dim3(256), 0, stream, (const T*)g, n, workspace));
+    SF_LAUNCH(norm_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, nb, norm_out, extra_sq);
+    return sf_check_launch("sf_grad_norm");
+}
+
+extern "C" int sf_adamw_step(const void* g, int dtype, float* master, float* m, float* v, void* param, long n,
+                             const float* norm, float max_norm, float lr, float beta1, float beta2, float eps, float wd,
+                             int step, float grad_prescale, void* stream) {
+    SF_CHECK_ARG(n >= 0 && step >= 1, "sf_adamw_step: bad args");
+    if (n == 0) return 0;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    SF_DISPATCH_T(dtype, SF_LAUNCH((adamw_kernel<T>), dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, stream, (const T*)g,
+                                   master, m, v, (T*)param, n, norm, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2s,
+                                   grad_prescale));
+    return sf_check_launch("sf_adamw_step");
+}

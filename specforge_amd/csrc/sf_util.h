@@ -1,0 +1,59 @@
+// Shared device helpers: 8-wide vector loads/stores of bf16 / fp32 rows, block reductions.
+#pragma once
+#include "sf_platform.h"
+
+#define SF_NEG_BIG (-3.0e38f)
+
+template <typename T> struct SfVec8;
+template <> struct SfVec8<sf_bf16> {
+    // 16-byte load of 8 bf16
+    static SF_DEVICE void ld(const sf_bf16* p, float (&o)[8]) {
+        sf_v8s v = *reinterpret_cast<const sf_v8s*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = sf_bf2f((sf_bf16)v[i]);
+    }
+    static SF_DEVICE void st(sf_bf16* p, const float (&o)[8]) {
+        sf_v8s v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (short)sf_f2bf(o[i]);
+        *reinterpret_cast<sf_v8s*>(p) = v;
+    }
+};
+template <> struct SfVec8<float> {
+    static SF_DEVICE void ld(const float* p, float (&o)[8]) {
+        sf_v4f a = *reinterpret_cast<const sf_v4f*>(p);
+        sf_v4f b = *reinterpret_cast<const sf_v4f*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+    }
+    static SF_DEVICE void st(float* p, const float (&o)[8]) {
+        sf_v4f a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = o[i]; b[i] = o[4 + i]; }
+        *reinterpret_cast<sf_v4f*>(p) = a;
+        *reinterpret_cast<sf_v4f*>(p + 4) = b;
+    }
+};
+
+// Sum / max over a whole workgroup (blockDim.x multiple of 64, <= 1024).  `red` is LDS
+// scratch of >= 16 floats owned by the caller; result is returned to every thread.
+SF_DEVICE float sf_block_sum(float v, float* red) {
+    v = sf_wave_sum(v);
+    const int w = (int)threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
+    sf_syncthreads();
+    if (sf_lane() == 0) red[w] = v;
+    sf_syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+SF_DEVICE float sf_block_max(float v, float* red) {
+    v = sf_wave_max(v);
+    const int w = (int)threadIdx.x >> 6, nw = ((int)blockDim.x + 63) >> 6;
+    sf_syncthreads();
+    if (sf_lane() == 0) red[w] = v;
+    sf_syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}

@@ -1,0 +1,224 @@
+"""Tensor-level wrappers over the C-ABI (one function per entry point of include/specforge_amd.h).
+
+torch is used for what it is here for: device memory and streams.  Every function takes
+torch tensors living on the GPU, hands raw pointers / strides / the current HIP stream to
+libsfhip.so and returns.  No arithmetic happens in Python; there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+BF16, F32 = 0, 1
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"specforge_amd: unsupported dtype {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if t.is_cuda == _lib.is_emulated():
+        # product: everything must be on the GPU.  (emulated test build: everything on the host)
+        raise RuntimeError(
+            "specforge_amd ops need CUDA/HIP tensors (libsfhip.so runs on the GPU; there is no CPU path)"
+            if not _lib.is_emulated() else "emulated test build needs CPU tensors")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    if _lib.is_emulated():
+        return None
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _rowmajor(t: torch.Tensor) -> int:
+    """leading dimension (elements) of a 2-D view whose inner stride is 1"""
+    assert t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1), (t.shape, t.stride())
+    return t.stride(0)
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0,
+            residual: Optional[torch.Tensor] = None):
+    """out[M,N] = alpha * a[M,K] @ b[N,K]^T (+ beta*out) (+ residual); a, b bf16; out bf16|fp32."""
+    L = _lib.lib()
+    M, K = a.shape
+    N, K2 = b.shape
+    assert K == K2 and out.shape == (M, N) and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    _lib.check(L.sf_gemm_nt(_p(a), _rowmajor(a), _p(b), _rowmajor(b), _p(out), _dt(out), _rowmajor(out), M, N, K,
+                            alpha, beta, _p(residual), _rowmajor(residual) if residual is not None else 0, _stream()),
+               "sf_gemm_nt")
+    return out
+
+
+def ce_fused(logits: torch.Tensor, target_pad: torch.Tensor, *, S: int, Spad: int, off: int, pos_mask_pad, loss_mask_pad,
+             tgt_ids_pad=None, pod_scale_pad=None, tsum_pad=None, d2t=None, grad_scale: float = 1.0, write_grad: bool = True,
+             row_loss, row_correct, row_accept, row_pred=None):
+    L = _lib.lib()
+    rows, V = logits.shape
+    assert target_pad.dtype == torch.float32 and target_pad.is_contiguous() and target_pad.shape[-1] == V
+    _lib.check(L.sf_ce_fused(_p(logits), _dt(logits), _rowmajor(logits), rows, V, _p(target_pad), S, Spad, off,
+                             _p(pos_mask_pad), _p(loss_mask_pad), _p(tgt_ids_pad), _p(pod_scale_pad), _p(tsum_pad),
+                             _p(d2t), grad_scale, 1 if write_grad else 0, _p(row_loss), _p(row_correct), _p(row_accept),
+                             _p(row_pred), _stream()), "sf_ce_fused")
+
+
+def reduce_sum(inp: torch.Tensor, n: int, nseg: int, out: torch.Tensor, scale: float = 1.0):
+    L = _lib.lib()
+    assert inp.dtype == torch.float32 and out.dtype == torch.float32 and inp.numel() >= n * nseg and out.numel() >= nseg
+    _lib.check(L.sf_reduce_sum(_p(inp), n, nseg, _p(out), scale, _stream()), "sf_reduce_sum")
+    return out
+
+
+def teacher_reduce(z: torch.Tensor, *, Vd: int, d2t, t2d_u8, loss_mask_pad, S: int, Spad: int, target_p_pad,
+                   pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad, row0: int = 0):
+    """rows of z are tokens row0 .. row0+rows (row index b*S+s)."""
+    L = _lib.lib()
+    rows, Vt = z.shape
+    assert row0 == 0, "chunked teacher rows are addressed by offsetting the padded outputs on the caller side"
+    _lib.check(L.sf_teacher_reduce(_p(z), _dt(z), _rowmajor(z), rows, Vt, Vd, _p(d2t), _p(t2d_u8), _p(loss_mask_pad), S,
+                                   Spad, _p(target_p_pad), _p(pod_scale_pad), _p(tsum_pad), _p(ids_pad),
+                                   _p(pos_mask_pad), _stream()), "sf_teacher_reduce")
+
+
+def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, y: torch.Tensor, rstd: Optional[torch.Tensor], *,
+                ids_pad=None, S: int = 1, Spad: int = 1, off: int = 0, rows: Optional[int] = None):
+    L = _lib.lib()
+    H = w.numel()
+    rows = y.shape[0] if rows is None else rows
+    _lib.check(L.sf_rmsnorm_fwd(_p(x), _dt(x), _rowmajor(x), _p(ids_pad), S, Spad, off, _p(w), eps, rows, H, _p(y),
+                                _rowmajor(y), _p(rstd), _stream()), "sf_rmsnorm_fwd")
+    return y
+
+
+def rmsnorm_bwd_workspace(rows: int, H: int) -> int:
+    return int(_lib.lib().sf_rmsnorm_bwd_workspace_floats(rows, H))
+
+
+def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, rstd: torch.Tensor, *, dx=None, add=None, dw_acc=None,
+                dw_accumulate: bool = True, workspace=None, ids_pad=None, S: int = 1, Spad: int = 1, off: int = 0):
+    L = _lib.lib()
+    rows, H = dy.shape[0], w.numel()
+    _lib.check(L.sf_rmsnorm_bwd(_p(dy), _dt(dy), _rowmajor(dy), _p(x), _rowmajor(x), _p(ids_pad), S, Spad, off, _p(w),
+                                _p(rstd), rows, H, _p(add), _rowmajor(add) if add is not None else 0, _p(dx),
+                                _rowmajor(dx) if dx is not None else 0, _p(dw_acc), 1 if dw_accumulate else 0,
+                                _p(workspace), _stream()), "sf_rmsnorm_bwd")
+
+
+def rope_(x: torch.Tensor, nheads: int, hd: int, cos_t: torch.Tensor, sin_t: torch.Tensor, pos_ids: torch.Tensor,
+          pos_off: int, backward: bool = False):
+    """in place on the first nheads*hd columns of the 2-D view x"""
+    L = _lib.lib()
+    assert cos_t.dtype == x.dtype and cos_t.is_contiguous() and sin_t.is_contiguous() and pos_ids.dtype == torch.int64
+    _lib.check(L.sf_rope(_p(x), _dt(x), _rowmajor(x), x.shape[0], nheads, hd, _p(cos_t), _p(sin_t), _p(pos_ids), pos_off,
+                         cos_t.shape[0], 1 if backward else 0, _stream()), "sf_rope")
+    return x
+
+
+def swiglu_fwd(gu: torch.Tensor, act: torch.Tensor):
+    L = _lib.lib()
+    rows, I = act.shape
+    assert gu.shape == (rows, 2 * I)
+    _lib.check(L.sf_swiglu_fwd(_p(gu), _dt(gu), _rowmajor(gu), rows, I, _p(act), _rowmajor(act), _stream()), "sf_swiglu_fwd")
+    return act
+
+
+def swiglu_bwd(dact: torch.Tensor, gu: torch.Tensor, dgu: torch.Tensor):
+    L = _lib.lib()
+    rows, I = dact.shape
+    _lib.check(L.sf_swiglu_bwd(_p(dact), _dt(dact), _rowmajor(dact), _p(gu), _rowmajor(gu), rows, I, _p(dgu),
+                               _rowmajor(dgu), _stream()), "sf_swiglu_bwd")
+    return dgu
+
+
+def transpose2d(inp: torch.Tensor, out: torch.Tensor):
+    """out[C,R] = inp[R,C]^T for 2-D row-major views"""
+    L = _lib.lib()
+    R, C = inp.shape
+    assert out.shape == (C, R)
+    _lib.check(L.sf_transpose(_p(inp), _dt(inp), 0, 0, _rowmajor(inp), _p(out), 0, 0, _rowmajor(out), 1, 1, R, C,
+                              _stream()), "sf_transpose")
+    return out
+
+
+def transpose_heads(inp: torch.Tensor, out: torch.Tensor, B: int, S: int, nheads: int, hd: int):
+    """inp: [B*S, >= nheads*hd] view (heads at columns h*hd) -> out [B, nheads, hd, S] contiguous"""
+    L = _lib.lib()
+    ld = _rowmajor(inp)
+    assert out.is_contiguous() and out.numel() == B * nheads * hd * S
+    _lib.check(L.sf_transpose(_p(inp), _dt(inp), S * ld, hd, ld, _p(out), nheads * hd * S, hd * S, S, B, nheads, S, hd,
+                              _stream()), "sf_transpose")
+    return out
+
+
+def cast_from_f32(inp: torch.Tensor, out: torch.Tensor, scale: float = 1.0):
+    L = _lib.lib()
+    rows, C = inp.shape
+    assert inp.dtype == torch.float32 and out.shape == (rows, C)
+    _lib.check(L.sf_cast_from_f32(_p(inp), _rowmajor(inp), _p(out), _dt(out), _rowmajor(out), rows, C, scale, _stream()),
+               "sf_cast_from_f32")
+    return out
+
+
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    arr = (ctypes.c_void_p * max(1, len(ts)))()
+    for i, t in enumerate(ts):
+        arr[i] = _p(t).value
+    return arr
+
+
+def attn_fwd(q, k0, v0t, kd: List[torch.Tensor], vd: List[torch.Tensor], kv_len, o, lse, *, B, S, nh, nkv, hd, scale):
+    L = _lib.lib()
+    ldk = _rowmajor(k0)
+    for t in list(kd) + list(vd):
+        assert _rowmajor(t) == ldk
+    _lib.check(L.sf_attn_fwd(_p(q), _rowmajor(q), _p(k0), ldk, _p(v0t), _ptr_array(kd), _ptr_array(vd), len(kd),
+                             _p(kv_len), _p(o), _rowmajor(o), _p(lse), B, S, nh, nkv, hd, scale, _stream()), "sf_attn_fwd")
+
+
+def attn_bwd_pre(q, o, dout, kd, vd, dkd, dvd, lse, delta, dq_init, *, B, S, nh, nkv, hd, scale):
+    L = _lib.lib()
+    ldk = _rowmajor(kd[0]) if kd else 0
+    lddk = _rowmajor(dkd[0]) if dkd else 0
+    _lib.check(L.sf_attn_bwd_pre(_p(q), _rowmajor(q), _p(o), _rowmajor(o), _p(dout), _rowmajor(dout), _ptr_array(kd),
+                                 _ptr_array(vd), _ptr_array(dkd), _ptr_array(dvd), ldk, lddk, len(kd), _p(lse), _p(delta),
+                                 _p(dq_init), B, S, nh, nkv, hd, scale, _stream()), "sf_attn_bwd_pre")
+
+
+def attn_bwd_dq(q, dout, k0, v0, k0t, kv_len, lse, delta, dq_init, dq, *, B, S, nh, nkv, hd, scale):
+    L = _lib.lib()
+    _lib.check(L.sf_attn_bwd_dq(_p(q), _rowmajor(q), _p(dout), _rowmajor(dout), _p(k0), _rowmajor(k0), _p(v0),
+                                _rowmajor(v0), _p(k0t), _p(kv_len), _p(lse), _p(delta), _p(dq_init), _p(dq),
+                                _rowmajor(dq), B, S, nh, nkv, hd, scale, _stream()), "sf_attn_bwd_dq")
+
+
+def attn_bwd_dkv(q, dout, qt, dot, k0, v0, kv_len, lse, delta, dk, dv, *, B, S, nh, nkv, hd, scale):
+    L = _lib.lib()
+    assert dk.dtype == torch.float32 and dv.dtype == torch.float32 and _rowmajor(dk) == _rowmajor(dv)
+    _lib.check(L.sf_attn_bwd_dkv(_p(q), _rowmajor(q), _p(dout), _rowmajor(dout), _p(qt), _p(dot), _p(k0), _rowmajor(k0),
+                                 _p(v0), _rowmajor(v0), _p(kv_len), _p(lse), _p(delta), _p(dk), _p(dv), _rowmajor(dk),
+                                 B, S, nh, nkv, hd, scale, _stream()), "sf_attn_bwd_dkv")
+
+
+def grad_norm(g: torch.Tensor, norm_out: torch.Tensor, workspace: torch.Tensor, extra_sq: float = 0.0):
+    L = _lib.lib()
+    assert g.is_contiguous() and workspace.numel() >= L.sf_grad_norm_workspace_floats()
+    _lib.check(L.sf_grad_norm(_p(g), _dt(g), g.numel(), extra_sq, _p(norm_out), _p(workspace), _stream()), "sf_grad_norm")
+    return norm_out
+
+
+def adamw_step(g, master, m, v, param, norm, *, max_norm, lr, beta1, beta2, eps, wd, step, grad_prescale=1.0):
+    L = _lib.lib()
+    n = g.numel()
+    assert master.numel() == n and m.numel() == n and v.numel() == n and param.numel() == n
+    _lib.check(L.sf_adamw_step(_p(g), _dt(g), _p(master), _p(m), _p(v), _p(param), n, _p(norm), max_norm, lr, beta1, beta2,
+                               eps, wd, step, grad_prescale, _stream()), "sf_adamw_step")

@@ -1,0 +1,378 @@
+// SIMT interpreter for the specforge_amd HIP kernels.  TEST INFRASTRUCTURE ONLY.
+//
+// The kernels under specforge_amd/csrc are written against sf_platform.h.  With
+// -DSF_EMU that header includes this file instead of <hip/hip_runtime.h> and the
+// very same kernel source is compiled for the x86 host (amdclang++ -x c++): every
+// GPU thread becomes a ucontext fiber, workgroups are distributed over a few OS
+// threads, and __syncthreads() / wave shuffles / MFMA / LDS-DMA are rendezvous
+// points between the fibers of a workgroup.  This is a kernel *debugger* (index
+// logic, divergent barriers, out-of-bounds via -fsanitize=address); it is not a
+// product path: specforge_amd/_lib.py only ever loads libsfhip.so, the tests
+// inject the emulated library explicitly.
+//
+// Lane layouts emulated here are the ones the CDNA4 guide documents:
+//   mfma_f32_16x16x32_bf16: A[i=l&15][k=8*(l>>4)+j]  B[k=8*(l>>4)+j][n=l&15]
+//                           D[row=4*(l>>4)+r][col=l&15]
+//   mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+j]  B[k=8*(l>>5)+j][n=l&31]
+//                           D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]
+//   global_load_lds 16B   : LDS dst = (first lane's dst) + 16*lane, src per lane
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define SFEMU_ASAN 1
+extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
+#endif
+#endif
+
+namespace sfemu {
+
+struct uint3e {
+    unsigned x, y, z;
+};
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+enum FiberState { RUNNABLE = 0, AT_BLOCK_BARRIER = 1, AT_WAVE_SYNC = 2, DONE = 3 };
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    int state = RUNNABLE;
+    uint3e tid{0, 0, 0};
+    int linear = 0;
+    unsigned coll_ops = 0;
+    void* asan_fake = nullptr;
+};
+
+static constexpr size_t kStackBytes = 256 * 1024;
+static constexpr int kSlotBytes = 128;  // per-lane exchange payload
+
+struct Wave {
+    alignas(16) unsigned char slot[2][64][kSlotBytes];
+};
+
+struct BlockCtx {
+    std::vector<Fiber> fibers;
+    std::vector<Wave> waves;
+    ucontext_t sched;
+    void* sched_asan_fake = nullptr;
+    const void* sched_stack_bottom = nullptr;
+    size_t sched_stack_size = 0;
+    int nthreads = 0;
+    Fiber* cur = nullptr;
+    uint3e bid{0, 0, 0};
+    dim3 bdim, gdim;
+    const std::function<void()>* body = nullptr;
+    std::vector<char> dyn_smem;
+    std::vector<char> stack_pool;
+};
+
+inline BlockCtx*& tls_ctx() {
+    static thread_local BlockCtx* c = nullptr;
+    return c;
+}
+
+inline void switch_to_sched() {
+    BlockCtx* c = tls_ctx();
+    Fiber* f = c->cur;
+#ifdef SFEMU_ASAN
+    __sanitizer_start_switch_fiber(f->state == DONE ? nullptr : &f->asan_fake, c->sched_stack_bottom, c->sched_stack_size);
+#endif
+    swapcontext(&f->ctx, &c->sched);
+#ifdef SFEMU_ASAN
+    __sanitizer_finish_switch_fiber(f->asan_fake, nullptr, nullptr);
+#endif
+}
+
+inline void fiber_entry() {
+    BlockCtx* c = tls_ctx();
+#ifdef SFEMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &c->sched_stack_bottom, &c->sched_stack_size);
+#endif
+    (*c->body)();
+    c->cur->state = DONE;
+    switch_to_sched();
+}
+
+inline void run_block(BlockCtx* c) {
+    const int n = c->nthreads;
+    for (int i = 0; i < n; ++i) {
+        Fiber& f = c->fibers[i];
+        f.state = RUNNABLE;
+        f.coll_ops = 0;
+        f.asan_fake = nullptr;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStackBytes;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    }
+    const int nwaves = (n + 63) / 64;
+    for (;;) {
+        bool ran = false;
+        for (int i = 0; i < n; ++i) {
+            Fiber& f = c->fibers[i];
+            if (f.state != RUNNABLE) continue;
+            ran = true;
+            c->cur = &f;
+#ifdef SFEMU_ASAN
+            __sanitizer_start_switch_fiber(&c->sched_asan_fake, f.stack, kStackBytes);
+#endif
+            swapcontext(&c->sched, &f.ctx);
+#ifdef SFEMU_ASAN
+            __sanitizer_finish_switch_fiber(c->sched_asan_fake, nullptr, nullptr);
+#endif
+        }
+        bool released = false;
+        int live = 0, at_bar = 0;
+        for (int w = 0; w < nwaves; ++w) {
+            int lo = w * 64, hi = std::min(n, lo + 64), wl = 0, ws = 0;
+            for (int i = lo; i < hi; ++i) {
+                int s = c->fibers[i].state;
+                if (s != DONE) ++wl;
+                if (s == AT_WAVE_SYNC) ++ws;
+                if (s == AT_BLOCK_BARRIER) ++at_bar;
+            }
+            live += wl;
+            if (wl > 0 && ws == wl) {
+                for (int i = lo; i < hi; ++i)
+                    if (c->fibers[i].state == AT_WAVE_SYNC) c->fibers[i].state = RUNNABLE;
+                released = true;
+            }
+        }
+        if (live == 0) break;
+        if (at_bar == live) {
+            for (int i = 0; i < n; ++i)
+                if (c->fibers[i].state == AT_BLOCK_BARRIER) c->fibers[i].state = RUNNABLE;
+            released = true;
+        }
+        if (!released && !ran) {
+            fprintf(stderr, "[sfemu] DEADLOCK in block (%u,%u,%u): divergent barrier / wave collective\n", c->bid.x, c->bid.y, c->bid.z);
+            for (int i = 0; i < n; ++i) fprintf(stderr, "%d", c->fibers[i].state);
+            fprintf(stderr, "\n");
+            abort();
+        }
+    }
+}
+
+inline int emu_threads() {
+    static int n = [] {
+        const char* e = getenv("SFEMU_THREADS");
+        int v = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+        return std::max(1, std::min(v, 64));
+    }();
+    return n;
+}
+
+inline void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
+    const long nblocks = (long)grid.x * grid.y * grid.z;
+    const int nthreads = (int)(block.x * block.y * block.z);
+    if (nblocks <= 0 || nthreads <= 0) return;
+    std::atomic<long> next{0};
+    auto worker = [&]() {
+        BlockCtx ctx;
+        ctx.nthreads = nthreads;
+        ctx.fibers.resize(nthreads);
+        ctx.waves.resize((nthreads + 63) / 64);
+        ctx.stack_pool.resize((size_t)nthreads * kStackBytes);
+        ctx.dyn_smem.resize(smem + 64);
+        ctx.bdim = block;
+        ctx.gdim = grid;
+        ctx.body = &body;
+        for (int i = 0; i < nthreads; ++i) {
+            Fiber& f = ctx.fibers[i];
+            f.stack = ctx.stack_pool.data() + (size_t)i * kStackBytes;
+            f.linear = i;
+            f.tid.x = i % block.x;
+            f.tid.y = (i / block.x) % block.y;
+            f.tid.z = i / (block.x * block.y);
+        }
+        tls_ctx() = &ctx;
+        for (;;) {
+            long b = next.fetch_add(1);
+            if (b >= nblocks) break;
+            ctx.bid.x = (unsigned)(b % grid.x);
+            ctx.bid.y = (unsigned)((b / grid.x) % grid.y);
+            ctx.bid.z = (unsigned)(b / ((long)grid.x * grid.y));
+            run_block(&ctx);
+        }
+        tls_ctx() = nullptr;
+    };
+    int nt = (int)std::min<long>(emu_threads(), nblocks);
+    if (nt <= 1) {
+        // still run on a fresh OS thread: thread_local __shared__ arrays stay per-launch-thread
+        std::thread t(worker);
+        t.join();
+    } else {
+        std::vector<std::thread> ts;
+        for (int i = 0; i < nt; ++i) ts.emplace_back(worker);
+        for (auto& t : ts) t.join();
+    }
+}
+
+// ---- what kernels see -------------------------------------------------------
+inline uint3e cur_tid() { return tls_ctx()->cur->tid; }
+inline uint3e cur_bid() { return tls_ctx()->bid; }
+inline dim3 cur_bdim() { return tls_ctx()->bdim; }
+inline dim3 cur_gdim() { return tls_ctx()->gdim; }
+inline char* dyn_smem_base() {
+    char* p = tls_ctx()->dyn_smem.data();
+    return (char*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+}
+
+inline void block_barrier() {
+    tls_ctx()->cur->state = AT_BLOCK_BARRIER;
+    switch_to_sched();
+}
+inline void wave_sync() {
+    tls_ctx()->cur->state = AT_WAVE_SYNC;
+    switch_to_sched();
+}
+inline int lane_id() { return tls_ctx()->cur->linear & 63; }
+inline int wave_index() { return tls_ctx()->cur->linear >> 6; }
+inline int wave_lanes() {
+    BlockCtx* c = tls_ctx();
+    int lo = wave_index() * 64;
+    return std::min(64, c->nthreads - lo);
+}
+
+// publish `bytes` of this lane, rendezvous, return the wave's slot table for reading.
+// Double-buffered by the per-fiber collective counter: a lane may start collective
+// n+1 (other buffer) while slower lanes still read buffer n; buffer n is rewritten
+// only by collective n+2, which every lane reaches after passing rendezvous n+1.
+typedef unsigned char SlotRow[kSlotBytes];
+inline SlotRow* wave_exchange(const void* mine, int bytes) {
+    BlockCtx* c = tls_ctx();
+    Fiber* f = c->cur;
+    Wave& w = c->waves[f->linear >> 6];
+    int par = (int)(f->coll_ops++ & 1u);
+    memcpy(w.slot[par][f->linear & 63], mine, (size_t)bytes);
+    wave_sync();
+    return w.slot[par];
+}
+
+template <typename T>
+inline T shfl(T v, int src_lane) {
+    static_assert(sizeof(T) <= kSlotBytes, "payload");
+    SlotRow* s = wave_exchange(&v, sizeof(T));
+    T r;
+    int n = wave_lanes();
+    int sl = src_lane & 63;
+    if (sl >= n) sl = lane_id();
+    memcpy(&r, s[sl], sizeof(T));
+    return r;
+}
+template <typename T>
+inline T shfl_xor(T v, int mask) {
+    return shfl(v, lane_id() ^ mask);
+}
+template <typename T>
+inline T shfl_down(T v, int d) {
+    int l = lane_id() + d;
+    return shfl(v, l > 63 ? lane_id() : l);
+}
+
+inline float bf16_bits_to_f(unsigned short h) {
+    unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+inline v4f mfma_16x16x32_bf16(v8s a, v8s b, v4f c) {
+    struct P {
+        v8s a, b;
+    } p{a, b};
+    SlotRow* s = wave_exchange(&p, sizeof(P));
+    int l = lane_id();
+    int col = l & 15;
+    v4f d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (l >> 4) + r;
+        float acc = 0.f;
+        for (int k = 0; k < 32; ++k) {
+            P pa, pb;
+            memcpy(&pa, s[row + 16 * (k >> 3)], sizeof(P));
+            memcpy(&pb, s[col + 16 * (k >> 3)], sizeof(P));
+            acc += bf16_bits_to_f((unsigned short)pa.a[k & 7]) * bf16_bits_to_f((unsigned short)pb.b[k & 7]);
+        }
+        d[r] = c[r] + acc;
+    }
+    return d;
+}
+
+inline v16f mfma_32x32x16_bf16(v8s a, v8s b, v16f c) {
+    struct P {
+        v8s a, b;
+    } p{a, b};
+    SlotRow* s = wave_exchange(&p, sizeof(P));
+    int l = lane_id();
+    int col = l & 31;
+    v16f d = c;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = 0.f;
+        for (int k = 0; k < 16; ++k) {
+            P pa, pb;
+            memcpy(&pa, s[row + 32 * (k >> 3)], sizeof(P));
+            memcpy(&pb, s[col + 32 * (k >> 3)], sizeof(P));
+            acc += bf16_bits_to_f((unsigned short)pa.a[k & 7]) * bf16_bits_to_f((unsigned short)pb.b[k & 7]);
+        }
+        d[r] = c[r] + acc;
+    }
+    return d;
+}
+
+// LDS-DMA: every lane passes its own source; the destination is wave-uniform
+// base (first lane's pointer) + 16*lane.  A lane whose own dst differs from that
+// is a layout bug on real hardware, so it is fatal here.
+inline void global_load_lds16(const void* gsrc, void* lds_dst) {
+    struct P {
+        const void* g;
+        void* l;
+    } p{gsrc, lds_dst};
+    SlotRow* s = wave_exchange(&p, sizeof(P));
+    P first;
+    memcpy(&first, s[0], sizeof(P));
+    char* dst = (char*)first.l + 16 * lane_id();
+    if (dst != (char*)lds_dst) {
+        fprintf(stderr, "[sfemu] global_load_lds: lane %d dst is not base+16*lane\n", lane_id());
+        abort();
+    }
+    memcpy(dst, gsrc, 16);
+}
+
+template <typename T>
+inline T atomic_add(T* p, T v) {
+    if constexpr (std::is_floating_point<T>::value) {
+        T old = *p, des;
+        do {
+            des = old + v;
+        } while (!__atomic_compare_exchange(p, &old, &des, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+        return old;
+    } else {
+        return __atomic_fetch_add(p, v, __ATOMIC_RELAXED);
+    }
+}
+
+}  // namespace sfemu

@@ -1,0 +1,110 @@
+"""TTT attention kernels vs the oracle's sdpa-backend restatement
+(oracle/eagle3_oracle.py::ttt_attention <- llama3_eagle.py:745-778), forward and all
+gradients (dq, dK/dV of block 0, dK_i/dV_i of the diagonal branches), GQA, right padding,
+sequence lengths that are not multiples of the tile sizes.  Mirrors the reference's
+backend-vs-sdpa parity tests (tests/test_utils/test_flex_attention.py:47-242, atol/rtol 1e-2
+forward; tests/test_utils/test_flash_attention.py:35-42 for bf16).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import eagle3_oracle as O
+from specforge_amd import ops
+
+
+def _mk(B, S, nh, nkv, hd, nsteps, seed):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(B, S, nh * hd, generator=g).to(torch.bfloat16)
+    ks = [torch.randn(B, S, nkv * hd, generator=g).to(torch.bfloat16) for _ in range(nsteps)]
+    vs = [torch.randn(B, S, nkv * hd, generator=g).to(torch.bfloat16) for _ in range(nsteps)]
+    do = torch.randn(B, S, nh * hd, generator=g).to(torch.bfloat16)
+    return q, ks, vs, do
+
+
+def _oracle(q, ks, vs, do, B, S, nh, nkv, hd, lengths):
+    """fp32 oracle on the bf16-rounded inputs"""
+    qf = q.float().view(B, S, nh, hd).transpose(1, 2).requires_grad_(True)
+    kf = [k.float().view(B, S, nkv, hd).transpose(1, 2).requires_grad_(True) for k in ks]
+    vf = [v.float().view(B, S, nkv, hd).transpose(1, 2).requires_grad_(True) for v in vs]
+    am = torch.zeros(B, S, dtype=torch.long)
+    for b, L in enumerate(lengths):
+        am[b, :L] = 1
+    add_mask = O.additive_attention_mask(am.bool(), S, torch.float32)
+    rep = nh // nkv
+    out = O.ttt_attention(qf, [O.repeat_kv(k, rep) for k in kf], [O.repeat_kv(v, rep) for v in vf], add_mask, hd)
+    out.backward(do.float().view(B, S, nh, hd).transpose(1, 2))
+    flat = lambda t: t.transpose(1, 2).reshape(B * S, -1)
+    return flat(out.detach()), flat(qf.grad), [flat(k.grad) for k in kf], [flat(v.grad) for v in vf]
+
+
+@pytest.mark.parametrize("hd", [64, 128])
+@pytest.mark.parametrize("B,S,nh,nkv,lengths,nsteps", [
+    (2, 48, 4, 2, [48, 23], 1),
+    (2, 48, 4, 2, [48, 23], 3),
+    (1, 200, 2, 1, [200], 4),
+    (1, 136, 2, 2, [130], 7),
+])
+def test_ttt_attention_fwd_bwd(backend, hd, B, S, nh, nkv, lengths, nsteps):
+    q, ks, vs, do = _mk(B, S, nh, nkv, hd, nsteps, seed=hd + S)
+    o_ref, dq_ref, dk_ref, dv_ref = _oracle(q, ks, vs, do, B, S, nh, nkv, hd, lengths)
+    d = lambda t: t.to(backend)
+    scale = 1.0 / math.sqrt(hd)
+    N = B * S
+    # the kernels see [B*S, *] views of wider (fused qkv) buffers
+    qkv = [torch.zeros(N, (nh + 2 * nkv) * hd, dtype=torch.bfloat16) for _ in range(nsteps)]
+    for i in range(nsteps):
+        qkv[i][:, nh * hd:(nh + nkv) * hd] = ks[i].view(N, -1)
+        qkv[i][:, (nh + nkv) * hd:] = vs[i].view(N, -1)
+    qkv[-1][:, :nh * hd] = q.view(N, -1)
+    qkv = [d(t) for t in qkv]
+    qv = qkv[-1][:, :nh * hd]
+    kview = [t[:, nh * hd:(nh + nkv) * hd] for t in qkv]
+    vview = [t[:, (nh + nkv) * hd:] for t in qkv]
+    kv_len = d(torch.tensor(lengths, dtype=torch.int32))
+    v0t = torch.empty(B, nkv, hd, S, dtype=torch.bfloat16, device=backend)
+    k0t = torch.empty_like(v0t)
+    ops.transpose_heads(vview[0], v0t, B, S, nkv, hd)
+    ops.transpose_heads(kview[0], k0t, B, S, nkv, hd)
+    o = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=backend)
+    lse = torch.empty(B, nh, S, device=backend)
+    ops.attn_fwd(qv, kview[0], v0t, kview[1:], vview[1:], kv_len, o, lse, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+    torch.testing.assert_close(o.float().cpu(), o_ref, rtol=2e-2, atol=2e-2)
+
+    # backward
+    dout = d(do.view(N, -1))
+    delta = torch.empty(B, nh, S, device=backend)
+    dq_init = torch.zeros(N, nh * hd, device=backend) if nsteps > 1 else None
+    dk_acc = [torch.zeros(N, nkv * hd, device=backend) for _ in range(nsteps)]
+    dv_acc = [torch.zeros(N, nkv * hd, device=backend) for _ in range(nsteps)]
+    ops.attn_bwd_pre(qv, o, dout, kview[1:], vview[1:], dk_acc[1:], dv_acc[1:], lse, delta, dq_init, B=B, S=S, nh=nh,
+                     nkv=nkv, hd=hd, scale=scale)
+    dq = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=backend)
+    ops.attn_bwd_dq(qv, dout, kview[0], vview[0], k0t, kv_len, lse, delta, dq_init, dq, B=B, S=S, nh=nh, nkv=nkv, hd=hd,
+                    scale=scale)
+    qt = torch.empty(B, nh, hd, S, dtype=torch.bfloat16, device=backend)
+    dot = torch.empty_like(qt)
+    ops.transpose_heads(qv, qt, B, S, nh, hd)
+    ops.transpose_heads(dout, dot, B, S, nh, hd)
+    ops.attn_bwd_dkv(qv, dout, qt, dot, kview[0], vview[0], kv_len, lse, delta, dk_acc[0], dv_acc[0], B=B, S=S, nh=nh,
+                     nkv=nkv, hd=hd, scale=scale)
+
+    def close(got, ref, what):
+        tol = 3e-2 * float(ref.abs().max()) + 1e-6
+        err = float((got.float().cpu() - ref).abs().max())
+        assert err <= tol, (what, err, tol)
+
+    close(dq, dq_ref, "dq")
+    for i in range(nsteps):
+        close(dk_acc[i], dk_ref[i], f"dk{i}")
+        close(dv_acc[i], dv_ref[i], f"dv{i}")
+    # padded keys of block 0 receive exactly zero gradient
+    for b, L in enumerate(lengths):
+        assert float(dk_acc[0].view(B, S, -1)[b, L:].abs().max() if L < S else 0.0) == 0.0
+        assert float(dv_acc[0].view(B, S, -1)[b, L:].abs().max() if L < S else 0.0) == 0.0
+    # accumulation semantics: a second backward call adds into the fp32 buffers
+    before = dk_acc[0].clone()
+    ops.attn_bwd_dkv(qv, dout, qt, dot, kview[0], vview[0], kv_len, lse, delta, dk_acc[0], dv_acc[0], B=B, S=S, nh=nh,
+                     nkv=nkv, hd=hd, scale=scale)
+    torch.testing.assert_close(dk_acc[0].cpu(), 2 * before.cpu(), rtol=1e-5, atol=1e-6)

@@ -1,0 +1,281 @@
+"""Per-kernel parity tests of the C-ABI ops against the CPU oracle / plain torch fp32.
+
+Each test runs twice: ``[emu]`` = the kernel sources under the SIMT interpreter on CPU
+tensors (runs everywhere, checks index logic + host glue), ``[gpu]`` = libsfhip.so on a
+real MI355X (marked ``gpu``; the parity tests proper, incl. the reference's own CE test
+grid shapes, tests/test_utils/test_loss.py:13-39).
+
+Tolerances: integer artefacts bit-exact; fp32 kernels 1e-4 (the reference's own
+rtol/atol for its Triton CE, tests/test_utils/test_loss.py:24-30) ... 1e-3 (north_star
+fp32 tolerance); bf16 2e-2 (north_star bf16 tolerance).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import eagle3_oracle as O
+from specforge_amd import ops
+
+
+def _dev(backend, t):
+    return t.to(backend)
+
+
+def _rand(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (64, 48, 288), (257, 384, 512)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_nt(backend, M, N, K, out_dtype):
+    a = _rand((M, K), torch.bfloat16, 1)
+    b = _rand((N, K), torch.bfloat16, 2)
+    # asymmetric operands catch transposed outputs
+    ref = a.float() @ b.float().t()
+    out = torch.full((M, N), 7.0, dtype=out_dtype, device=backend)
+    ops.gemm_nt(_dev(backend, a), _dev(backend, b), out)
+    tol = 1e-3 if out_dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=tol, atol=tol * math.sqrt(K))
+
+
+def test_gemm_nt_epilogues(backend):
+    M, N, K = 136, 72, 128
+    a, b = _rand((M, K), torch.bfloat16, 3), _rand((N, K), torch.bfloat16, 4)
+    res = _rand((M, N), torch.bfloat16, 5)
+    c0 = _rand((M, N), torch.float32, 6)
+    ref = a.float() @ b.float().t()
+    out = c0.clone().to(backend)
+    ops.gemm_nt(_dev(backend, a), _dev(backend, b), out, alpha=0.5, beta=2.0)
+    torch.testing.assert_close(out.cpu(), 0.5 * ref + 2.0 * c0, rtol=1e-3, atol=1e-2)
+    outb = torch.empty((M, N), dtype=torch.bfloat16, device=backend)
+    ops.gemm_nt(_dev(backend, a), _dev(backend, b), outb, residual=_dev(backend, res))
+    expect = (ref.to(torch.bfloat16) + res).float()
+    torch.testing.assert_close(outb.float().cpu(), expect, rtol=2e-2, atol=0.25)
+    # strided views (column slices of wider buffers)
+    wide = torch.zeros((M, N + 40), dtype=torch.bfloat16, device=backend)
+    ops.gemm_nt(_dev(backend, a), _dev(backend, b), wide[:, 8:8 + N])
+    torch.testing.assert_close(wide[:, 8:8 + N].float().cpu(), ref, rtol=2e-2, atol=0.25)
+    assert float(wide[:, :8].abs().max()) == 0 and float(wide[:, 8 + N:].abs().max()) == 0
+
+
+# ------------------------------------------------------------------ fused CE
+def _ce_reference(logits, target, pos_mask, pod_scale, d2t, tgt_ids, loss_mask, gs):
+    x = logits.float().clone().requires_grad_(True)
+    lp = torch.log_softmax(x, dim=-1)
+    row_loss = -(target * lp).sum(-1) * pos_mask
+    (row_loss.sum() * gs).backward()
+    sm = torch.softmax(logits.float(), -1)
+    accept = torch.minimum(target * pod_scale[:, None], sm).sum(-1) * pos_mask
+    pred = logits.float().argmax(-1)
+    correct = ((pred + d2t[pred]) == tgt_ids).float() * loss_mask
+    return row_loss.detach(), x.grad, accept, correct, pred
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("B,S,V,T,off", [(2, 16, 256, 3, 0), (1, 24, 1000, 4, 2), (2, 8, 4096, 7, 5)])
+def test_ce_fused(backend, dtype, tol, B, S, V, T, off):
+    Spad = S + T
+    g = torch.Generator().manual_seed(7)
+    logits = (torch.randn(B * S, V, generator=g) * 2).to(dtype)
+    logits[3, 5] = logits[3].max() + 1  # a clear argmax
+    logits[4, 9] = logits[4, 2] = logits[4].float().max().to(dtype) + 2  # a tie -> lowest index
+    target_pad = torch.softmax(torch.randn(B, Spad, V, generator=g) * 3, -1)
+    pos_pad = (torch.rand(B, Spad, generator=g) > 0.3).int()
+    lm_pad = (torch.rand(B, Spad, generator=g) > 0.2).int()
+    pod_pad = torch.rand(B, Spad, generator=g)
+    tsum_pad = target_pad.sum(-1)
+    d2t = torch.randint(0, 50, (V,), generator=g).sort().values
+    ids_pad = torch.randint(0, V + 50, (B, Spad), generator=g)
+    sl = lambda t: t[:, off:off + S].reshape(B * S, *t.shape[2:])
+    gs = 0.64 / (B * S)
+    rl, grad, acc, cor, pred = _ce_reference(logits, sl(target_pad), sl(pos_pad).float(), sl(pod_pad), d2t, sl(ids_pad),
+                                             sl(lm_pad).float(), gs)
+    # make some rows provably "correct"
+    pr = pred + d2t[pred]
+    ids_pad[:, off:off + S] = torch.where(torch.arange(B * S).view(B, S) % 2 == 0, pr.view(B, S), ids_pad[:, off:off + S])
+    cor = ((pr == sl(ids_pad)).float() * sl(lm_pad).float())
+    d = lambda t: t.to(backend)
+    x = d(logits.clone())
+    row_loss, row_cor, row_acc = (torch.empty(B * S, device=backend) for _ in range(3))
+    row_pred = torch.empty(B * S, dtype=torch.int32, device=backend)
+    ops.ce_fused(x, d(target_pad), S=S, Spad=Spad, off=off, pos_mask_pad=d(pos_pad), loss_mask_pad=d(lm_pad),
+                 tgt_ids_pad=d(ids_pad), pod_scale_pad=d(pod_pad), tsum_pad=d(tsum_pad), d2t=d(d2t), grad_scale=gs,
+                 row_loss=row_loss, row_correct=row_cor, row_accept=row_acc, row_pred=row_pred)
+    assert torch.equal(row_pred.cpu().long(), pred)          # integer artefact: bit-exact
+    assert torch.equal(row_cor.cpu(), cor)                   # integer-valued
+    torch.testing.assert_close(row_loss.cpu(), rl, rtol=tol, atol=tol)
+    torch.testing.assert_close(row_acc.cpu(), acc, rtol=tol, atol=tol)
+    gtol = tol * float(grad.abs().max())
+    torch.testing.assert_close(x.float().cpu(), grad, rtol=tol, atol=gtol)
+    # masked rows carry exactly zero gradient (core/loss.py:160-170)
+    assert float(x.float().cpu()[sl(pos_pad) == 0].abs().max()) == 0.0
+    # drop-in mode: tsum computed in-kernel, no pod/ids
+    x2 = d(logits.clone())
+    ops.ce_fused(x2, d(target_pad), S=S, Spad=Spad, off=off, pos_mask_pad=d(pos_pad), loss_mask_pad=d(lm_pad),
+                 grad_scale=gs, row_loss=row_loss, row_correct=row_cor, row_accept=row_acc)
+    torch.testing.assert_close(x2.float().cpu(), grad, rtol=tol, atol=gtol)
+    out = torch.empty(1, device=backend)
+    ops.reduce_sum(row_loss, B * S, 1, out, 1.0 / (B * S))
+    torch.testing.assert_close(out.cpu()[0], rl.mean(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ teacher
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_teacher_reduce(backend, dtype):
+    B, S, T, Vt, Vd = 2, 12, 3, 640, 256
+    Spad = S + T
+    g = torch.Generator().manual_seed(11)
+    z = (torch.randn(B * S, Vt, generator=g) * 3).to(dtype)
+    z[2, 77] = z[2, 5] = z[2].float().max().to(dtype) + 1  # tie -> lowest index
+    t2d, d2t = O.make_vocab_mapping(Vt, Vd, seed=1)
+    loss_mask = (torch.rand(B, S, generator=g) > 0.2).long()
+    tp, tpod, ids, pm = O.compute_target_p(z.view(B, S, Vt), t2d, loss_mask[..., None])
+    d = lambda t: t.to(backend)
+    lm_pad = torch.zeros(B, Spad, dtype=torch.int32)
+    lm_pad[:, :S] = loss_mask.int()
+    tp_pad = torch.full((B, Spad, Vd), 1.0 / Vd, device=backend)
+    pod = torch.zeros(B, Spad, device=backend)
+    tsum = torch.zeros(B, Spad, device=backend)
+    ids_pad = torch.zeros(B, Spad, dtype=torch.int64, device=backend)
+    pm_pad = torch.zeros(B, Spad, dtype=torch.int32, device=backend)
+    ops.teacher_reduce(d(z), Vd=Vd, d2t=d(d2t), t2d_u8=d(t2d.to(torch.uint8)), loss_mask_pad=d(lm_pad), S=S, Spad=Spad,
+                       target_p_pad=tp_pad, pod_scale_pad=pod, tsum_pad=tsum, ids_pad=ids_pad, pos_mask_pad=pm_pad)
+    assert torch.equal(ids_pad.cpu()[:, :S], ids)                       # bit-exact
+    assert torch.equal(pm_pad.cpu()[:, :S, None], pm.int())            # bit-exact
+    torch.testing.assert_close(tp_pad.cpu()[:, :S], tp, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(tp_pad.cpu()[:, :S] * pod.cpu()[:, :S, None], tpod, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(tsum.cpu()[:, :S], tp.sum(-1), rtol=1e-5, atol=1e-6)
+    assert float((tp_pad.cpu()[:, S:] - 1.0 / Vd).abs().max()) == 0    # padded tail untouched
+
+
+# ------------------------------------------------------------------ RMSNorm
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("R,H", [(20, 128), (33, 896)])
+def test_rmsnorm_fwd_bwd(backend, dtype, tol, R, H):
+    x = _rand((R, H), dtype, 1)
+    w = (1 + 0.1 * _rand((H,), torch.float32, 2)).to(dtype)
+    dy = _rand((R, H), dtype, 3)
+    add = _rand((R, H), dtype, 4)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = O.rmsnorm(xr, wr, 1e-5)
+    y_ref.backward(dy)
+    d = lambda t: t.to(backend)
+    ycat = torch.zeros((R, 2 * H), dtype=dtype, device=backend)
+    rstd = torch.empty(R, device=backend)
+    ops.rmsnorm_fwd(d(x), d(w), 1e-5, ycat[:, H:], rstd)
+    torch.testing.assert_close(ycat[:, H:].float().cpu(), y_ref.detach().float(), rtol=tol, atol=tol)
+    assert float(ycat[:, :H].abs().max()) == 0
+    dx = torch.empty((R, H), dtype=dtype, device=backend)
+    dw = torch.full((H,), 0.5, device=backend)
+    ws = torch.empty(ops.rmsnorm_bwd_workspace(R, H), device=backend)
+    ops.rmsnorm_bwd(d(dy), d(x), d(w), rstd, dx=dx, add=d(add), dw_acc=dw, dw_accumulate=True, workspace=ws)
+    gx = xr.grad.float() + add.float()
+    torch.testing.assert_close(dx.float().cpu(), gx, rtol=tol, atol=tol * float(gx.abs().max()))
+    gw = wr.grad.float()
+    torch.testing.assert_close(dw.cpu() - 0.5, gw, rtol=max(tol, 1e-4), atol=max(tol, 1e-4) * float(gw.abs().max()))
+
+
+def test_rmsnorm_gather(backend):
+    B, S, T, H, V = 2, 8, 3, 128, 50
+    table = _rand((V, H), torch.bfloat16, 1)
+    w = (1 + 0.1 * _rand((H,), torch.float32, 2)).to(torch.bfloat16)
+    ids_pad = torch.zeros(B, S + T, dtype=torch.int64)
+    ids_pad[:, :S] = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(3))
+    for off in (0, 2):
+        y = torch.empty((B * S, H), dtype=torch.bfloat16, device=backend)
+        rstd = torch.empty(B * S, device=backend)
+        ops.rmsnorm_fwd(table.to(backend), w.to(backend), 1e-5, y, rstd, ids_pad=ids_pad.to(backend), S=S, Spad=S + T, off=off)
+        emb = table[ids_pad[:, off:off + S].reshape(-1)]
+        torch.testing.assert_close(y.float().cpu(), O.rmsnorm(emb, w, 1e-5).float(), rtol=2e-2, atol=2e-2)
+
+
+# ------------------------------------------------------------------ RoPE / SwiGLU / transpose / cast
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("hd", [64, 128])
+def test_rope(backend, dtype, tol, hd):
+    B, S, nh, nkv = 2, 8, 3, 1
+    cfg = O.DraftConfig(hidden_size=nh * hd, intermediate_size=8, num_attention_heads=nh, num_key_value_heads=nkv,
+                        vocab_size=8, draft_vocab_size=8, head_dim=hd, max_position_embeddings=64)
+    cos, sin = O.rope_tables(cfg, 84, dtype)
+    qkv = _rand((B * S, (nh + 2 * nkv) * hd), dtype, 1)
+    pos = torch.arange(S).repeat(B)
+    q = qkv[:, :nh * hd].reshape(B, S, nh, hd).transpose(1, 2).clone().requires_grad_(True)
+    k = qkv[:, nh * hd:(nh + nkv) * hd].reshape(B, S, nkv, hd).transpose(1, 2).clone().requires_grad_(True)
+    qe, ke = O.apply_rope(q, k, cos, sin, pos.view(B, S) + 3)
+    x = qkv.clone().to(backend)
+    ops.rope_(x, nh + nkv, hd, cos.to(backend), sin.to(backend), pos.to(backend), 3)
+    got_q = x[:, :nh * hd].reshape(B, S, nh, hd).transpose(1, 2).float().cpu()
+    got_k = x[:, nh * hd:(nh + nkv) * hd].reshape(B, S, nkv, hd).transpose(1, 2).float().cpu()
+    torch.testing.assert_close(got_q, qe.detach().float(), rtol=tol, atol=tol)
+    torch.testing.assert_close(got_k, ke.detach().float(), rtol=tol, atol=tol)
+    assert torch.equal(x[:, (nh + nkv) * hd:].cpu(), qkv[:, (nh + nkv) * hd:])  # v untouched
+    dq = _rand(q.shape, dtype, 2)
+    qe.backward(dq)
+    g = dq.transpose(1, 2).reshape(B * S, nh * hd).clone().to(backend)
+    ops.rope_(g, nh, hd, cos.to(backend), sin.to(backend), pos.to(backend), 3, backward=True)
+    torch.testing.assert_close(g.float().cpu(), q.grad.transpose(1, 2).reshape(B * S, nh * hd).float(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_swiglu(backend, dtype, tol):
+    R, I = 37, 192
+    gu = _rand((R, 2 * I), dtype, 1)
+    dact = _rand((R, I), dtype, 2)
+    gr = gu.clone().requires_grad_(True)
+    ref = torch.nn.functional.silu(gr[:, :I]) * gr[:, I:]
+    ref.backward(dact)
+    act = torch.empty((R, I), dtype=dtype, device=backend)
+    ops.swiglu_fwd(gu.to(backend), act)
+    torch.testing.assert_close(act.float().cpu(), ref.detach().float(), rtol=tol, atol=tol)
+    dgu = torch.empty((R, 2 * I), dtype=dtype, device=backend)
+    ops.swiglu_bwd(dact.to(backend), gu.to(backend), dgu)
+    torch.testing.assert_close(dgu.float().cpu(), gr.grad.float(), rtol=tol, atol=tol * float(gr.grad.abs().max()))
+
+
+def test_transpose_and_cast(backend):
+    x = _rand((72, 200), torch.bfloat16, 1)
+    out = torch.empty((200, 72), dtype=torch.bfloat16, device=backend)
+    ops.transpose2d(x.to(backend), out)
+    assert torch.equal(out.cpu(), x.t().contiguous())
+    B, S, nh, hd = 2, 24, 3, 64
+    wide = _rand((B * S, nh * hd + 64), torch.bfloat16, 2)
+    outh = torch.empty((B, nh, hd, S), dtype=torch.bfloat16, device=backend)
+    ops.transpose_heads(wide.to(backend)[:, 64:], outh, B, S, nh, hd)
+    ref = wide[:, 64:].reshape(B, S, nh, hd).permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(outh.cpu(), ref)
+    f = _rand((16, 128), torch.float32, 3)
+    o = torch.zeros((16, 256), dtype=torch.bfloat16, device=backend)
+    ops.cast_from_f32(f.to(backend), o[:, 128:], 0.5)
+    assert torch.equal(o[:, 128:].cpu(), (f * 0.5).to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------ optimizer
+def test_grad_norm_and_adamw_match_reference_run(backend, golden_dir):
+    import os
+
+    blob = torch.load(os.path.join(golden_dir, "optimizer_bf16.pt"), weights_only=False)
+    sizes = [p.numel() for p in blob["p0"]]
+    flat = torch.cat([p.reshape(-1) for p in blob["p0"]]).to(backend)           # bf16 params
+    master = flat.float().clone()
+    m = torch.zeros_like(master)
+    v = torch.zeros_like(master)
+    norm = torch.empty(1, device=backend)
+    ws = torch.empty(1024, device=backend)
+    for step in range(4):
+        g = torch.cat([x.reshape(-1) for x in blob["grads"][step]]).to(backend)
+        ops.grad_norm(g, norm, ws)
+        torch.testing.assert_close(norm.cpu()[0], blob["norms"][step], rtol=1e-5, atol=1e-6)
+        lr = O.cosine_warmup_lr(step, blob["lr"], blob["total_steps"], blob["warmup_steps"])
+        assert abs(lr - blob["lrs"][step]) < 1e-12
+        ops.adamw_step(g, master, m, v, flat, norm, max_norm=blob["max_grad_norm"], lr=lr, beta1=0.9, beta2=0.999,
+                       eps=1e-8, wd=0.0, step=step + 1)
+        want = torch.cat([p.reshape(-1) for p in blob["params_after"][step]])
+        # bf16 params after the reference's BF16Optimizer.step: equal up to 1 bf16 ulp of rounding ties
+        torch.testing.assert_close(flat.float().cpu(), want.float(), rtol=8e-3, atol=1e-6)
+    want_master = torch.cat([t.reshape(-1) for t in blob["masters"]])
+    torch.testing.assert_close(master.cpu(), want_master, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(m.cpu(), torch.cat([t.reshape(-1) for t in blob["exp_avg"]]), rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(v.cpu(), torch.cat([t.reshape(-1) for t in blob["exp_avg_sq"]]), rtol=1e-5, atol=1e-10)
