@@ -62,7 +62,7 @@ SF_DEVICE void stage_rows64(char* lds, const sf_bf16* base, long ld, int row0, i
         const int pc = lane % CPR;
         const int lc = pc ^ (rr & 7);
         const sf_bf16* src = (row0 + rr < nrows_valid) ? base + (long)(row0 + rr) * ld + lc * 8 : sf_zero16a;
-        sf_glds16(src, lds + rr * (HD * 2) + pc * 16);
+        sf_glds16(src, lds + (wave * NI + t) * 1024);  // uniform base; lane i lands at +16*i
     }
 }
 // transposed tile: HD rows (d) x 64 columns (keys / queries) from a [HD][S] matrix
@@ -76,7 +76,7 @@ SF_DEVICE void stage_cols64(char* lds, const sf_bf16* base, int S, int col0, int
         const int lc = pc ^ (rr & 7);
         const int col = col0 + lc * 8;
         const sf_bf16* src = (col < S) ? base + (long)rr * S + col : sf_zero16a;
-        sf_glds16(src, lds + rr * 128 + pc * 16);
+        sf_glds16(src, lds + (wave * NI + t) * 1024);
     }
 }
 // A fragment (32 rows x 16 k) from a natural tile: row = r0 + (lane&31), k = 16*ks + 8*(lane>>5)
@@ -119,7 +119,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_fwd_kernel(AttnFwdArgs p) {
     SF_DYN_SMEM(smem);
     char* lds_k = smem;                 // [64][HD]
     char* lds_vt = smem + 64 * HD * 2;  // [HD][64]
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hi = lane >> 5;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
     const int qb0 = (int)blockIdx.x * 128, h = (int)blockIdx.y, b = (int)blockIdx.z;
     const int g = h / (p.nh / p.nkv);
     const int S = p.S;
@@ -366,7 +366,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dq_kernel(AttnBwdArgs p) {
     char* lds_k = smem;                  // [64][HD]
     char* lds_v = smem + 64 * HD * 2;    // [64][HD]
     char* lds_kt = smem + 128 * HD * 2;  // [HD][64]
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hi = lane >> 5;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
     const int qb0 = (int)blockIdx.x * 128, h = (int)blockIdx.y, b = (int)blockIdx.z;
     const int g = h / (p.nh / p.nkv);
     const int S = p.S;
@@ -468,7 +468,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
     char* lds_dot = smem + 192 * HD * 2;
     float* lds_lse = reinterpret_cast<float*>(smem + 256 * HD * 2);
     float* lds_dlt = lds_lse + 64;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, hi = lane >> 5;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
     const int kb0 = (int)blockIdx.x * 128, g = (int)blockIdx.y, b = (int)blockIdx.z;
     const int S = p.S, nrep = p.nh / p.nkv;
     const int kvlen = p.kv_len ? p.kv_len[b] : S;

@@ -61,7 +61,7 @@ SF_DEVICE void tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int& tm,
 template <int OUT_F32>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) gemm_nt_kernel(GemmArgs p) {
     SF_DYN_SMEM(smem);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
     const int wr = wave >> 1, wc = wave & 1;
     int tm, tn;
     tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
@@ -86,8 +86,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) gemm_nt_kernel(GemmArgs p) {
             const int gm = m0 + rr, gn = n0 + rr;
             const sf_bf16* sa = (gm < p.M && kk < p.K) ? p.A + (long)gm * p.lda + kk : sf_zero16;
             const sf_bf16* sb = (gn < p.N && kk < p.K) ? p.B + (long)gn * p.ldb + kk : sf_zero16;
-            sf_glds16(sa, la + rr * 128 + pc * 16);
-            sf_glds16(sb, lb + rr * 128 + pc * 16);
+            sf_glds16(sa, la + (wave * 4 + t) * 1024);  // uniform base; lane i lands at +16*i
+            sf_glds16(sb, lb + (wave * 4 + t) * 1024);
         }
     };
 

@@ -41,6 +41,7 @@ template <typename T> SF_DEVICE T sf_shfl(T v, int l) { return sfemu::shfl(v, l)
 SF_DEVICE sf_v4f sf_mfma16(sf_v8s a, sf_v8s b, sf_v4f c) { return sfemu::mfma_16x16x32_bf16(a, b, c); }
 SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) { return sfemu::mfma_32x32x16_bf16(a, b, c); }
 SF_DEVICE void sf_glds16(const void* g, void* l) { sfemu::global_load_lds16(g, l); }
+SF_DEVICE int sf_wave_id() { return sfemu::wave_index(); }
 SF_DEVICE void sf_wait_vm0() {}
 SF_DEVICE void sf_setprio_hi() {}
 SF_DEVICE void sf_setprio_lo() {}
@@ -77,7 +78,12 @@ SF_DEVICE sf_v4f sf_mfma16(sf_v8s a, sf_v8s b, sf_v4f c) {
 SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-// LDS-DMA, 16 B per lane: LDS dst = wave-uniform base + 16*lane (caller's pointer must obey that)
+// LDS-DMA, 16 B per lane.  `l` MUST be the same (wave-uniform) LDS address in every lane: the
+// hardware writes lane i's 16 bytes at M0 + 16*i with M0 = readfirstlane(l), so a per-lane
+// pointer goes wrong as soon as the compiler issues the load under a partial EXEC mask
+// (first ACTIVE lane != lane 0) -- observed on gfx950 when a select between two source
+// pointers was lowered to two exec-masked loads.
+SF_DEVICE int sf_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 SF_DEVICE void sf_glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);

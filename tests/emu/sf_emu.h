@@ -15,7 +15,7 @@
 //                           D[row=4*(l>>4)+r][col=l&15]
 //   mfma_f32_32x32x16_bf16: A[i=l&31][k=8*(l>>5)+j]  B[k=8*(l>>5)+j][n=l&31]
 //                           D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31]
-//   global_load_lds 16B   : LDS dst = (first lane's dst) + 16*lane, src per lane
+//   global_load_lds 16B   : LDS dst = wave-uniform base + 16*lane, src per lane
 #pragma once
 #include <ucontext.h>
 
@@ -343,23 +343,25 @@ inline v16f mfma_32x32x16_bf16(v8s a, v8s b, v16f c) {
     return d;
 }
 
-// LDS-DMA: every lane passes its own source; the destination is wave-uniform
-// base (first lane's pointer) + 16*lane.  A lane whose own dst differs from that
-// is a layout bug on real hardware, so it is fatal here.
-inline void global_load_lds16(const void* gsrc, void* lds_dst) {
+// LDS-DMA: every lane passes its own source; the destination is a WAVE-UNIFORM base (the
+// hardware takes it from M0 = readfirstlane(ptr)) + 16*lane.  Lanes disagreeing on the base
+// is a bug on real hardware (wrong as soon as the load is exec-masked), so it is fatal here.
+inline void global_load_lds16(const void* gsrc, void* lds_base) {
     struct P {
         const void* g;
         void* l;
-    } p{gsrc, lds_dst};
+    } p{gsrc, lds_base};
     SlotRow* s = wave_exchange(&p, sizeof(P));
-    P first;
-    memcpy(&first, s[0], sizeof(P));
-    char* dst = (char*)first.l + 16 * lane_id();
-    if (dst != (char*)lds_dst) {
-        fprintf(stderr, "[sfemu] global_load_lds: lane %d dst is not base+16*lane\n", lane_id());
-        abort();
+    const int n = wave_lanes();
+    for (int i = 0; i < n; ++i) {
+        P o;
+        memcpy(&o, s[i], sizeof(P));
+        if (o.l != lds_base) {
+            fprintf(stderr, "[sfemu] global_load_lds: LDS base is not wave-uniform (lane %d vs %d)\n", lane_id(), i);
+            abort();
+        }
     }
-    memcpy(dst, gsrc, 16);
+    memcpy((char*)lds_base + 16 * lane_id(), gsrc, 16);
 }
 
 template <typename T>
