@@ -98,6 +98,8 @@ int sf_swiglu_bwd(const void* dact, int dtype, long lddact, const void* gu, long
  * images of the attention kernels (no reference equivalent: autograd transposes are views). */
 int sf_transpose(const void* in, int dtype, long in_b1, long in_b2, long in_ld, void* out, long out_b1, long out_b2,
                  long out_ld, int nb1, int nb2, int R, int C, void* stream);
+/* y = (accumulate ? y : 0) + alpha*x, fp32: carries norm-weight gradients across micro-steps. */
+int sf_axpy_f32(long n, float alpha, const float* x, float* y, int accumulate, void* stream);
 int sf_cast_from_f32(const float* in, long ldin, void* out, int dtype, long ldout, long rows, int C, float scale,
                      void* stream);
 
@@ -122,11 +124,11 @@ int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long lddo, const 
                     float scale, void* stream);
 
 /* ---- optimizer: BF16Optimizer.step on flat buffers (specforge/optimizer.py:95-168) ---------
- * norm_out[0] = sqrt(sum float(g)^2 + extra_sq); adamw: clip = min(1, max_norm/(norm+1e-6))
+ * norm_out[0] = prescale*sqrt(sum float(g)^2); adamw: clip = min(1, max_norm/(norm+1e-6))
  * (max_norm <= 0 disables), g32 = float(g)*clip*grad_prescale, torch.optim.AdamW update of the
  * fp32 master, param = storage(master). */
 long sf_grad_norm_workspace_floats(void);
-int sf_grad_norm(const void* g, int dtype, long n, float extra_sq, float* norm_out, float* workspace, void* stream);
+int sf_grad_norm(const void* g, int dtype, long n, float prescale, float* norm_out, float* workspace, void* stream);
 int sf_adamw_step(const void* g, int dtype, float* master, float* m, float* v, void* param, long n,
                   const float* norm, float max_norm, float lr, float beta1, float beta2, float eps, float wd,
                   int step, float grad_prescale, void* stream);

@@ -292,7 +292,7 @@ SF_GLOBAL void sumsq_kernel(const T* g, long n, float* partial) {
     acc = sf_block_sum(acc, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
-SF_GLOBAL void norm_finish_kernel(const float* partial, int nb, float* norm_out, float extra_sq) {
+SF_GLOBAL void norm_finish_kernel(const float* partial, int nb, float* norm_out, float prescale) {
     SF_SHARED double part[256];
     const int tid = (int)threadIdx.x;
     double acc = 0.0;
@@ -303,7 +303,7 @@ SF_GLOBAL void norm_finish_kernel(const float* partial, int nb, float* norm_out,
         if (tid < sft) part[tid] += part[tid + sft];
         sf_syncthreads();
     }
-    if (tid == 0) norm_out[0] = (float)sqrt(part[0] + (double)extra_sq);
+    if (tid == 0) norm_out[0] = (float)(sqrt(part[0]) * (double)prescale);
 }
 // BF16Optimizer.step on flat buffers (optimizer.py:95-168): clip = min(1, max_norm/(norm+1e-6)),
 // g32 = float(g)*clip, torch.optim.AdamW update of the fp32 master, param = T(master).
@@ -429,12 +429,12 @@ extern "C" int sf_cast_from_f32(const float* in, long ldin, void* out, int dtype
 
 extern "C" long sf_grad_norm_workspace_floats(void) { return 1024; }
 
-// norm_out[0] = sqrt(sum float(g)^2 + extra_sq)
-extern "C" int sf_grad_norm(const void* g, int dtype, long n, float extra_sq, float* norm_out, float* workspace, void* stream) {
+// norm_out[0] = prescale * sqrt(sum float(g)^2)   (prescale = 1/world for SUM-reduced grads)
+extern "C" int sf_grad_norm(const void* g, int dtype, long n, float prescale, float* norm_out, float* workspace, void* stream) {
     SF_CHECK_ARG(n >= 0 && workspace && norm_out, "sf_grad_norm: bad args");
     const int nb = (int)((n / 8 + 255) / 256 < 1 ? 1 : ((n / 8 + 255) / 256 > 1024 ? 1024 : (n / 8 + 255) / 256));
     SF_DISPATCH_T(dtype, SF_LAUNCH((sumsq_kernel<T>), dim3(nb), dim3(256), 0, stream, (const T*)g, n, workspace));
-    SF_LAUNCH(norm_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, nb, norm_out, extra_sq);
+    SF_LAUNCH(norm_finish_kernel, dim3(1), dim3(256), 0, stream, (const float*)workspace, nb, norm_out, prescale);
     return sf_check_launch("sf_grad_norm");
 }
 
@@ -449,4 +449,19 @@ extern "C" int sf_adamw_step(const void* g, int dtype, float* master, float* m, 
                                    master, m, v, (T*)param, n, norm, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2s,
                                    grad_prescale));
     return sf_check_launch("sf_adamw_step");
+}
+
+namespace {
+// y = (accumulate ? y : 0) + alpha * x      (fp32, grid-stride)
+SF_GLOBAL void axpy_f32_kernel(long n, float alpha, const float* x, float* y, int accumulate) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = (accumulate ? y[i] : 0.f) + alpha * x[i];
+}
+}  // namespace
+
+extern "C" int sf_axpy_f32(long n, float alpha, const float* x, float* y, int accumulate, void* stream) {
+    SF_CHECK_ARG(n >= 0, "sf_axpy_f32: bad size");
+    if (n == 0) return 0;
+    SF_LAUNCH(axpy_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, n, alpha, x, y, accumulate);
+    return sf_check_launch("sf_axpy_f32");
 }

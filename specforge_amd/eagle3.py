@@ -1,0 +1,171 @@
+"""Drop-in ``OnlineEagle3Model`` + ``Eagle3TrainStrategy`` on the HIP engine.
+
+Same constructor arguments, ``forward`` keyword arguments and 7-tuple of per-TTT-step lists as
+the reference (specforge/algorithms/eagle3/model.py:100-442) and the same
+``forward_loss(batch) -> StepOutput`` contract (specforge/training/strategies/base.py:124-319),
+so ``TrainerCore.train_step`` (training/controller.py:328-363) and ``_reduce_eagle3_metrics``
+(controller.py:200-304) drive it unchanged.  The whole micro-step is ONE autograd node:
+``loss.backward()`` triggers ``Eagle3Engine.backward`` which writes straight into the flat
+gradient buffer the parameters' ``.grad`` alias.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .engine import Eagle3Engine
+from .model import LlamaForCausalLMEagle3
+
+
+def padding_left_shift(t: torch.Tensor) -> torch.Tensor:
+    """``padding(tensor, left=False)`` (specforge/utils.py:128-135): shift left by one along dim 1, zero fill."""
+    return torch.cat((t[:, 1:], torch.zeros_like(t[:, -1:])), dim=1)
+
+
+class _TTTStep(torch.autograd.Function):
+    """plosses[T] as one node; backward = the engine's hand-written sweep."""
+
+    @staticmethod
+    def forward(ctx, anchor, engine, plosses):
+        ctx.engine = engine
+        return plosses.clone()
+
+    @staticmethod
+    def backward(ctx, grad_plosses):
+        eng: Eagle3Engine = ctx.engine
+        gp = grad_plosses.detach().float().cpu().tolist()  # one host sync per micro-step
+        g = gp[0]
+        # The decay weights are baked into the fused CE gradients; the caller must use the same ones.
+        for k, v in enumerate(gp):
+            want = g * (eng.decay ** k)
+            if abs(v - want) > 1e-6 * max(1.0, abs(want)):
+                raise RuntimeError(
+                    f"ploss weights seen in backward ({gp}) are not g*ploss_decay^k with ploss_decay={eng.decay}; "
+                    "construct OnlineEagle3Model(ploss_decay=...) with the strategy's value")
+        eng.backward(g)
+        return None, None, None
+
+
+class OnlineEagle3Model(nn.Module):
+    """EAGLE3 TTT trainer module (reference: eagle3/model.py:100-442) on the HIP engine."""
+
+    def __init__(self, draft_model: LlamaForCausalLMEagle3, length: int = 7, attention_backend: str = "hip",
+                 lk_loss_type: Optional[str] = None, kl_scale: float = 1.0, kl_decay: float = 1.0,
+                 ploss_decay: float = 0.8):
+        super().__init__()
+        if lk_loss_type is not None:
+            raise NotImplementedError("lk_loss_type is a 'next' row (SURVEY.md 8f rank 4); the HIP path trains the default CE objective")
+        self.draft_model = draft_model
+        self.length = length
+        self.attention_backend = attention_backend
+        self.lk_loss_type, self.kl_scale, self.kl_decay = lk_loss_type, kl_scale, kl_decay
+        self.engine = Eagle3Engine(draft_model, ttt_length=length, ploss_decay=ploss_decay)
+        self._anchor = nn.Parameter(torch.zeros((), device=self.engine.dev), requires_grad=True)
+
+    def forward(self, input_ids, attention_mask, target=None, loss_mask=None, hidden_states=None, past_key_values=None,
+                position_ids=None, target_hidden_for_compact=None, target_head_weight=None,
+                compact_teacher_chunk_size: Optional[int] = None):
+        if past_key_values is not None:
+            raise NotImplementedError("past_key_values is unused by EAGLE3 training (eagle3/model.py:262)")
+        train = torch.is_grad_enabled() and self.training
+        dev = self.engine.dev
+        to = lambda t: None if t is None else t.to(dev)
+        out = self.engine.forward(
+            input_ids=to(input_ids), attention_mask=attention_mask, loss_mask=to(loss_mask), hidden_states=to(hidden_states),
+            target_hidden=to(target_hidden_for_compact), target_head_weight=target_head_weight,
+            target_logits=to(target) if target_hidden_for_compact is None else None, position_ids=to(position_ids), train=train)
+        plosses = torch.stack(out["plosses"])
+        if train:
+            plosses = _TTTStep.apply(self._anchor, self.engine, plosses)
+        self.last_artifacts = dict(target_token_ids=out["target_token_ids"], position_mask=out["position_mask"])
+        return (list(plosses.unbind(0)), out["acceptance_rates"], out["acces"], out["acc_corrects"], out["acc_denoms"],
+                out["metric_losses"], out["metric_loss_denoms"])
+
+
+@dataclass(frozen=True)
+class StepOutput:
+    """training/strategies/base.py:29-42"""
+
+    loss: torch.Tensor
+    metrics: Dict[str, Any]
+    ratio_metrics: Dict[str, Tuple[Any, Any]] = field(default_factory=dict)
+    loss_terms: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+
+
+class TargetHead(nn.Module):
+    """Frozen teacher projection (specforge/modeling/target/target_head.py:15-108): ``fc`` H -> V_target."""
+
+    def __init__(self, weight: torch.Tensor):
+        super().__init__()
+        self.fc = nn.Linear(weight.shape[1], weight.shape[0], bias=False, device=weight.device, dtype=weight.dtype)
+        with torch.no_grad():
+            self.fc.weight.copy_(weight)
+        self.fc.weight.requires_grad = False
+
+    @staticmethod
+    def preprocess(input_ids, target, loss_mask):
+        """target_head.py:103-108: shift target and input_ids left by one, loss_mask -> [B,S,1]"""
+        return padding_left_shift(input_ids), padding_left_shift(target), loss_mask[..., None]
+
+
+class Eagle3TrainStrategy:
+    """training/strategies/base.py:124-319.  The teacher always runs the streaming path
+    (target hidden state + frozen head weight -> soft targets; [B,S,V_target] is never kept)."""
+
+    name = "eagle3"
+    required_features = {"input_ids", "attention_mask", "loss_mask", "hidden_state", "target"}
+
+    def __init__(self, eagle3_model: OnlineEagle3Model, *, target_head: Optional[TargetHead] = None,
+                 ploss_decay: float = 0.8, compact_teacher: bool = True, compact_teacher_chunk_size: Optional[int] = None):
+        self.eagle3_model = eagle3_model
+        self.target_head = target_head
+        self.ploss_decay = ploss_decay
+        if abs(eagle3_model.engine.decay - ploss_decay) > 1e-12:
+            raise ValueError("OnlineEagle3Model.ploss_decay and the strategy's ploss_decay must agree")
+
+    def trainable_module(self) -> nn.Module:
+        return self.eagle3_model
+
+    def validate_batch(self, batch) -> None:
+        missing = self.required_features - set(batch.tensors)
+        if missing:
+            raise ValueError(f"eagle3 strategy: batch lacks {sorted(missing)}")
+
+    def forward_loss(self, batch, ctx=None) -> StepOutput:
+        self.validate_batch(batch)
+        t = batch.tensors
+        target_repr = getattr(batch, "metadata", {}).get("target_repr", "hidden_state")
+        kwargs = {}
+        if target_repr == "hidden_state":
+            if self.target_head is None:
+                raise ValueError("target_repr='hidden_state' needs the offline target_head")
+            input_ids, target_hidden, loss_mask = TargetHead.preprocess(t["input_ids"], t["target"], t["loss_mask"])
+            kwargs = dict(target_hidden_for_compact=target_hidden, target_head_weight=self.target_head.fc.weight.data)
+            target = None
+        else:  # logits delivered as-is (online capture)
+            input_ids, target, loss_mask = TargetHead.preprocess(t["input_ids"], t["target"], t["loss_mask"])
+        plosses, acceptance_rates, acces, acc_corrects, acc_denoms, metric_losses, metric_loss_denoms = self.eagle3_model(
+            input_ids=input_ids, attention_mask=t["attention_mask"], loss_mask=loss_mask, target=target,
+            hidden_states=t["hidden_state"], position_ids=t.get("position_ids"), **kwargs)
+        weights = [self.ploss_decay ** i for i in range(len(plosses))]
+        loss = sum(weights[i] * plosses[i] for i in range(len(plosses)))
+        d = lambda xs: [x.detach() for x in xs]
+        return StepOutput(loss=loss, metrics=dict(plosses=d(plosses), acces=d(acces), acceptance_rates=d(acceptance_rates),
+                                                  acc_corrects=d(acc_corrects), acc_denoms=d(acc_denoms),
+                                                  metric_losses=d(metric_losses), metric_loss_denoms=d(metric_loss_denoms)))
+
+    def checkpoint_state_filter(self, state_dict: Dict[str, Any]) -> Dict[str, Any]:
+        """strip ``draft_model.``, drop the frozen embedding and engine internals (strategies/base.py:306-319)"""
+        return {k.replace("draft_model.", ""): v for k, v in state_dict.items()
+                if "draft_model." in k and "embed" not in k.lower()}
+
+
+@dataclass
+class TrainBatch:
+    """runtime/contracts.py:80-129 (the fields the strategy reads)"""
+
+    tensors: Dict[str, torch.Tensor]
+    metadata: Dict[str, Any] = field(default_factory=dict)

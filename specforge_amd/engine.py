@@ -1,0 +1,412 @@
+"""The EAGLE3 TTT micro-step on the HIP kernels: teacher targets, 7x (embed+norms, fused QKV,
+RoPE, TTT attention, O, SwiGLU MLP, lm_head, fused CE) forward, and the hand-scheduled
+backward sweep with deferred, K-concatenated weight gradients.
+
+Reference call stack this replaces: ``Eagle3TrainStrategy.forward_loss``
+(specforge/training/strategies/base.py:237-304) -> ``OnlineEagle3Model.forward``
+(specforge/algorithms/eagle3/model.py:244-442) -> ``LlamaForCausalLMEagle3`` /
+``LlamaDecoderLayer`` (specforge/modeling/draft/llama3_eagle.py:1598-1798) ->
+``LogSoftmaxLoss`` (specforge/core/loss.py:173-228) -> autograd backward.
+
+Design notes (MI355X-first, 288 GB HBM):
+* No autograd graph: every activation the backward needs lives in a persistent stash that is
+  allocated once per (B, S) shape; step k's K/V are views into step k's fused QKV buffer.
+* The soft-target CE writes d(logits) in place while computing the loss, so the lm_head
+  input gradient is taken in the forward sweep and only [N, H] survives per step.
+* Weight gradients are NOT computed per TTT step.  X^T and dY^T of every linear are stashed
+  for all T steps side by side ([*, T*N]); after the sweep ONE GEMM per weight contracts over
+  K = T*N tokens with fp32 accumulation and writes the bf16 gradient straight into the flat
+  gradient buffer, largest first -- each finished bucket is handed to the DP backend, whose
+  RCCL all-reduce overlaps the next wgrad GEMM.
+* The upstream gradient g = dLoss/d(sum_k decay^k ploss_k) enters only as the alpha of those
+  final GEMMs: everything before is linear in it.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ops
+from .model import DraftConfig, FlatParams, LlamaForCausalLMEagle3, rope_tables
+
+
+class Eagle3Engine:
+    def __init__(self, model: LlamaForCausalLMEagle3, *, ttt_length: int = 7, ploss_decay: float = 0.8,
+                 teacher_rows: int = 4096):
+        self.model = model
+        self.cfg: DraftConfig = model.config
+        c = self.cfg
+        if not c.norm_output:
+            raise NotImplementedError("norm_output=False is not on the HIP path yet (every reference recipe uses True)")
+        if c.head_dim not in (64, 128):
+            raise NotImplementedError("TTT attention kernels are built for head_dim 64 and 128")
+        self.T = int(ttt_length)
+        if not 1 <= self.T <= 8:
+            raise ValueError("ttt_length must be in 1..8")
+        self.decay = float(ploss_decay)
+        self.flat = FlatParams(model)
+        self.dev = self.flat.data.device
+        self.teacher_rows = teacher_rows
+        cos, sin = rope_tables(c, torch.bfloat16)
+        self.cos, self.sin = cos.to(self.dev), sin.to(self.dev)
+        self._bufs: Dict = {}
+        self._wt_version = -1
+        self.weights_version = 0          # bumped by the optimizer after every step
+        self.micro_in_window = 0          # micro-steps accumulated into flat.grad since the last optimizer step
+        self.on_bucket_ready: Optional[Callable[[int, int], None]] = None
+        self._t2d_u8 = None
+        self._fwd_state = None
+        H, I, hd = c.hidden_size, c.intermediate_size, c.head_dim
+        self.QW = (c.num_attention_heads + 2 * c.num_key_value_heads) * hd
+        self.w_qkv = self.flat.fused("midlayer.self_attn.q_proj.weight", "midlayer.self_attn.v_proj.weight", self.QW, 2 * H)
+        self.w_gu = self.flat.fused("midlayer.mlp.gate_proj.weight", "midlayer.mlp.up_proj.weight", 2 * I, H)
+        self.g_qkv = self.flat.fused("midlayer.self_attn.q_proj.weight", "midlayer.self_attn.v_proj.weight", self.QW, 2 * H, grad=True)
+        self.g_gu = self.flat.fused("midlayer.mlp.gate_proj.weight", "midlayer.mlp.up_proj.weight", 2 * I, H, grad=True)
+        # fp32 running totals of the norm-weight gradients over the accumulation window
+        self._norm_names = [n for n in self.flat.names if n.endswith("norm.weight") or "layernorm" in n or "fc_norm" in n]
+        self._norm_total = {n: torch.zeros(self.flat.params[n].numel(), device=self.dev) for n in self._norm_names}
+        self._norm_micro = {n: torch.zeros(self.flat.params[n].numel(), device=self.dev) for n in self._norm_names}
+
+    # ------------------------------------------------------------------ buffers
+    def _e(self, *shape, dtype=torch.bfloat16):
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    def _buffers(self, B: int, S: int):
+        key = (B, S)
+        if key in self._bufs:
+            return self._bufs[key]
+        c, T = self.cfg, self.T
+        N, Spad = B * S, S + T
+        H, I, hd, nh, nkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        Vd, Ht3 = c.draft_vocab_size, 3 * c.target_hidden_size
+        f32, i32, i64 = torch.float32, torch.int32, torch.int64
+        b = dict(N=N, Spad=Spad)
+        # teacher targets (padded tails are constants: 1/Vd, 0, 0 -- eagle3/model.py:445-484)
+        b["tp"] = torch.full((B, Spad, Vd), 1.0 / Vd, dtype=f32, device=self.dev)
+        b["pod"] = torch.zeros(B, Spad, dtype=f32, device=self.dev)
+        b["tsum"] = torch.full((B, Spad), float(torch.full((Vd,), 1.0 / Vd).sum()), dtype=f32, device=self.dev)
+        b["tids"] = torch.zeros(B, Spad, dtype=i64, device=self.dev)
+        b["pm"] = torch.zeros(B, Spad, dtype=i32, device=self.dev)
+        b["lm"] = torch.zeros(B, Spad, dtype=i32, device=self.dev)
+        b["ids"] = torch.zeros(B, Spad, dtype=i64, device=self.dev)
+        b["kvlen"] = torch.zeros(B, dtype=i32, device=self.dev)
+        b["pos"] = torch.zeros(N, dtype=i64, device=self.dev)
+        # per-step stash
+        b["h"] = [self._e(N, H) for _ in range(T + 1)]
+        b["h1"] = [self._e(N, H) for _ in range(T)]
+        b["qkv"] = [self._e(N, self.QW) for _ in range(T)]
+        b["o"] = [self._e(N, nh * hd) for _ in range(T)]
+        b["lse"] = [self._e(B, nh, S, dtype=f32) for _ in range(T)]
+        b["gu"] = [self._e(N, 2 * I) for _ in range(T)]
+        b["dln"] = [self._e(N, H) for _ in range(T)]
+        for nm in ("rstd_e", "rstd_h", "rstd_p", "rstd_n"):
+            b[nm] = [self._e(N, dtype=f32) for _ in range(T)]
+        b["rstd_fc"] = [self._e(N, dtype=f32) for _ in range(3)]
+        b["v0t"] = self._e(B, nkv, hd, S)
+        b["k0t"] = self._e(B, nkv, hd, S)
+        # transient per-step work buffers
+        b["xcat"] = self._e(N, 2 * H)
+        b["pn"] = self._e(N, H)
+        b["act"] = self._e(N, I)
+        b["ln"] = self._e(N, H)
+        b["logits"] = self._e(N, Vd)
+        b["hsn"] = self._e(N, Ht3) if c.fc_norm else None
+        b["rows"] = self._e(3, N, dtype=f32)
+        b["metrics"] = torch.zeros(T, 3, dtype=f32, device=self.dev)
+        # transposed stashes for the deferred, K-concatenated wgrad GEMMs: [features, T*N]
+        TN = T * N
+        for nm, feat in (("xcatT", 2 * H), ("oT", nh * hd), ("pnT", H), ("actT", I), ("lnT", H), ("dlogT", Vd),
+                         ("dhT", H), ("dguT", 2 * I), ("dh1T", H), ("dqkvT", self.QW)):
+            b[nm] = self._e(feat, TN)
+        b["hsT"] = self._e(Ht3, N)
+        b["dh0T"] = self._e(H, N)
+        # backward work buffers
+        b["dh_a"], b["dh_b"], b["dh1"] = self._e(N, H), self._e(N, H), self._e(N, H)
+        b["dact"] = self._e(N, I)
+        b["dgu"] = self._e(N, 2 * I)
+        b["dpn"] = self._e(N, H)
+        b["do"] = self._e(N, nh * hd)
+        b["dqkv"] = self._e(N, self.QW)
+        b["dxcat"] = self._e(N, 2 * H)
+        b["dhs"] = self._e(N, Ht3) if c.fc_norm else None
+        b["delta"] = self._e(B, nh, S, dtype=f32)
+        b["dq_init"] = self._e(N, nh * hd, dtype=f32)
+        b["qt"] = self._e(B, nh, hd, S)
+        b["dot"] = self._e(B, nh, hd, S)
+        b["dk"] = [self._e(N, nkv * hd, dtype=f32) for _ in range(T)]
+        b["dv"] = [self._e(N, nkv * hd, dtype=f32) for _ in range(T)]
+        b["nws"] = self._e(ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)
+        self._bufs[key] = b
+        return b
+
+    def _refresh_weight_transposes(self):
+        """W^T images for the dgrad GEMMs (NT form); rebuilt only after an optimizer step."""
+        if self._wt_version == self.weights_version:
+            return
+        c, f = self.cfg, self.flat
+        H, I, hd, nh = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads
+        if not hasattr(self, "wlmT"):
+            self.wlmT = self._e(H, c.draft_vocab_size)
+            self.wguT = self._e(H, 2 * I)
+            self.wdT = self._e(I, H)
+            self.wqkvT = self._e(2 * H, self.QW)
+            self.woT = self._e(nh * hd, H)
+            self.wfcT = self._e(3 * c.target_hidden_size, H) if c.fc_norm else None
+        ops.transpose2d(f.view("lm_head.weight"), self.wlmT)
+        ops.transpose2d(self.w_gu, self.wguT)
+        ops.transpose2d(f.view("midlayer.mlp.down_proj.weight"), self.wdT)
+        ops.transpose2d(self.w_qkv, self.wqkvT)
+        ops.transpose2d(f.view("midlayer.self_attn.o_proj.weight"), self.woT)
+        if self.wfcT is not None:
+            ops.transpose2d(f.view("fc.weight"), self.wfcT)
+        self._wt_version = self.weights_version
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, *, input_ids, attention_mask, loss_mask, hidden_states, target_hidden=None,
+                target_head_weight=None, target_logits=None, position_ids=None, train: bool = True):
+        """One micro-step forward.  ``input_ids`` / ``target_*`` are already shifted by
+        ``TargetHead.preprocess`` (target_head.py:103-108); ``loss_mask`` is [B,S] or [B,S,1].
+        Returns the metric dict of ``Eagle3TrainStrategy.forward_loss`` (lists of 0-dim tensors)."""
+        c, T, f = self.cfg, self.T, self.flat
+        B, S = input_ids.shape
+        b = self._buffers(B, S)
+        N, Spad = b["N"], b["Spad"]
+        H, I, hd, nh, nkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        Vd, Ht = c.draft_vocab_size, c.target_hidden_size
+        eps, scale = c.rms_norm_eps, 1.0 / math.sqrt(hd)
+        if S % 8 != 0:
+            raise ValueError("sequence length must be a multiple of 8 (16-byte rows of the transposed attention images)")
+        if S + T > self.cos.shape[0]:
+            raise ValueError("sequence length exceeds the RoPE table (max_position_embeddings + 20)")
+        loss_mask = loss_mask.reshape(B, S)
+        if attention_mask is None:
+            attention_mask = torch.ones(B, S, dtype=torch.int64, device=self.dev)
+        if not attention_mask.is_cuda and attention_mask.numel():
+            am = attention_mask.bool()
+            if bool((am[:, 1:] & ~am[:, :-1]).any()):
+                raise ValueError("attention_mask must be right-padded (1...1 0...0): the collator's contract, data/utils.py:122-196")
+        self._refresh_weight_transposes()
+        # ---- host-side plumbing into the padded, typed buffers
+        b["ids"][:, :S].copy_(input_ids)
+        b["lm"][:, :S].copy_(loss_mask)
+        b["kvlen"].copy_(attention_mask.to(self.dev).sum(dim=1))
+        if position_ids is None:
+            b["pos"].copy_(torch.arange(S, device=self.dev).repeat(B))
+        else:
+            b["pos"].copy_(position_ids.reshape(-1))
+        if self._t2d_u8 is None or self._t2d_u8.device != self.dev:
+            self._t2d_u8 = self.model.t2d.to(self.dev).to(torch.uint8).contiguous()
+            self._d2t = self.model.d2t.to(self.dev).contiguous()
+        hs = hidden_states.reshape(N, 3 * Ht)
+        self._last_hs = hs
+
+        # ---- teacher: target logits (chunked GEMM, bf16 like TargetHead.forward) -> soft targets
+        if target_logits is not None:
+            z = target_logits.reshape(N, -1)
+            ops.teacher_reduce(z, Vd=Vd, d2t=self._d2t, t2d_u8=self._t2d_u8, loss_mask_pad=b["lm"], S=S, Spad=Spad,
+                               target_p_pad=b["tp"], pod_scale_pad=b["pod"], tsum_pad=b["tsum"], ids_pad=b["tids"],
+                               pos_mask_pad=b["pm"])
+        else:
+            th = target_hidden.reshape(B, S, Ht)
+            Vt = target_head_weight.shape[0]
+            cb = max(1, self.teacher_rows // S)
+            zkey = ("z", min(cb, B) * S, Vt)
+            if zkey not in self._bufs:
+                self._bufs[zkey] = self._e(min(cb, B) * S, Vt)
+            for b0 in range(0, B, cb):
+                nb = min(cb, B - b0)
+                z = self._bufs[zkey][: nb * S]
+                ops.gemm_nt(th[b0:b0 + nb].reshape(nb * S, Ht), target_head_weight, z)
+                ops.teacher_reduce(z, Vd=Vd, d2t=self._d2t, t2d_u8=self._t2d_u8, loss_mask_pad=b["lm"][b0:b0 + nb], S=S,
+                                   Spad=Spad, target_p_pad=b["tp"][b0:b0 + nb], pod_scale_pad=b["pod"][b0:b0 + nb],
+                                   tsum_pad=b["tsum"][b0:b0 + nb], ids_pad=b["tids"][b0:b0 + nb],
+                                   pos_mask_pad=b["pm"][b0:b0 + nb])
+
+        # ---- fc (optionally 3x RMSNorm first): llama3_eagle.py:1762-1770
+        if c.fc_norm:
+            for i in range(3):
+                ops.rmsnorm_fwd(hs[:, i * Ht:(i + 1) * Ht], f.view(f"fc_norm.{i}.weight"), eps,
+                                b["hsn"][:, i * Ht:(i + 1) * Ht], b["rstd_fc"][i])
+            fc_in = b["hsn"]
+        else:
+            fc_in = hs
+        ops.gemm_nt(fc_in, f.view("fc.weight"), b["h"][0])
+        if train:
+            ops.transpose2d(fc_in, b["hsT"])
+
+        kcol, vcol = slice(nh * hd, (nh + nkv) * hd), slice((nh + nkv) * hd, self.QW)
+        for k in range(T):
+            cols = slice(k * N, (k + 1) * N)
+            xcat, qkv = b["xcat"], b["qkv"][k]
+            # input_layernorm(embed(ids<<k)) | hidden_norm(h_k)   (llama3_eagle.py:1625-1630)
+            ops.rmsnorm_fwd(self.model.embed_tokens.weight.data, f.view("midlayer.input_layernorm.weight"), eps, xcat[:, :H],
+                            b["rstd_e"][k], ids_pad=b["ids"], S=S, Spad=Spad, off=k, rows=N)
+            ops.rmsnorm_fwd(b["h"][k], f.view("midlayer.hidden_norm.weight"), eps, xcat[:, H:], b["rstd_h"][k])
+            ops.gemm_nt(xcat, self.w_qkv, qkv)
+            ops.rope_(qkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k)
+            if k == 0:
+                ops.transpose_heads(qkv[:, vcol], b["v0t"], B, S, nkv, hd)
+                ops.transpose_heads(qkv[:, kcol], b["k0t"], B, S, nkv, hd)
+            ops.attn_fwd(qkv[:, :nh * hd], b["qkv"][0][:, kcol], b["v0t"], [b["qkv"][i][:, kcol] for i in range(1, k + 1)],
+                         [b["qkv"][i][:, vcol] for i in range(1, k + 1)], b["kvlen"], b["o"][k], b["lse"][k],
+                         B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+            ops.gemm_nt(b["o"][k], f.view("midlayer.self_attn.o_proj.weight"), b["h1"][k], residual=b["h"][k])
+            ops.rmsnorm_fwd(b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"), eps, b["pn"], b["rstd_p"][k])
+            ops.gemm_nt(b["pn"], self.w_gu, b["gu"][k])
+            ops.swiglu_fwd(b["gu"][k], b["act"])
+            ops.gemm_nt(b["act"], f.view("midlayer.mlp.down_proj.weight"), b["h"][k + 1], residual=b["h1"][k])
+            ops.rmsnorm_fwd(b["h"][k + 1], f.view("norm.weight"), eps, b["ln"], b["rstd_n"][k])
+            ops.gemm_nt(b["ln"], f.view("lm_head.weight"), b["logits"])
+            # loss + d(logits) in place + accuracy + acceptance; ploss_k = mean over ALL B*S rows
+            ops.ce_fused(b["logits"], b["tp"], S=S, Spad=Spad, off=k, pos_mask_pad=b["pm"], loss_mask_pad=b["lm"],
+                         tgt_ids_pad=b["tids"], pod_scale_pad=b["pod"], tsum_pad=b["tsum"], d2t=self._d2t,
+                         grad_scale=(self.decay ** k) / N, write_grad=train, row_loss=b["rows"][0],
+                         row_correct=b["rows"][1], row_accept=b["rows"][2])
+            ops.reduce_sum(b["rows"], N, 3, b["metrics"][k], 1.0)
+            if train:
+                ops.gemm_nt(b["logits"], self.wlmT, b["dln"][k])        # lm_head dgrad, taken now
+                ops.transpose2d(b["logits"], b["dlogT"][:, cols])
+                ops.transpose2d(b["ln"], b["lnT"][:, cols])
+                ops.transpose2d(xcat, b["xcatT"][:, cols])
+                ops.transpose2d(b["o"][k], b["oT"][:, cols])
+                ops.transpose2d(b["pn"], b["pnT"][:, cols])
+                ops.transpose2d(b["act"], b["actT"][:, cols])
+
+        self._fwd_state = (B, S) if train else None
+        # ---- metrics (tiny integer-mask sums; eagle3/model.py:161-190, core/lk_loss.py:43-80)
+        met = b["metrics"]
+        lm_f, pm_f = b["lm"].float(), b["pm"].float()
+        out = dict(plosses=[], acces=[], acceptance_rates=[], acc_corrects=[], acc_denoms=[], metric_losses=[],
+                   metric_loss_denoms=[])
+        for k in range(T):
+            denom = lm_f[:, k:k + S].sum().clamp_min(1e-6)
+            pden = pm_f[:, k:k + S].sum().clamp_min(1e-8)
+            ploss = met[k, 0] / N
+            out["plosses"].append(ploss)
+            out["acc_corrects"].append(met[k, 1].clone())
+            out["acc_denoms"].append(denom)
+            out["acces"].append(met[k, 1] / denom)
+            out["acceptance_rates"].append(met[k, 2] / pden)
+            out["metric_losses"].append(ploss.clone())
+            out["metric_loss_denoms"].append(torch.tensor(float(N), device=self.dev))
+        out["target_token_ids"] = b["tids"][:, :S]
+        out["position_mask"] = b["pm"][:, :S]
+        return out
+
+    # ----------------------------------------------------------------- backward
+    @torch.no_grad()
+    def backward(self, g: float = 1.0):
+        """Backward sweep of the last ``forward(train=True)``; accumulates g * dLoss/dW into
+        ``flat.grad`` (overwrites on the first micro-step of an accumulation window)."""
+        if self._fwd_state is None:
+            raise RuntimeError("Eagle3Engine.backward called without a training forward")
+        B, S = self._fwd_state
+        self._fwd_state = None
+        c, T, f = self.cfg, self.T, self.flat
+        b = self._buffers(B, S)
+        N, Spad = b["N"], b["Spad"]
+        H, I, hd, nh, nkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
+        Ht = c.target_hidden_size
+        scale = 1.0 / math.sqrt(hd)
+        kcol, vcol = slice(nh * hd, (nh + nkv) * hd), slice((nh + nkv) * hd, self.QW)
+        ws = b["nws"]
+        for t in b["dk"] + b["dv"]:
+            t.zero_()
+        nm = self._norm_micro
+        first = {n: True for n in nm}
+
+        def nacc(name):  # (dw_acc, accumulate?) for a norm weight within this micro-step
+            acc = not first[name]
+            first[name] = False
+            return nm[name], acc
+
+        dh_next = None
+        for k in range(T - 1, -1, -1):
+            cols = slice(k * N, (k + 1) * N)
+            # final norm + (already taken) lm_head dgrad; residual-stream gradient of step k+1 joins here
+            dh = b["dh_a"]
+            acc, a = nacc("norm.weight")
+            ops.rmsnorm_bwd(b["dln"][k], b["h"][k + 1], f.view("norm.weight"), b["rstd_n"][k], dx=dh, add=dh_next,
+                            dw_acc=acc, dw_accumulate=a, workspace=ws)
+            ops.transpose2d(dh, b["dhT"][:, cols])
+            # MLP
+            ops.gemm_nt(dh, self.wdT, b["dact"])
+            ops.swiglu_bwd(b["dact"], b["gu"][k], b["dgu"])
+            ops.transpose2d(b["dgu"], b["dguT"][:, cols])
+            ops.gemm_nt(b["dgu"], self.wguT, b["dpn"])
+            acc, a = nacc("midlayer.post_attention_layernorm.weight")
+            ops.rmsnorm_bwd(b["dpn"], b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"), b["rstd_p"][k],
+                            dx=b["dh1"], add=dh, dw_acc=acc, dw_accumulate=a, workspace=ws)
+            ops.transpose2d(b["dh1"], b["dh1T"][:, cols])
+            # attention
+            ops.gemm_nt(b["dh1"], self.woT, b["do"])
+            qkv, dqkv = b["qkv"][k], b["dqkv"]
+            q = qkv[:, :nh * hd]
+            kd = [b["qkv"][i][:, kcol] for i in range(1, k + 1)]
+            vd = [b["qkv"][i][:, vcol] for i in range(1, k + 1)]
+            ops.attn_bwd_pre(q, b["o"][k], b["do"], kd, vd, b["dk"][1:k + 1], b["dv"][1:k + 1], b["lse"][k], b["delta"],
+                             b["dq_init"] if k > 0 else None, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+            ops.attn_bwd_dq(q, b["do"], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], b["k0t"], b["kvlen"], b["lse"][k],
+                            b["delta"], b["dq_init"] if k > 0 else None, dqkv[:, :nh * hd], B=B, S=S, nh=nh, nkv=nkv,
+                            hd=hd, scale=scale)
+            ops.transpose_heads(q, b["qt"], B, S, nh, hd)
+            ops.transpose_heads(b["do"], b["dot"], B, S, nh, hd)
+            ops.attn_bwd_dkv(q, b["do"], b["qt"], b["dot"], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], b["kvlen"],
+                             b["lse"][k], b["delta"], b["dk"][0], b["dv"][0], B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+            # K_k / V_k have now received every contribution (steps k..T-1)
+            ops.cast_from_f32(b["dk"][k], dqkv[:, kcol])
+            ops.cast_from_f32(b["dv"][k], dqkv[:, vcol])
+            ops.rope_(dqkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k, backward=True)
+            ops.transpose2d(dqkv, b["dqkvT"][:, cols])
+            ops.gemm_nt(dqkv, self.wqkvT, b["dxcat"])
+            dh_prev = b["dh_b"]
+            acc, a = nacc("midlayer.hidden_norm.weight")
+            ops.rmsnorm_bwd(b["dxcat"][:, H:], b["h"][k], f.view("midlayer.hidden_norm.weight"), b["rstd_h"][k],
+                            dx=dh_prev, add=b["dh1"], dw_acc=acc, dw_accumulate=a, workspace=ws)
+            acc, a = nacc("midlayer.input_layernorm.weight")
+            ops.rmsnorm_bwd(b["dxcat"][:, :H], self.model.embed_tokens.weight.data, f.view("midlayer.input_layernorm.weight"),
+                            b["rstd_e"][k], dx=None, dw_acc=acc, dw_accumulate=a, workspace=ws, ids_pad=b["ids"], S=S,
+                            Spad=Spad, off=k)
+            dh_next = dh_prev  # dh_b was consumed (as `add`) before it is rewritten in the next iteration
+        dh0 = dh_next
+        ops.transpose2d(dh0, b["dh0T"])
+        if c.fc_norm:
+            ops.gemm_nt(dh0, self.wfcT, b["dhs"])
+            hs = self._last_hs
+            for i in range(3):
+                acc, a = nacc(f"fc_norm.{i}.weight")
+                ops.rmsnorm_bwd(b["dhs"][:, i * Ht:(i + 1) * Ht], hs[:, i * Ht:(i + 1) * Ht], f.view(f"fc_norm.{i}.weight"),
+                                b["rstd_fc"][i], dx=None, dw_acc=acc, dw_accumulate=a, workspace=ws)
+
+        # ---- deferred weight gradients: one K = T*N GEMM per weight, bf16 straight into flat.grad
+        beta = 0.0 if self.micro_in_window == 0 else 1.0
+        jobs = [
+            ("lm_head.weight", "lm_head.weight", b["dlogT"], b["lnT"], f.gview("lm_head.weight")),
+            ("midlayer.mlp.gate_proj.weight", "midlayer.mlp.up_proj.weight", b["dguT"], b["pnT"], self.g_gu),
+            ("midlayer.mlp.down_proj.weight", "midlayer.mlp.down_proj.weight", b["dhT"], b["actT"],
+             f.gview("midlayer.mlp.down_proj.weight")),
+            ("midlayer.self_attn.q_proj.weight", "midlayer.self_attn.v_proj.weight", b["dqkvT"], b["xcatT"], self.g_qkv),
+            ("midlayer.self_attn.o_proj.weight", "midlayer.self_attn.o_proj.weight", b["dh1T"], b["oT"],
+             f.gview("midlayer.self_attn.o_proj.weight")),
+            ("fc.weight", "fc.weight", b["dh0T"], b["hsT"], f.gview("fc.weight")),
+        ]
+        for first_name, last_name, dyT, xT, gout in jobs:
+            ops.gemm_nt(dyT, xT, gout, alpha=g, beta=beta)
+            if self.on_bucket_ready is not None:
+                self.on_bucket_ready(f.slices[first_name][0], f.slices[last_name][1])
+        # norm weights: fp32 running total over the window, then one cast into the flat gradient
+        lo = f.slices[self._norm_names[0]][0]
+        for n in self._norm_names:
+            ops.axpy_f32(g, nm[n], self._norm_total[n], accumulate=self.micro_in_window > 0)
+            ops.cast_from_f32(self._norm_total[n].view(1, -1), f.gview(n).view(1, -1))
+        if self.on_bucket_ready is not None:
+            self.on_bucket_ready(lo, f.numel)
+        self.micro_in_window += 1
+
+    def end_window(self):
+        """called by the optimizer after it consumed flat.grad"""
+        self.micro_in_window = 0
+        self.weights_version += 1

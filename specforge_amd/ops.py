@@ -169,6 +169,13 @@ def cast_from_f32(inp: torch.Tensor, out: torch.Tensor, scale: float = 1.0):
     return out
 
 
+def axpy_f32(alpha: float, x: torch.Tensor, y: torch.Tensor, accumulate: bool = True):
+    L = _lib.lib()
+    assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.numel() == y.numel()
+    _lib.check(L.sf_axpy_f32(x.numel(), alpha, _p(x), _p(y), 1 if accumulate else 0, _stream()), "sf_axpy_f32")
+    return y
+
+
 def _ptr_array(ts: Sequence[torch.Tensor]):
     arr = (ctypes.c_void_p * max(1, len(ts)))()
     for i, t in enumerate(ts):
@@ -209,10 +216,10 @@ def attn_bwd_dkv(q, dout, qt, dot, k0, v0, kv_len, lse, delta, dk, dv, *, B, S, 
                                  B, S, nh, nkv, hd, scale, _stream()), "sf_attn_bwd_dkv")
 
 
-def grad_norm(g: torch.Tensor, norm_out: torch.Tensor, workspace: torch.Tensor, extra_sq: float = 0.0):
+def grad_norm(g: torch.Tensor, norm_out: torch.Tensor, workspace: torch.Tensor, prescale: float = 1.0):
     L = _lib.lib()
     assert g.is_contiguous() and workspace.numel() >= L.sf_grad_norm_workspace_floats()
-    _lib.check(L.sf_grad_norm(_p(g), _dt(g), g.numel(), extra_sq, _p(norm_out), _p(workspace), _stream()), "sf_grad_norm")
+    _lib.check(L.sf_grad_norm(_p(g), _dt(g), g.numel(), prescale, _p(norm_out), _p(workspace), _stream()), "sf_grad_norm")
     return norm_out
 
 

@@ -1,0 +1,245 @@
+"""Optimizer + data-parallel training backend of the HIP EAGLE3 path.
+
+* ``BF16Optimizer``: same constructor arguments, ``step() -> grad_norm``, ``get_learning_rate()``
+  and ``state_dict()`` keys as the reference (specforge/optimizer.py:12-232) -- fp32 masters +
+  AdamW + global-L2 clip + warmup/cosine schedule -- but on the engine's flat buffers: ONE
+  grad-norm reduction kernel and ONE fused clip+AdamW+bf16-cast kernel per step, no host sync
+  (the clip coefficient is read from device memory by the AdamW kernel).
+* ``HipDPTrainingBackend``: the ``TrainingBackend`` contract (specforge/training/backend.py:126-148)
+  without FSDP/DDP: gradients of the replicated draft are all-reduced over the default process
+  group (``backend="nccl"`` is RCCL over xGMI on ROCm; gloo in the CPU tests) bucket by bucket
+  from inside the engine's backward sweep, so the collective of bucket i overlaps the wgrad
+  GEMM of bucket i+1; non-boundary micro-steps skip the collective (DDP ``no_sync`` semantics,
+  backend.py:310-320).  The 1/world of DDP's gradient averaging is folded into the grad-norm
+  and AdamW kernels (no extra pass over the gradients).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+from .eagle3 import OnlineEagle3Model
+
+
+class _WarmupSchedule:
+    """LR in effect after ``last_epoch`` scheduler steps of the reference's ``CosineAnnealingWarmupLR`` /
+    ``ConstantWarmupLR`` (specforge/lr_scheduler.py:56-147): linear warmup ``(k+1)/W*lr``; the cosine branch
+    chains torch's recursive CosineAnnealingLR started one step late, giving
+    ``base*(1+cos(pi*e/T))/(1+cos(pi/T))`` with e = k-W (pinned by tests/golden/optimizer_bf16.pt)."""
+
+    def __init__(self, kind: str, base_lr: float, total_steps: int, warmup_steps: int, eta_min: float = 0.0):
+        if kind not in ("cosine", "constant"):
+            raise ValueError(f"unsupported lr_scheduler={kind!r}; expected one of ['constant', 'cosine']")
+        self.kind, self.base_lr, self.total_steps, self.warmup_steps, self.eta_min = kind, base_lr, total_steps, warmup_steps, eta_min
+        self.last_epoch = 0
+
+    def lr(self) -> float:
+        k, W = self.last_epoch, self.warmup_steps
+        if k < W:
+            return (k + 1) / W * self.base_lr
+        if self.kind == "constant":
+            return self.base_lr
+        e, T = k - W, self.total_steps - W
+        return self.eta_min + (self.base_lr - self.eta_min) * (1 + math.cos(math.pi * e / T)) / (1 + math.cos(math.pi / T))
+
+    def step(self):
+        self.last_epoch += 1
+
+    def state_dict(self):
+        return dict(last_epoch=self.last_epoch, base_lr=self.base_lr, total_steps=self.total_steps,
+                    warmup_steps=self.warmup_steps, eta_min=self.eta_min, kind=self.kind)
+
+    def load_state_dict(self, sd):
+        self.last_epoch = int(sd["last_epoch"])
+
+
+class BF16Optimizer:
+    def __init__(self, model: OnlineEagle3Model, lr, weight_decay=0.0, max_grad_norm=0.5, total_steps=800_000,
+                 warmup_ratio=0.015, lr_scheduler="cosine", offload_master=False, betas=(0.9, 0.999), eps=1e-8):
+        if offload_master:
+            raise NotImplementedError("fp32 masters live in HBM on MI355X (288 GB); offload_master is not supported")
+        self.model = model
+        self.engine = model.engine
+        f = self.engine.flat
+        self.max_grad_norm = float(max_grad_norm)
+        self.weight_decay, self.betas, self.eps = float(weight_decay), betas, eps
+        self.master = f.data.float().clone()
+        self.exp_avg = torch.zeros_like(self.master)
+        self.exp_avg_sq = torch.zeros_like(self.master)
+        self.norm = torch.zeros(1, device=f.data.device)
+        self._ws = torch.empty(1024, device=f.data.device)
+        self.step_count = 0
+        self.lr_scheduler_type = lr_scheduler
+        self.scheduler = _WarmupSchedule(lr_scheduler, float(lr), int(total_steps), int(warmup_ratio * total_steps))
+        self.last_grad_norm = None
+        self.grad_prescale = 1.0  # 1/world when the DP backend SUM-reduces (DDP averages)
+
+    def get_learning_rate(self) -> float:
+        return self.scheduler.lr()
+
+    def step(self):
+        f = self.engine.flat
+        self.step_count += 1
+        lr = self.scheduler.lr()
+        ops.grad_norm(f.grad, self.norm, self._ws, self.grad_prescale)
+        ops.adamw_step(f.grad, self.master, self.exp_avg, self.exp_avg_sq, f.data, self.norm, max_norm=self.max_grad_norm,
+                       lr=lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, wd=self.weight_decay,
+                       step=self.step_count, grad_prescale=self.grad_prescale)
+        self.scheduler.step()
+        self.engine.end_window()
+        self.last_grad_norm = self.norm[0].clone()
+        return self.last_grad_norm
+
+    # ---- reference-shaped state dict (optimizer.py:221-229; torch.optim.AdamW layout inside) ----
+    def _per_param(self, flat: torch.Tensor) -> List[torch.Tensor]:
+        f = self.engine.flat
+        return [flat[f.slices[n][0]:f.slices[n][1]].view(f.params[n].shape) for n in f.module_order]
+
+    def state_dict(self) -> Dict[str, Any]:
+        n = len(self.engine.flat.module_order)
+        state = {i: dict(step=torch.tensor(float(self.step_count)), exp_avg=m.detach().cpu().clone(),
+                         exp_avg_sq=v.detach().cpu().clone())
+                 for i, (m, v) in enumerate(zip(self._per_param(self.exp_avg), self._per_param(self.exp_avg_sq)))}
+        group = dict(lr=self.scheduler.lr(), betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay,
+                     amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     initial_lr=self.scheduler.base_lr, params=list(range(n)))
+        return {
+            "optimizer_state_dict": {"state": state if self.step_count else {}, "param_groups": [group]},
+            "scheduler_state_dict": self.scheduler.state_dict(),
+            "lr_scheduler_type": self.lr_scheduler_type,
+            "max_grad_norm": self.max_grad_norm,
+            "fp32_params": [t.detach().cpu().clone() for t in self._per_param(self.master)],
+        }
+
+    def load_state_dict(self, sd: Dict[str, Any]) -> None:
+        if sd.get("lr_scheduler_type", "cosine") != self.lr_scheduler_type:
+            raise ValueError(f"checkpoint optimizer used lr_scheduler={sd.get('lr_scheduler_type')!r} but this run has "
+                             f"lr_scheduler={self.lr_scheduler_type!r}")
+        if sd.get("max_grad_norm") is not None and float(sd["max_grad_norm"]) != self.max_grad_norm:
+            raise ValueError(f"checkpoint optimizer used max_grad_norm={sd['max_grad_norm']} but this run has "
+                             f"max_grad_norm={self.max_grad_norm}")
+        st = sd["optimizer_state_dict"]["state"]
+        with torch.no_grad():
+            for i, (m, v) in enumerate(zip(self._per_param(self.exp_avg), self._per_param(self.exp_avg_sq))):
+                if i in st:
+                    m.copy_(st[i]["exp_avg"])
+                    v.copy_(st[i]["exp_avg_sq"])
+                    self.step_count = int(st[i]["step"])
+            if sd.get("fp32_params") is not None:
+                for dst, src in zip(self._per_param(self.master), sd["fp32_params"]):
+                    if dst.shape != src.shape:
+                        raise ValueError(f"fp32 master param shape mismatch: checkpoint {tuple(src.shape)} vs {tuple(dst.shape)}")
+                    dst.copy_(src)
+            else:
+                self.master.copy_(self.engine.flat.data.float())
+        self.scheduler.load_state_dict(sd["scheduler_state_dict"])
+
+
+@dataclass
+class ParallelConfig:
+    """the fields callers read (training/backend.py:30-123)"""
+
+    world_size: int = 1
+    tp_size: int = 1
+    sp_size: int = 1
+    dp_size: int = 1
+    sharding_strategy: str = "NO_SHARD"
+    fsdp_process_group: Any = None
+
+
+class HipDPTrainingBackend:
+    name = "hip_dp"
+
+    def __init__(self, parallel_config: Optional[ParallelConfig] = None, *, optimizer_factory=None, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.parallel_config = parallel_config or ParallelConfig(world_size=self.world, dp_size=self.world,
+                                                                 fsdp_process_group=process_group)
+        self._optimizer_factory = optimizer_factory
+        self.module: Optional[OnlineEagle3Model] = None
+        self.optimizer: Optional[BF16Optimizer] = None
+        self._handles: List[Any] = []
+        self._sync_this_backward = True
+        self.no_sync_backwards = 0  # telemetry: micro-steps that skipped the collective
+
+    @property
+    def optimizer_state_is_replicated(self) -> bool:
+        return True
+
+    def prepare_model(self, model: OnlineEagle3Model, *, wrap: bool = True, optimizer_target=None) -> nn.Module:
+        self.module = model
+        model.engine.on_bucket_ready = self._bucket_ready if self.world > 1 else None
+        if self.world > 1:  # replicas must start identical (DDP broadcasts rank 0's parameters)
+            dist.broadcast(model.engine.flat.data, src=0, group=self.group)
+        if self._optimizer_factory is not None:
+            self.optimizer = self._optimizer_factory(optimizer_target if optimizer_target is not None else model)
+            self.optimizer.grad_prescale = 1.0 / self.world
+        return model
+
+    def set_optimizer(self, optimizer: BF16Optimizer) -> None:
+        self.optimizer = optimizer
+        optimizer.grad_prescale = 1.0 / self.world
+
+    def _bucket_ready(self, lo: int, hi: int) -> None:
+        if not self._sync_this_backward:
+            return
+        # async SUM over RCCL: enqueued behind the wgrad GEMM that produced the bucket, runs on the
+        # communicator's stream while the compute stream continues with the next GEMM
+        self._handles.append(dist.all_reduce(self.module.engine.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                             async_op=True))
+
+    def backward(self, loss: torch.Tensor, *, is_boundary: bool = True) -> None:
+        self._sync_this_backward = bool(is_boundary)
+        if not is_boundary and self.world > 1:
+            self.no_sync_backwards += 1
+        loss.backward()
+
+    def scale_gradients(self, factor) -> None:
+        raise NotImplementedError("loss_terms strategies (DFlash) are outside the EAGLE3 path")
+
+    def step(self):
+        for h in self._handles:
+            h.wait()
+        self._handles.clear()
+        return self.optimizer.step()
+
+    def state_dict(self) -> dict:
+        sd = {k: v.detach().clone() for k, v in self.module.state_dict().items() if not k.startswith("_anchor")}
+        return {"model": sd, "optimizer": self.optimizer.state_dict() if self.optimizer else None,
+                "rng": {"cpu": torch.get_rng_state()}}
+
+    def load_state_dict(self, state: dict) -> None:
+        own = self.module.state_dict()
+        with torch.no_grad():
+            for k, v in state["model"].items():
+                own[k].copy_(v)
+        if self.optimizer is not None and state.get("optimizer") is not None:
+            self.optimizer.load_state_dict(state["optimizer"])
+            self.module.engine.flat.data.copy_(self.optimizer.master)
+        self.module.engine.weights_version += 1
+        if state.get("rng") and "cpu" in state["rng"]:
+            torch.set_rng_state(state["rng"]["cpu"])
+
+
+def distributed_sampler_indices(size: int, *, dp_rank: int, dp_size: int, seed: int, epoch: int, shuffle: bool = True):
+    """``_distributed_sampler_indices`` (specforge/launch.py:219-239): == torch DistributedSampler."""
+    if size <= 0:
+        return []
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(int(seed) + int(epoch))
+        idx = torch.randperm(size, generator=g).tolist()
+    else:
+        idx = list(range(size))
+    total = math.ceil(size / dp_size) * dp_size
+    pad = total - len(idx)
+    if pad:
+        reps = math.ceil(pad / len(idx))
+        idx.extend((idx * reps)[:pad])
+    return idx[dp_rank:total:dp_size]
