@@ -83,8 +83,8 @@ def cpu_baseline(cfg, S, ttt, threads):
     torch.set_num_threads(threads)
     oc = O.DraftConfig(**{k: cfg[k] for k in ("hidden_size", "intermediate_size", "num_attention_heads", "num_key_value_heads",
                                                "vocab_size", "draft_vocab_size", "head_dim", "target_hidden_size",
-                                               "max_position_embeddings", "rms_norm_eps", "rope_theta")},
-                       rope_scaling=cfg.get("rope_scaling"))
+                                               "max_position_embeddings", "rms_norm_eps")},
+                       rope_theta=cfg.get("rope_theta", 10000.0), rope_scaling=cfg.get("rope_scaling"))
     p = {k: v.requires_grad_(True) for k, v in O.init_params(oc, seed=0).items()}
     g = torch.Generator().manual_seed(0)
     embed = torch.randn(oc.vocab_size, oc.hidden_size, generator=g) * 0.02
@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--ttt", type=int, default=7)
     ap.add_argument("--small", action="store_true", help="tiny model dims (smoke / debugging only; NOT the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-seq", type=int, default=128)
+    ap.add_argument("--cpu-sample-seq", type=int, default=64)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,8 +193,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_seq if not args.small else 64, args.ttt,
-                                                    os.cpu_count() or 1)
+                # bounded sample: 32 threads (more only adds oversubscription on these matrix sizes)
+                line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample_seq, args.ttt, min(32, os.cpu_count() or 1))
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {e}"}

@@ -1,0 +1,61 @@
+"""C-ABI checks that need no GPU: libsfhip.so (the hipcc/gfx950 build) loads and exports every
+symbol include/specforge_amd.h declares; the product path has no CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "specforge_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    from specforge_amd import _lib, build
+
+    path = build.build_hip()  # cross-compiles for gfx950 without a GPU
+    lib = ctypes.CDLL(path)
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libsfhip.so lacks {n}"
+    assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
+    lib.sf_abi_version.restype = ctypes.c_int
+    assert lib.sf_abi_version() == 1
+    assert lib.sf_is_emulated() == 0
+
+
+def test_product_path_has_no_cpu_fallback(monkeypatch, tmp_path):
+    from specforge_amd import _lib, ops
+
+    _lib._inject_library_for_tests(None)
+    # (1) missing library -> loud error
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+    monkeypatch.undo()
+    _lib._inject_library_for_tests(None)
+    # (2) product library + CPU tensors -> refused before any kernel is launched
+    a = torch.zeros(8, 8, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.gemm_nt(a, a, torch.zeros(8, 8, dtype=torch.bfloat16))
+    _lib._inject_library_for_tests(None)
+
+
+def test_argument_checks_return_errors_not_crashes(emu_lib_path):
+    from specforge_amd import _lib, ops
+
+    _lib._inject_library_for_tests(emu_lib_path)
+    try:
+        a = torch.zeros(8, 12, dtype=torch.bfloat16)  # K=12 is not a multiple of 8
+        with pytest.raises(_lib.SfError, match="multiples of 8"):
+            ops.gemm_nt(a, a, torch.zeros(8, 8, dtype=torch.bfloat16))
+        assert b"sf_gemm_nt" in _lib.lib().sf_last_error()
+    finally:
+        _lib._inject_library_for_tests(None)
