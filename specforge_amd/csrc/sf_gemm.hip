@@ -16,6 +16,7 @@
 // Workgroup ids are remapped so that each XCD (private L2) walks a compact group of tiles.
 #include "sf_api_internal.h"
 #include "sf_util.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -172,6 +173,17 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) gemm_nt_kernel(GemmArgs p) {
 
 }  // namespace
 
+int sf_gemm_nt_256_launch(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
+                          int K, float alpha, float beta, const void* R, long ldr, void* stream);
+// tuning knob for A/B measurements only: SF_GEMM_TILE=128 pins the 128x128 kernel
+static bool sf_gemm_use_256() {
+    static const bool use = [] {
+        const char* e = getenv("SF_GEMM_TILE");
+        return !(e && atoi(e) == 128);
+    }();
+    return use;
+}
+
 extern "C" int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
                           int K, float alpha, float beta, const void* R, long ldr, void* stream) {
     SF_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sf_gemm_nt: negative shape");
@@ -180,6 +192,9 @@ extern "C" int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void
     SF_CHECK_ARG(c_dtype == SF_BF16 || c_dtype == SF_F32, "sf_gemm_nt: c_dtype");
     SF_CHECK_ARG(!(R && c_dtype == SF_F32), "sf_gemm_nt: residual epilogue is bf16-only");
     if (M == 0 || N == 0) return 0;
+    // big, 64-aligned-K shapes (every GEMM of the training step) take the 256x256 ping-pong kernel
+    if (K % 64 == 0 && K >= 64 && M >= 192 && N >= 192 && sf_gemm_use_256())
+        return sf_gemm_nt_256_launch(A, lda, B, ldb, C, c_dtype, ldc, M, N, K, alpha, beta, R, ldr, stream);
     GemmArgs p;
     p.A = (const sf_bf16*)A; p.lda = lda;
     p.B = (const sf_bf16*)B; p.ldb = ldb;
