@@ -21,6 +21,7 @@
 // address (same scheme as sf_gemm.hip).
 #include "sf_api_internal.h"
 #include "sf_util.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -47,17 +48,20 @@ struct AttnFwdArgs {
     float* lse;                        // [B, nh, S] natural-log lse over all S+k columns
     int B, S, nh, nkv;
     float scale;
+    int dbg;  // profiling experiments only (SF_ATTN_DBG): 1 = stage tile 0 only, 2 = skip the MFMA/softmax work
 };
 
 // ---- LDS tile staging -------------------------------------------------------
 // natural tile: 64 rows (keys / queries) x HD, row-major, 16-byte chunks XOR-swizzled by row&7
-template <int HD>
+template <int HD, int NW>
 SF_DEVICE void stage_rows64(char* lds, const sf_bf16* base, long ld, int row0, int nrows_valid, int wave, int lane) {
     constexpr int CPR = HD / 8;            // chunks per row
     constexpr int RPI = 64 / CPR;          // rows per wave-instruction (1 KiB)
-    constexpr int NI = 64 / RPI / 4;       // instructions per wave
+    constexpr int NP = 64 / RPI;           // 1 KiB pieces per tile
+    constexpr int NI = (NP + NW - 1) / NW; // instructions per wave
 #pragma unroll
     for (int t = 0; t < NI; ++t) {
+        if (NP % NW != 0 && wave * NI + t >= NP) break;  // wave-uniform
         const int rr = (wave * NI + t) * RPI + lane / CPR;
         const int pc = lane % CPR;
         const int lc = pc ^ (rr & 7);
@@ -66,11 +70,13 @@ SF_DEVICE void stage_rows64(char* lds, const sf_bf16* base, long ld, int row0, i
     }
 }
 // transposed tile: HD rows (d) x 64 columns (keys / queries) from a [HD][S] matrix
-template <int HD>
+template <int HD, int NW>
 SF_DEVICE void stage_cols64(char* lds, const sf_bf16* base, int S, int col0, int wave, int lane) {
-    constexpr int NI = HD / 8 / 4;  // 8 rows of 128 B per instruction
+    constexpr int NP = HD / 8;             // 8 rows of 128 B per 1 KiB piece
+    constexpr int NI = (NP + NW - 1) / NW;
 #pragma unroll
     for (int t = 0; t < NI; ++t) {
+        if (NP % NW != 0 && wave * NI + t >= NP) break;  // wave-uniform
         const int rr = (wave * NI + t) * 8 + (lane >> 3);
         const int pc = lane & 7;
         const int lc = pc ^ (rr & 7);
@@ -79,21 +85,35 @@ SF_DEVICE void stage_cols64(char* lds, const sf_bf16* base, int S, int col0, int
         sf_glds16(src, lds + (wave * NI + t) * 1024);
     }
 }
+// Per-lane LDS byte offsets of the MFMA fragments, computed once per kernel so the tile loops issue
+// ds_reads with (register + immediate) addresses only.  Tile row blocks start at multiples of 32
+// rows, so (row & 7) == (lane & 7) for every fragment row.
+template <int HD>
+struct FragOff {
+    int rows[HD / 16];  // natural tile, k-step ks: (lane&31)*rowbytes + swizzled chunk (2ks + hi)
+    int cols[4][2];     // transposed tile, 16-column group i: two 8-byte runs (chunks 2i, 2i+1) at +8*hi
+    SF_DEVICE void init(int lane) {
+        const int c = lane & 31, hi = lane >> 5, x = lane & 7;
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) rows[ks] = c * (HD * 2) + (((2 * ks + hi) ^ x) << 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cols[i][0] = c * 128 + (((2 * i) ^ x) << 4) + hi * 8;
+            cols[i][1] = c * 128 + (((2 * i + 1) ^ x) << 4) + hi * 8;
+        }
+    }
+};
 // A fragment (32 rows x 16 k) from a natural tile: row = r0 + (lane&31), k = 16*ks + 8*(lane>>5)
 template <int HD>
-SF_DEVICE sf_v8s frag_rows(const char* lds, int r0, int ks, int lane) {
-    const int row = r0 + (lane & 31);
-    const int lc = 2 * ks + (lane >> 5);
-    return *reinterpret_cast<const sf_v8s*>(lds + row * (HD * 2) + ((lc ^ (row & 7)) << 4));
+SF_DEVICE sf_v8s frag_rows(const char* lds, int r0, int ks, const FragOff<HD>& fo) {
+    return *reinterpret_cast<const sf_v8s*>(lds + r0 * (HD * 2) + fo.rows[ks]);
 }
 // A fragment from a transposed tile for the "C-layout as B operand" contraction: row d = d0+(lane&31),
 // k-slots = columns {c0 + 4*hi + 0..3} and {c0 + 8 + 4*hi + 0..3}  (c0 multiple of 16)
-SF_DEVICE sf_v8s frag_cols(const char* lds, int d0, int c0, int lane) {
-    const int row = d0 + (lane & 31);
-    const int hi = lane >> 5;
-    const int ch = c0 >> 3;  // 16-byte chunk of the first run; second run is the next chunk
-    const sf_v4s lo = *reinterpret_cast<const sf_v4s*>(lds + row * 128 + (((ch) ^ (row & 7)) << 4) + hi * 8);
-    const sf_v4s up = *reinterpret_cast<const sf_v4s*>(lds + row * 128 + (((ch + 1) ^ (row & 7)) << 4) + hi * 8);
+template <int HD>
+SF_DEVICE sf_v8s frag_cols(const char* lds, int d0, int c0, const FragOff<HD>& fo) {
+    const sf_v4s lo = *reinterpret_cast<const sf_v4s*>(lds + d0 * 128 + fo.cols[c0 >> 4][0]);
+    const sf_v4s up = *reinterpret_cast<const sf_v4s*>(lds + d0 * 128 + fo.cols[c0 >> 4][1]);
     return sf_v8s{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
 }
 SF_DEVICE sf_v8s pack_bf16x8(const sf_v16f& p, int r0) {
@@ -113,14 +133,12 @@ SF_DEVICE float dot8(sf_v8s a, sf_v8s b) {
 }
 
 // ------------------------------------------------------------------ forward
-template <int HD>
-SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_fwd_kernel(AttnFwdArgs p) {
-    constexpr int KS = HD / 16, DB = HD / 32;
-    SF_DYN_SMEM(smem);
-    char* lds_k = smem;                 // [64][HD]
-    char* lds_vt = smem + 64 * HD * 2;  // [HD][64]
+template <int HD, int NW>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
+    constexpr int KS = HD / 16, DB = HD / 32, QB = NW * 32, TILE = 128 * HD * 2;
+    SF_DYN_SMEM(smem);  // 2 x { K [64][HD], V^T [HD][64] }
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
-    const int qb0 = (int)blockIdx.x * 128, h = (int)blockIdx.y, b = (int)blockIdx.z;
+    const int qb0 = (int)blockIdx.x * QB, h = (int)blockIdx.y, b = (int)blockIdx.z;
     const int g = h / (p.nh / p.nkv);
     const int S = p.S;
     const int kvlen = p.kv_len ? p.kv_len[b] : S;
@@ -129,6 +147,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_fwd_kernel(AttnFwdArgs p) {
     const bool qok = qi < S;
     const long qrow = (long)b * S + (qok ? qi : S - 1);
     const float sc = p.scale * kLog2e;
+    FragOff<HD> fo;
+    fo.init(lane);
 
     sf_v8s qf[KS];
 #pragma unroll
@@ -144,17 +164,26 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_fwd_kernel(AttnFwdArgs p) {
 
     const sf_bf16* kbase = p.k0 + (long)b * S * p.ldk + g * HD;
     const sf_bf16* vtbase = p.v0t + ((long)b * p.nkv + g) * HD * S;
-    int kend = qb0 + 128 < S ? qb0 + 128 : S;  // causal upper bound for this block
+    int kend = qb0 + QB < S ? qb0 + QB : S;  // causal upper bound for this block
     if (kvlen < kend) kend = kvlen;
     const int ntiles = (kend + 63) / 64;
+    if (ntiles > 0) {
+        stage_rows64<HD, NW>(smem, kbase, p.ldk, 0, S, wave, lane);
+        stage_cols64<HD, NW>(smem + 64 * HD * 2, vtbase, S, 0, wave, lane);
+    }
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 64;
-        sf_syncthreads();  // previous tile fully consumed
-        stage_rows64<HD>(lds_k, kbase, p.ldk, key0, S, wave, lane);
-        stage_cols64<HD>(lds_vt, vtbase, S, key0, wave, lane);
         sf_wait_vm0();
-        sf_syncthreads();
+        sf_syncthreads();  // tile kt landed for everyone; buffer (kt+1)&1 is no longer being read
+        if (kt + 1 < ntiles && !(p.dbg & 1)) {
+            char* nb = smem + ((kt + 1) & 1) * TILE;
+            stage_rows64<HD, NW>(nb, kbase, p.ldk, key0 + 64, S, wave, lane);
+            stage_cols64<HD, NW>(nb + 64 * HD * 2, vtbase, S, key0 + 64, wave, lane);
+        }
+        const char* lds_k = smem + (kt & 1) * TILE;
+        const char* lds_vt = lds_k + 64 * HD * 2;
         if (key0 > qw0 + 31) continue;  // whole tile above this wave's diagonal (wave-uniform)
+        if (p.dbg & 2) continue;
         const bool need_mask = (key0 + 63 > qw0) || (key0 + 63 >= kvlen);
         sf_v16f s[2];
 #pragma unroll
@@ -162,40 +191,44 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_fwd_kernel(AttnFwdArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s[kb] = sf_mfma32(frag_rows<HD>(lds_k, kb * 32, ks, lane), qf[ks], s[kb]);
+            for (int ks = 0; ks < KS; ++ks) s[kb] = sf_mfma32(frag_rows<HD>(lds_k, kb * 32, ks, fo), qf[ks], s[kb]);
         }
-        float mt = kNegBig;
+        // scores stay unscaled in the accumulators; only diagonal / padded tiles pay for masking
+        if (need_mask) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = s[kb][r] * sc;
-                if (need_mask) {
+                for (int r = 0; r < 16; ++r) {
                     const int kk = key0 + kb * 32 + crow(r, hi);
-                    if (kk > qi || kk >= kvlen) v = kNegBig;
+                    if (kk > qi || kk >= kvlen) s[kb][r] = -INFINITY;
                 }
-                s[kb][r] = v;
-                mt = fmaxf(mt, v);
-            }
+        }
+        float mt = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s[0][r], s[1][r]));
         mt = fmaxf(mt, sf_shfl_xor(mt, 32));
-        const float mn = fmaxf(m, mt);
-        const float alpha = sf_exp2(m - mn);
-        m = mn;
+        const float mts = mt * sc;  // running max m lives in the scaled log2 domain
+        // deferred rescale: O and l are rescaled only when some row's max grew by more than 2^8
+        if (!sf_all(mts - m <= 8.0f)) {
+            const float mn = fmaxf(m, mts);
+            const float alpha = sf_exp2_raw(m - mn);
+            m = mn;
+            lpart *= alpha;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+        }
         float ps = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = s[kb][r];
-                const float e = (v <= kNegBig) ? 0.f : sf_exp2(v - mn);
+                const float e = sf_exp2_raw(fmaf(s[kb][r], sc, -m));  // exp2(-inf) == 0 for masked keys
                 s[kb][r] = e;
                 ps += e;
             }
-        lpart = lpart * alpha + ps;
-#pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
+        lpart += ps;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -203,7 +236,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_fwd_kernel(AttnFwdArgs p) {
                 const sf_v8s pf = pack_bf16x8(s[kb], 8 * jp);
 #pragma unroll
                 for (int d = 0; d < DB; ++d)
-                    acc_o[d] = sf_mfma32(frag_cols(lds_vt, d * 32, kb * 32 + 16 * jp, lane), pf, acc_o[d]);
+                    acc_o[d] = sf_mfma32(frag_cols<HD>(lds_vt, d * 32, kb * 32 + 16 * jp, fo), pf, acc_o[d]);
             }
     }
     float l = lpart + sf_shfl_xor(lpart, 32);
@@ -359,15 +392,12 @@ struct AttnBwdArgs {
     float scale;
 };
 
-template <int HD>
-SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dq_kernel(AttnBwdArgs p) {
-    constexpr int KS = HD / 16, DB = HD / 32;
-    SF_DYN_SMEM(smem);
-    char* lds_k = smem;                  // [64][HD]
-    char* lds_v = smem + 64 * HD * 2;    // [64][HD]
-    char* lds_kt = smem + 128 * HD * 2;  // [HD][64]
+template <int HD, int NW>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
+    constexpr int KS = HD / 16, DB = HD / 32, QB = NW * 32, TILE = 192 * HD * 2;
+    SF_DYN_SMEM(smem);  // 2 x { K [64][HD], V [64][HD], K^T [HD][64] }
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
-    const int qb0 = (int)blockIdx.x * 128, h = (int)blockIdx.y, b = (int)blockIdx.z;
+    const int qb0 = (int)blockIdx.x * QB, h = (int)blockIdx.y, b = (int)blockIdx.z;
     const int g = h / (p.nh / p.nkv);
     const int S = p.S;
     const int kvlen = p.kv_len ? p.kv_len[b] : S;
@@ -376,6 +406,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const bool qok = qi < S;
     const long qrow = (long)b * S + (qok ? qi : S - 1);
     const float sc = p.scale * kLog2e;
+    FragOff<HD> fo;
+    fo.init(lane);
     const long li = ((long)b * p.nh + h) * S + (qok ? qi : S - 1);
     const float lse2 = p.lse[li] * kLog2e;
     const float dlt = p.delta[li];
@@ -395,17 +427,23 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const sf_bf16* kbase = p.k0 + (long)b * S * p.ldk + g * HD;
     const sf_bf16* vbase = p.v0 + (long)b * S * p.ldv + g * HD;
     const sf_bf16* ktbase = p.k0t + ((long)b * p.nkv + g) * HD * S;
-    int kend = qb0 + 128 < S ? qb0 + 128 : S;
+    int kend = qb0 + QB < S ? qb0 + QB : S;
     if (kvlen < kend) kend = kvlen;
     const int ntiles = (kend + 63) / 64;
+    auto stage = [&](char* dst, int key0) {
+        stage_rows64<HD, NW>(dst, kbase, p.ldk, key0, S, wave, lane);
+        stage_rows64<HD, NW>(dst + 64 * HD * 2, vbase, p.ldv, key0, S, wave, lane);
+        stage_cols64<HD, NW>(dst + 128 * HD * 2, ktbase, S, key0, wave, lane);
+    };
+    if (ntiles > 0) stage(smem, 0);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 64;
-        sf_syncthreads();
-        stage_rows64<HD>(lds_k, kbase, p.ldk, key0, S, wave, lane);
-        stage_rows64<HD>(lds_v, vbase, p.ldv, key0, S, wave, lane);
-        stage_cols64<HD>(lds_kt, ktbase, S, key0, wave, lane);
         sf_wait_vm0();
         sf_syncthreads();
+        if (kt + 1 < ntiles) stage(smem + ((kt + 1) & 1) * TILE, key0 + 64);
+        const char* lds_k = smem + (kt & 1) * TILE;
+        const char* lds_v = lds_k + 64 * HD * 2;
+        const char* lds_kt = lds_k + 128 * HD * 2;
         if (key0 > qw0 + 31) continue;
         sf_v16f s[2], dp[2];
 #pragma unroll
@@ -414,8 +452,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dq_kernel(AttnBwdArgs p) {
             for (int r = 0; r < 16; ++r) { s[kb][r] = 0.f; dp[kb][r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                s[kb] = sf_mfma32(frag_rows<HD>(lds_k, kb * 32, ks, lane), qf[ks], s[kb]);
-                dp[kb] = sf_mfma32(frag_rows<HD>(lds_v, kb * 32, ks, lane), dof[ks], dp[kb]);
+                s[kb] = sf_mfma32(frag_rows<HD>(lds_k, kb * 32, ks, fo), qf[ks], s[kb]);
+                dp[kb] = sf_mfma32(frag_rows<HD>(lds_v, kb * 32, ks, fo), dof[ks], dp[kb]);
             }
         }
 #pragma unroll
@@ -424,7 +462,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dq_kernel(AttnBwdArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int kk = key0 + kb * 32 + crow(r, hi);
                 const bool ok = (kk <= qi) && (kk < kvlen);
-                const float pv = ok ? sf_exp2(s[kb][r] * sc - lse2) : 0.f;
+                const float pv = ok ? sf_exp2_raw(fmaf(s[kb][r], sc, -lse2)) : 0.f;
                 s[kb][r] = pv * (dp[kb][r] - dlt);  // dS^T
             }
 #pragma unroll
@@ -434,7 +472,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dq_kernel(AttnBwdArgs p) {
                 const sf_v8s df = pack_bf16x8(s[kb], 8 * jp);
 #pragma unroll
                 for (int d = 0; d < DB; ++d)
-                    acc[d] = sf_mfma32(frag_cols(lds_kt, d * 32, kb * 32 + 16 * jp, lane), df, acc[d]);
+                    acc[d] = sf_mfma32(frag_cols<HD>(lds_kt, d * 32, kb * 32 + 16 * jp, fo), df, acc[d]);
             }
     }
     if (!qok) return;
@@ -457,42 +495,46 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dq_kernel(AttnBwdArgs p) {
 }
 
 // ---------------------------------------------------------- backward: dK, dV
-// LDS: Q [64][HD], dO [64][HD], Q^T [HD][64], dO^T [HD][64], lse2[64], delta[64]
-template <int HD>
-SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
-    constexpr int KS = HD / 16, DB = HD / 32;
+// Workgroup = NW waves = NW/2 key sub-blocks of 32 keys x 2 roles: waves [0, NW/2) accumulate dV^T,
+// waves [NW/2, NW) accumulate dK^T of the same keys (each recomputes S; a wave then carries ONE
+// 64-register accumulator set, so the kernel fits 2 waves/SIMD without spilling and the two roles
+// of a key sub-block sit on the same SIMD and overlap exp/LDS work with MFMA).
+// LDS (double buffered): Q [64][HD], dO [64][HD], Q^T [HD][64], dO^T [HD][64], lse2[64], delta[64]
+template <int HD, int NW>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dkv_kernel(AttnBwdArgs p) {
+    constexpr int KS = HD / 16, DB = HD / 32, NSUB = NW / 2, KB = NSUB * 32, TILE = 256 * HD * 2 + 512;
     SF_DYN_SMEM(smem);
-    char* lds_q = smem;
-    char* lds_do = smem + 64 * HD * 2;
-    char* lds_qt = smem + 128 * HD * 2;
-    char* lds_dot = smem + 192 * HD * 2;
-    float* lds_lse = reinterpret_cast<float*>(smem + 256 * HD * 2);
-    float* lds_dlt = lds_lse + 64;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
-    const int kb0 = (int)blockIdx.x * 128, g = (int)blockIdx.y, b = (int)blockIdx.z;
+    const int role = wave / NSUB;  // 0: dV, 1: dK   (wave-uniform)
+    const int sub = wave - role * NSUB;
+    const int kb0 = (int)blockIdx.x * KB, g = (int)blockIdx.y, b = (int)blockIdx.z;
     const int S = p.S, nrep = p.nh / p.nkv;
     const int kvlen = p.kv_len ? p.kv_len[b] : S;
-    const int kw0 = kb0 + wave * 32;
+    const int kw0 = kb0 + sub * 32;
     const int ki = kw0 + c;  // this lane's key (column of S)
     const bool kok = ki < S;
     const long krow = (long)b * S + (kok ? ki : S - 1);
     const float sc = p.scale * kLog2e;
+    FragOff<HD> fo;
+    fo.init(lane);
 
     sf_v8s kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         kf[ks] = *reinterpret_cast<const sf_v8s*>(p.k0 + krow * p.ldk + g * HD + 16 * ks + 8 * hi);
-        vf[ks] = *reinterpret_cast<const sf_v8s*>(p.v0 + krow * p.ldv + g * HD + 16 * ks + 8 * hi);
+        vf[ks] = kf[ks];
+        if (role == 1) vf[ks] = *reinterpret_cast<const sf_v8s*>(p.v0 + krow * p.ldv + g * HD + 16 * ks + 8 * hi);
     }
-    sf_v16f acc_dk[DB], acc_dv[DB];
+    sf_v16f acc[DB];
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc_dk[d][r] = 0.f; acc_dv[d][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
     const bool block_live = kb0 < kvlen;  // keys at/after kv_len never receive probability mass
     const int qt_first = kb0 / 64;
     const int nqt = (S + 63) / 64;
+    int it = 0;
     if (block_live)
         for (int hh = 0; hh < nrep; ++hh) {
             const int h = g * nrep + hh;
@@ -502,20 +544,30 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
             const sf_bf16* dotbase = p.dot + ((long)b * p.nh + h) * HD * S;
             const float* lsebase = p.lse + ((long)b * p.nh + h) * S;
             const float* dltbase = p.delta + ((long)b * p.nh + h) * S;
-            for (int qt = qt_first; qt < nqt; ++qt) {
-                const int q0 = qt * 64;
-                sf_syncthreads();
-                stage_rows64<HD>(lds_q, qbase, p.ldq, q0, S, wave, lane);
-                stage_rows64<HD>(lds_do, dobase, p.lddo, q0, S, wave, lane);
-                stage_cols64<HD>(lds_qt, qtbase, S, q0, wave, lane);
-                stage_cols64<HD>(lds_dot, dotbase, S, q0, wave, lane);
+            auto stage = [&](char* dst, int q0) {
+                stage_rows64<HD, NW>(dst, qbase, p.ldq, q0, S, wave, lane);
+                stage_rows64<HD, NW>(dst + 64 * HD * 2, dobase, p.lddo, q0, S, wave, lane);
+                stage_cols64<HD, NW>(dst + 128 * HD * 2, qtbase, S, q0, wave, lane);
+                stage_cols64<HD, NW>(dst + 192 * HD * 2, dotbase, S, q0, wave, lane);
                 if (tid < 64) {
+                    float* sl = reinterpret_cast<float*>(dst + 256 * HD * 2);
                     const int qq = q0 + tid;
-                    lds_lse[tid] = qq < S ? lsebase[qq] * kLog2e : 0.f;
-                    lds_dlt[tid] = qq < S ? dltbase[qq] : 0.f;
+                    sl[tid] = qq < S ? lsebase[qq] * kLog2e : 0.f;
+                    sl[64 + tid] = qq < S ? dltbase[qq] : 0.f;
                 }
+            };
+            // the buffer parity continues across the heads of the group: `it` counts tiles globally
+            if (qt_first < nqt) stage(smem + (it & 1) * TILE, qt_first * 64);
+            for (int qt = qt_first; qt < nqt; ++qt, ++it) {
+                const int q0 = qt * 64;
                 sf_wait_vm0();
                 sf_syncthreads();
+                if (qt + 1 < nqt) stage(smem + ((it + 1) & 1) * TILE, q0 + 64);
+                const char* lds_q = smem + (it & 1) * TILE;
+                const char* lds_do = lds_q + 64 * HD * 2;
+                const char* lds_xt = lds_q + (role == 0 ? 192 : 128) * HD * 2;  // dO^T for dV, Q^T for dK
+                const float* lds_lse = reinterpret_cast<const float*>(lds_q + 256 * HD * 2);
+                const float* lds_dlt = lds_lse + 64;
                 if (q0 + 63 < kw0) continue;  // every query of the tile is before this wave's keys
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
@@ -523,49 +575,41 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
-                        s = sf_mfma32(frag_rows<HD>(lds_q, qb * 32, ks, lane), kf[ks], s);
-                        dp = sf_mfma32(frag_rows<HD>(lds_do, qb * 32, ks, lane), vf[ks], dp);
+                    for (int ks = 0; ks < KS; ++ks) s = sf_mfma32(frag_rows<HD>(lds_q, qb * 32, ks, fo), kf[ks], s);
+                    if (role == 1) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) dp = sf_mfma32(frag_rows<HD>(lds_do, qb * 32, ks, fo), vf[ks], dp);
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ql = qb * 32 + crow(r, hi);
                         const int qq = q0 + ql;
                         const bool ok = (ki <= qq) && (ki < kvlen) && (qq < S);
-                        const float pv = ok ? sf_exp2(s[r] * sc - lds_lse[ql]) : 0.f;
-                        s[r] = pv;                            // P
-                        dp[r] = pv * (dp[r] - lds_dlt[ql]);   // dS
+                        const float pv = ok ? sf_exp2_raw(fmaf(s[r], sc, -lds_lse[ql])) : 0.f;
+                        s[r] = role == 0 ? pv : pv * (dp[r] - lds_dlt[ql]);  // P (dV waves) | dS (dK waves)
                     }
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) {
-                        const sf_v8s pf = pack_bf16x8(s, 8 * jp);
-                        const sf_v8s df = pack_bf16x8(dp, 8 * jp);
+                        const sf_v8s f = pack_bf16x8(s, 8 * jp);
 #pragma unroll
-                        for (int d = 0; d < DB; ++d) {
-                            acc_dv[d] = sf_mfma32(frag_cols(lds_dot, d * 32, qb * 32 + 16 * jp, lane), pf, acc_dv[d]);
-                            acc_dk[d] = sf_mfma32(frag_cols(lds_qt, d * 32, qb * 32 + 16 * jp, lane), df, acc_dk[d]);
-                        }
+                        for (int d = 0; d < DB; ++d)
+                            acc[d] = sf_mfma32(frag_cols<HD>(lds_xt, d * 32, qb * 32 + 16 * jp, fo), f, acc[d]);
                     }
                 }
             }
         }
     if (!kok || !block_live) return;
-    float* dkrow = p.dk + krow * p.lddk + g * HD;
-    float* dvrow = p.dv + krow * p.lddk + g * HD;
+    float* orow = (role == 0 ? p.dv : p.dk) + krow * p.lddk + g * HD;
+    const float oscale = role == 0 ? 1.0f : p.scale;
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = d * 32 + 8 * j + 4 * hi;
-            sf_v4f a = *reinterpret_cast<const sf_v4f*>(dkrow + col);
-            sf_v4f bb = *reinterpret_cast<const sf_v4f*>(dvrow + col);
+            sf_v4f a = *reinterpret_cast<const sf_v4f*>(orow + col);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] += acc_dk[d][4 * j + t] * p.scale;
-                bb[t] += acc_dv[d][4 * j + t];
-            }
-            *reinterpret_cast<sf_v4f*>(dkrow + col) = a;
-            *reinterpret_cast<sf_v4f*>(dvrow + col) = bb;
+            for (int t = 0; t < 4; ++t) a[t] += acc[d][4 * j + t] * oscale;
+            *reinterpret_cast<sf_v4f*>(orow + col) = a;
         }
 }
 
@@ -577,6 +621,23 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
         else if ((hd) == 64) { constexpr int HD = 64; CALL; }     \
         else SF_CHECK_ARG(false, "head_dim must be 64 or 128");   \
     } while (0)
+
+constexpr int kAttnWaves = 8;  // waves per workgroup of the three MFMA attention kernels
+
+#ifdef SF_EMU
+#define SF_ALLOW_SMEM(kernel, bytes)
+#else
+// > 64 KiB of dynamic LDS needs the opt-in (once per kernel instantiation)
+#define SF_ALLOW_SMEM(kernel, bytes)                                                                        \
+    do {                                                                                                    \
+        static bool done_ = false;                                                                          \
+        if (!done_) {                                                                                       \
+            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));  \
+            (void)hipGetLastError();                                                                        \
+            done_ = true;                                                                                   \
+        }                                                                                                   \
+    } while (0)
+#endif
 
 extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, const void* v0t, const void* const* kd,
                            const void* const* vd, int ndiag, const int* kv_len, void* o, long ldo, float* lse, int B,
@@ -593,8 +654,11 @@ extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, co
     p.ndiag = ndiag; p.kv_len = kv_len;
     p.o = (sf_bf16*)o; p.ldo = ldo; p.lse = lse;
     p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.scale = scale;
-    dim3 grid((S + 127) / 128, nh, B);
-    SF_HD_DISPATCH(hd, SF_LAUNCH((attn_fwd_kernel<HD>), grid, dim3(256), 128 * HD * 2, stream, p));
+    { const char* e = getenv("SF_ATTN_DBG"); p.dbg = e ? atoi(e) : 0; }
+    constexpr int NW = kAttnWaves;
+    dim3 grid((S + NW * 32 - 1) / (NW * 32), nh, B);
+    SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_fwd_kernel<HD, NW>), 2 * 128 * HD * 2);
+                   SF_LAUNCH((attn_fwd_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
     return sf_check_launch("sf_attn_fwd");
 }
 
@@ -649,8 +713,10 @@ extern "C" int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long ld
     AttnBwdArgs p;
     fill_bwd_args(p, q, ldq, dout, lddo, nullptr, nullptr, k0, ldk, v0, ldv, k0t, kv_len, lse, delta, dq_init, dq, lddq,
                   nullptr, nullptr, 0, B, S, nh, nkv, scale);
-    dim3 grid((S + 127) / 128, nh, B);
-    SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_dq_kernel<HD>), grid, dim3(256), 192 * HD * 2, stream, p));
+    constexpr int NW = kAttnWaves;
+    dim3 grid((S + NW * 32 - 1) / (NW * 32), nh, B);
+    SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dq_kernel<HD, NW>), 2 * 192 * HD * 2);
+                   SF_LAUNCH((attn_bwd_dq_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 192 * HD * 2, stream, p));
     return sf_check_launch("sf_attn_bwd_dq");
 }
 
@@ -664,7 +730,9 @@ extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long l
     AttnBwdArgs p;
     fill_bwd_args(p, q, ldq, dout, lddo, qt, dot, k0, ldk, v0, ldv, nullptr, kv_len, lse, delta, nullptr, nullptr, 0, dk,
                   dv, lddk, B, S, nh, nkv, scale);
-    dim3 grid((S + 127) / 128, nkv, B);
-    SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_dkv_kernel<HD>), grid, dim3(256), 256 * HD * 2 + 512, stream, p));
+    constexpr int NW = kAttnWaves;
+    dim3 grid((S + NW * 16 - 1) / (NW * 16), nkv, B);  // NW/2 key sub-blocks of 32 keys per workgroup
+    SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, NW>), 2 * (256 * HD * 2 + 512));
+                   SF_LAUNCH((attn_bwd_dkv_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (256 * HD * 2 + 512), stream, p));
     return sf_check_launch("sf_attn_bwd_dkv");
 }

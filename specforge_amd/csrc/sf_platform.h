@@ -42,12 +42,18 @@ SF_DEVICE sf_v4f sf_mfma16(sf_v8s a, sf_v8s b, sf_v4f c) { return sfemu::mfma_16
 SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) { return sfemu::mfma_32x32x16_bf16(a, b, c); }
 SF_DEVICE void sf_glds16(const void* g, void* l) { sfemu::global_load_lds16(g, l); }
 SF_DEVICE int sf_wave_id() { return sfemu::wave_index(); }
+SF_DEVICE bool sf_all(bool pred) {
+    int v = pred ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) v &= sfemu::shfl_xor(v, m);
+    return v != 0;
+}
 SF_DEVICE void sf_wait_vm0() {}
 SF_DEVICE void sf_setprio_hi() {}
 SF_DEVICE void sf_setprio_lo() {}
 template <typename T> SF_DEVICE T sf_atomic_add(T* p, T v) { return sfemu::atomic_add(p, v); }
 SF_DEVICE float sf_exp(float x) { return expf(x); }
 SF_DEVICE float sf_exp2(float x) { return exp2f(x); }
+SF_DEVICE float sf_exp2_raw(float x) { return exp2f(x); }
 SF_DEVICE float sf_log(float x) { return logf(x); }
 SF_DEVICE float sf_rsqrt(float x) { return 1.0f / sqrtf(x); }
 
@@ -84,6 +90,7 @@ SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) {
 // (first ACTIVE lane != lane 0) -- observed on gfx950 when a select between two source
 // pointers was lowered to two exec-masked loads.
 SF_DEVICE int sf_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+SF_DEVICE bool sf_all(bool pred) { return __all(pred ? 1 : 0) != 0; }
 SF_DEVICE void sf_glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -94,6 +101,8 @@ SF_DEVICE void sf_setprio_lo() { __builtin_amdgcn_s_setprio(0); }
 template <typename T> SF_DEVICE T sf_atomic_add(T* p, T v) { return atomicAdd(p, v); }
 SF_DEVICE float sf_exp(float x) { return expf(x); }
 SF_DEVICE float sf_exp2(float x) { return exp2f(x); }
+// bare v_exp_f32 (no denormal-range fix-up): for softmax terms, where tiny results may flush to 0
+SF_DEVICE float sf_exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
 SF_DEVICE float sf_log(float x) { return logf(x); }
 SF_DEVICE float sf_rsqrt(float x) { return rsqrtf(x); }
 #endif
@@ -105,13 +114,11 @@ SF_HD float sf_bf2f(sf_bf16 h) {
     return x.f;
 }
 // round-to-nearest-even, NaN stays NaN (same as torch's float->bfloat16)
+// (native __bf16 cast: lowers to v_cvt_pk_bf16_f32 on gfx950 -- one VALU op per two values instead of
+// ~9 for the bit-twiddled form; the host compiler's soft conversion is bit-identical for non-NaN inputs)
 SF_HD sf_bf16 sf_f2bf(float f) {
-    union { uint32_t u; float f; } x;
-    x.f = f;
-    uint32_t u = x.u;
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (sf_bf16)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (sf_bf16)(u >> 16);
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(sf_bf16, b);
 }
 SF_HD float sf_round_bf(float f) { return sf_bf2f(sf_f2bf(f)); }
 

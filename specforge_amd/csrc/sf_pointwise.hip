@@ -136,12 +136,22 @@ rmsnorm_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, const long long
 }
 
 // acc[col] (+)= sum_b partial[b][col]   (deterministic: fixed order)
+// 1024 threads = 64 columns x 16 row lanes; lane order of the final sum is fixed.
 SF_GLOBAL void colsum_accum_kernel(const float* partial, int nb, int H, float* acc, int accumulate) {
-    const int col = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (col >= H) return;
+    SF_SHARED float red[16][64];
+    const int cl = (int)threadIdx.x & 63, rl = (int)threadIdx.x >> 6;
+    const int col = (int)blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partial[(long)b * H + col];
-    acc[col] = accumulate ? acc[col] + s : s;
+    if (col < H)
+        for (int b = rl; b < nb; b += 16) s += partial[(long)b * H + col];
+    red[rl][cl] = s;
+    sf_syncthreads();
+    if (rl == 0 && col < H) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cl];
+        acc[col] = accumulate ? acc[col] + t : t;
+    }
 }
 
 // --------------------------------------------------------------------- RoPE
@@ -374,7 +384,7 @@ extern "C" int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* 
                                    ldx, ids_pad, S, Spad, off, (const T*)w, rstd, H, rows, rpb, (const T*)add, ldadd,
                                    (T*)dx, lddx, dw_acc ? workspace : (float*)nullptr));
     if (dw_acc)
-        SF_LAUNCH(colsum_accum_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nb, H, dw_acc,
+        SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, nb, H, dw_acc,
                   dw_accumulate);
     return sf_check_launch("sf_rmsnorm_bwd");
 }

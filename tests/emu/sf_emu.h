@@ -60,7 +60,7 @@ struct Fiber {
     void* asan_fake = nullptr;
 };
 
-static constexpr size_t kStackBytes = 256 * 1024;
+static constexpr size_t kStackBytes = 64 * 1024;
 static constexpr int kSlotBytes = 128;  // per-lane exchange payload
 
 struct Wave {
