@@ -105,9 +105,9 @@ int sf_cast_from_f32(const float* in, long ldin, void* out, int dtype, long ldou
 
 /* ---- TTT attention (llama3_eagle.py:745-778; lse-merge blueprint 1024-1151) ----------------
  * q/o/dout/dq: [B*S, nh*hd] views; k0/v0 and the diagonal-branch kd[i]/vd[i]: [B*S, nkv*hd]
- * views; v0t/k0t: [B,nkv,hd,S]; qt/dot: [B,nh,hd,S]; lse/delta: [B,nh,S] fp32; kv_len: [B]
- * valid (right-padded) key count or NULL.  hd in {64,128}. */
-int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, const void* v0t, const void* const* kd,
+ * views (transposed operand fragments are taken from the same tiles with ds_read_b64_tr_b16);
+ * lse/delta: [B,nh,S] fp32; kv_len: [B] valid (right-padded) key count or NULL.  hd in {64,128}. */
+int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, const void* v0, const void* const* kd,
                 const void* const* vd, int ndiag, const int* kv_len, void* o, long ldo, float* lse, int B, int S,
                 int nh, int nkv, int hd, float scale, void* stream);
 int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo, const void* dout, long lddo,
@@ -115,11 +115,10 @@ int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo, const void
                     long lddk, int ndiag, const float* lse, float* delta, float* dq_init, int B, int S, int nh,
                     int nkv, int hd, float scale, void* stream);
 int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long lddo, const void* k0, long ldk, const void* v0,
-                   long ldv, const void* k0t, const int* kv_len, const float* lse, const float* delta,
+                   long ldv, const int* kv_len, const float* lse, const float* delta,
                    const float* dq_init, void* dq, long lddq, int B, int S, int nh, int nkv, int hd, float scale,
                    void* stream);
-int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long lddo, const void* qt, const void* dot,
-                    const void* k0, long ldk, const void* v0, long ldv, const int* kv_len, const float* lse,
+int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long lddo, const void* k0, long ldk, const void* v0, long ldv, const int* kv_len, const float* lse,
                     const float* delta, float* dk, float* dv, long lddk, int B, int S, int nh, int nkv, int hd,
                     float scale, void* stream);
 

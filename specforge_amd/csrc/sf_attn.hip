@@ -39,7 +39,7 @@ constexpr int kMaxDiag = 8;
 struct AttnFwdArgs {
     const sf_bf16* q; long ldq;        // [B*S, nh*hd] view, row stride ldq
     const sf_bf16* k0; long ldk;       // step-0 keys [B*S, nkv*hd] view
-    const sf_bf16* v0t;                // step-0 values transposed: [B, nkv, hd, S] contiguous
+    const sf_bf16* v0;                 // step-0 values [B*S, nkv*hd] view (row stride ldk)
     const sf_bf16* kd[kMaxDiag];       // diagonal-branch keys of steps 1..ndiag (views, stride ldk)
     const sf_bf16* vd[kMaxDiag];       // diagonal-branch values
     int ndiag;
@@ -69,38 +69,22 @@ SF_DEVICE void stage_rows64(char* lds, const sf_bf16* base, long ld, int row0, i
         sf_glds16(src, lds + (wave * NI + t) * 1024);  // uniform base; lane i lands at +16*i
     }
 }
-// transposed tile: HD rows (d) x 64 columns (keys / queries) from a [HD][S] matrix
-template <int HD, int NW>
-SF_DEVICE void stage_cols64(char* lds, const sf_bf16* base, int S, int col0, int wave, int lane) {
-    constexpr int NP = HD / 8;             // 8 rows of 128 B per 1 KiB piece
-    constexpr int NI = (NP + NW - 1) / NW;
-#pragma unroll
-    for (int t = 0; t < NI; ++t) {
-        if (NP % NW != 0 && wave * NI + t >= NP) break;  // wave-uniform
-        const int rr = (wave * NI + t) * 8 + (lane >> 3);
-        const int pc = lane & 7;
-        const int lc = pc ^ (rr & 7);
-        const int col = col0 + lc * 8;
-        const sf_bf16* src = (col < S) ? base + (long)rr * S + col : sf_zero16a;
-        sf_glds16(src, lds + (wave * NI + t) * 1024);
-    }
-}
 // Per-lane LDS byte offsets of the MFMA fragments, computed once per kernel so the tile loops issue
 // ds_reads with (register + immediate) addresses only.  Tile row blocks start at multiples of 32
 // rows, so (row & 7) == (lane & 7) for every fragment row.
 template <int HD>
 struct FragOff {
     int rows[HD / 16];  // natural tile, k-step ks: (lane&31)*rowbytes + swizzled chunk (2ks + hi)
-    int cols[4][2];     // transposed tile, 16-column group i: two 8-byte runs (chunks 2i, 2i+1) at +8*hi
+    int tr[HD / 32];    // transpose-read of a natural tile, 32-column block db: this lane's 8-byte piece
     SF_DEVICE void init(int lane) {
         const int c = lane & 31, hi = lane >> 5, x = lane & 7;
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) rows[ks] = c * (HD * 2) + (((2 * ks + hi) ^ x) << 4);
+        // ds_read_b64_tr_b16: 16-lane group (lane>>4) covers tile rows r0 + 4*hi + 0..3 and columns
+        // db*32 + 16*((lane>>4)&1) + 0..15; lane i of the group supplies piece i = (row i/4, cols 4*(i%4)..+3)
+        const int i = lane & 15, qx = 4 * hi + (i >> 2), t = 2 * ((lane >> 4) & 1) + ((i >> 1) & 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            cols[i][0] = c * 128 + (((2 * i) ^ x) << 4) + hi * 8;
-            cols[i][1] = c * 128 + (((2 * i + 1) ^ x) << 4) + hi * 8;
-        }
+        for (int db = 0; db < HD / 32; ++db) tr[db] = qx * (HD * 2) + ((((4 * db + t) ^ qx)) << 4) + (i & 1) * 8;
     }
 };
 // A fragment (32 rows x 16 k) from a natural tile: row = r0 + (lane&31), k = 16*ks + 8*(lane>>5)
@@ -108,12 +92,14 @@ template <int HD>
 SF_DEVICE sf_v8s frag_rows(const char* lds, int r0, int ks, const FragOff<HD>& fo) {
     return *reinterpret_cast<const sf_v8s*>(lds + r0 * (HD * 2) + fo.rows[ks]);
 }
-// A fragment from a transposed tile for the "C-layout as B operand" contraction: row d = d0+(lane&31),
-// k-slots = columns {c0 + 4*hi + 0..3} and {c0 + 8 + 4*hi + 0..3}  (c0 multiple of 16)
+// A fragment for the "C-layout as B operand" contraction, taken from a NATURAL tile X[row][d] with the
+// hardware transpose read: MFMA row = column d = db*32 + (lane&31) of the tile, k-slots = tile rows
+// {r0 + 4*hi + 0..3} and {r0 + 8 + 4*hi + 0..3}  (r0 multiple of 16)
 template <int HD>
-SF_DEVICE sf_v8s frag_cols(const char* lds, int d0, int c0, const FragOff<HD>& fo) {
-    const sf_v4s lo = *reinterpret_cast<const sf_v4s*>(lds + d0 * 128 + fo.cols[c0 >> 4][0]);
-    const sf_v4s up = *reinterpret_cast<const sf_v4s*>(lds + d0 * 128 + fo.cols[c0 >> 4][1]);
+SF_DEVICE sf_v8s frag_tr(const char* lds, int db, int r0, const FragOff<HD>& fo) {
+    const char* base = lds + r0 * (HD * 2) + fo.tr[db];
+    const sf_v4s lo = sf_ds_read_tr16(base);
+    const sf_v4s up = sf_ds_read_tr16(base + 8 * (HD * 2));
     return sf_v8s{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
 }
 SF_DEVICE sf_v8s pack_bf16x8(const sf_v16f& p, int r0) {
@@ -136,7 +122,7 @@ SF_DEVICE float dot8(sf_v8s a, sf_v8s b) {
 template <int HD, int NW>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
     constexpr int KS = HD / 16, DB = HD / 32, QB = NW * 32, TILE = 128 * HD * 2;
-    SF_DYN_SMEM(smem);  // 2 x { K [64][HD], V^T [HD][64] }
+    SF_DYN_SMEM(smem);  // 2 x { K [64][HD], V [64][HD] }
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
     const int qb0 = (int)blockIdx.x * QB, h = (int)blockIdx.y, b = (int)blockIdx.z;
     const int g = h / (p.nh / p.nkv);
@@ -163,13 +149,13 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
     float m = kNegBig, lpart = 0.f;
 
     const sf_bf16* kbase = p.k0 + (long)b * S * p.ldk + g * HD;
-    const sf_bf16* vtbase = p.v0t + ((long)b * p.nkv + g) * HD * S;
+    const sf_bf16* vbase = p.v0 + (long)b * S * p.ldk + g * HD;
     int kend = qb0 + QB < S ? qb0 + QB : S;  // causal upper bound for this block
     if (kvlen < kend) kend = kvlen;
     const int ntiles = (kend + 63) / 64;
     if (ntiles > 0) {
         stage_rows64<HD, NW>(smem, kbase, p.ldk, 0, S, wave, lane);
-        stage_cols64<HD, NW>(smem + 64 * HD * 2, vtbase, S, 0, wave, lane);
+        stage_rows64<HD, NW>(smem + 64 * HD * 2, vbase, p.ldk, 0, S, wave, lane);
     }
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 64;
@@ -178,10 +164,10 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
         if (kt + 1 < ntiles && !(p.dbg & 1)) {
             char* nb = smem + ((kt + 1) & 1) * TILE;
             stage_rows64<HD, NW>(nb, kbase, p.ldk, key0 + 64, S, wave, lane);
-            stage_cols64<HD, NW>(nb + 64 * HD * 2, vtbase, S, key0 + 64, wave, lane);
+            stage_rows64<HD, NW>(nb + 64 * HD * 2, vbase, p.ldk, key0 + 64, S, wave, lane);
         }
         const char* lds_k = smem + (kt & 1) * TILE;
-        const char* lds_vt = lds_k + 64 * HD * 2;
+        const char* lds_v = lds_k + 64 * HD * 2;
         if (key0 > qw0 + 31) continue;  // whole tile above this wave's diagonal (wave-uniform)
         if (p.dbg & 2) continue;
         const bool need_mask = (key0 + 63 > qw0) || (key0 + 63 >= kvlen);
@@ -236,7 +222,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
                 const sf_v8s pf = pack_bf16x8(s[kb], 8 * jp);
 #pragma unroll
                 for (int d = 0; d < DB; ++d)
-                    acc_o[d] = sf_mfma32(frag_cols<HD>(lds_vt, d * 32, kb * 32 + 16 * jp, fo), pf, acc_o[d]);
+                    acc_o[d] = sf_mfma32(frag_tr<HD>(lds_v, d, kb * 32 + 16 * jp, fo), pf, acc_o[d]);
             }
     }
     float l = lpart + sf_shfl_xor(lpart, 32);
@@ -377,11 +363,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_pre_kernel(AttnBwdPreArgs p) {
 struct AttnBwdArgs {
     const sf_bf16* q; long ldq;      // natural
     const sf_bf16* dout; long lddo;  // natural
-    const sf_bf16* qt;               // [B, nh, hd, S]   (dkv kernel)
-    const sf_bf16* dot;              // [B, nh, hd, S]   (dkv kernel)
     const sf_bf16* k0; long ldk;     // natural
     const sf_bf16* v0; long ldv;     // natural
-    const sf_bf16* k0t;              // [B, nkv, hd, S]  (dq kernel)
     const int* kv_len;
     const float* lse;                // [B, nh, S]
     const float* delta;              // [B, nh, S]
@@ -394,8 +377,8 @@ struct AttnBwdArgs {
 
 template <int HD, int NW>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
-    constexpr int KS = HD / 16, DB = HD / 32, QB = NW * 32, TILE = 192 * HD * 2;
-    SF_DYN_SMEM(smem);  // 2 x { K [64][HD], V [64][HD], K^T [HD][64] }
+    constexpr int KS = HD / 16, DB = HD / 32, QB = NW * 32, TILE = 128 * HD * 2;
+    SF_DYN_SMEM(smem);  // 2 x { K [64][HD], V [64][HD] }; K serves both S^T = K.Q^T and (transpose-read) dQ^T += K^T.dS^T
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
     const int qb0 = (int)blockIdx.x * QB, h = (int)blockIdx.y, b = (int)blockIdx.z;
     const int g = h / (p.nh / p.nkv);
@@ -426,14 +409,12 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
 
     const sf_bf16* kbase = p.k0 + (long)b * S * p.ldk + g * HD;
     const sf_bf16* vbase = p.v0 + (long)b * S * p.ldv + g * HD;
-    const sf_bf16* ktbase = p.k0t + ((long)b * p.nkv + g) * HD * S;
     int kend = qb0 + QB < S ? qb0 + QB : S;
     if (kvlen < kend) kend = kvlen;
     const int ntiles = (kend + 63) / 64;
     auto stage = [&](char* dst, int key0) {
         stage_rows64<HD, NW>(dst, kbase, p.ldk, key0, S, wave, lane);
         stage_rows64<HD, NW>(dst + 64 * HD * 2, vbase, p.ldv, key0, S, wave, lane);
-        stage_cols64<HD, NW>(dst + 128 * HD * 2, ktbase, S, key0, wave, lane);
     };
     if (ntiles > 0) stage(smem, 0);
     for (int kt = 0; kt < ntiles; ++kt) {
@@ -443,7 +424,6 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         if (kt + 1 < ntiles) stage(smem + ((kt + 1) & 1) * TILE, key0 + 64);
         const char* lds_k = smem + (kt & 1) * TILE;
         const char* lds_v = lds_k + 64 * HD * 2;
-        const char* lds_kt = lds_k + 128 * HD * 2;
         if (key0 > qw0 + 31) continue;
         sf_v16f s[2], dp[2];
 #pragma unroll
@@ -456,13 +436,16 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
                 dp[kb] = sf_mfma32(frag_rows<HD>(lds_v, kb * 32, ks, fo), dof[ks], dp[kb]);
             }
         }
+        const bool need_mask = (key0 + 63 > qw0) || (key0 + 63 >= kvlen);  // wave-uniform
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kk = key0 + kb * 32 + crow(r, hi);
-                const bool ok = (kk <= qi) && (kk < kvlen);
-                const float pv = ok ? sf_exp2_raw(fmaf(s[kb][r], sc, -lse2)) : 0.f;
+                float pv = sf_exp2_raw(fmaf(s[kb][r], sc, -lse2));
+                if (need_mask) {
+                    const int kk = key0 + kb * 32 + crow(r, hi);
+                    if (kk > qi || kk >= kvlen) pv = 0.f;
+                }
                 s[kb][r] = pv * (dp[kb][r] - dlt);  // dS^T
             }
 #pragma unroll
@@ -472,7 +455,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
                 const sf_v8s df = pack_bf16x8(s[kb], 8 * jp);
 #pragma unroll
                 for (int d = 0; d < DB; ++d)
-                    acc[d] = sf_mfma32(frag_cols<HD>(lds_kt, d * 32, kb * 32 + 16 * jp, fo), df, acc[d]);
+                    acc[d] = sf_mfma32(frag_tr<HD>(lds_k, d, kb * 32 + 16 * jp, fo), df, acc[d]);
             }
     }
     if (!qok) return;
@@ -499,10 +482,11 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
 // waves [NW/2, NW) accumulate dK^T of the same keys (each recomputes S; a wave then carries ONE
 // 64-register accumulator set, so the kernel fits 2 waves/SIMD without spilling and the two roles
 // of a key sub-block sit on the same SIMD and overlap exp/LDS work with MFMA).
-// LDS (double buffered): Q [64][HD], dO [64][HD], Q^T [HD][64], dO^T [HD][64], lse2[64], delta[64]
+// LDS (double buffered): Q [64][HD], dO [64][HD], lse2[64], delta[64]; Q^T / dO^T fragments come from the
+// same tiles through the hardware transpose read
 template <int HD, int NW>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dkv_kernel(AttnBwdArgs p) {
-    constexpr int KS = HD / 16, DB = HD / 32, NSUB = NW / 2, KB = NSUB * 32, TILE = 256 * HD * 2 + 512;
+    constexpr int KS = HD / 16, DB = HD / 32, NSUB = NW / 2, KB = NSUB * 32, TILE = 128 * HD * 2 + 512;
     SF_DYN_SMEM(smem);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
     const int role = wave / NSUB;  // 0: dV, 1: dK   (wave-uniform)
@@ -540,17 +524,13 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dkv_kernel(AttnBwdArgs p) {
             const int h = g * nrep + hh;
             const sf_bf16* qbase = p.q + (long)b * S * p.ldq + h * HD;
             const sf_bf16* dobase = p.dout + (long)b * S * p.lddo + h * HD;
-            const sf_bf16* qtbase = p.qt + ((long)b * p.nh + h) * HD * S;
-            const sf_bf16* dotbase = p.dot + ((long)b * p.nh + h) * HD * S;
             const float* lsebase = p.lse + ((long)b * p.nh + h) * S;
             const float* dltbase = p.delta + ((long)b * p.nh + h) * S;
             auto stage = [&](char* dst, int q0) {
                 stage_rows64<HD, NW>(dst, qbase, p.ldq, q0, S, wave, lane);
                 stage_rows64<HD, NW>(dst + 64 * HD * 2, dobase, p.lddo, q0, S, wave, lane);
-                stage_cols64<HD, NW>(dst + 128 * HD * 2, qtbase, S, q0, wave, lane);
-                stage_cols64<HD, NW>(dst + 192 * HD * 2, dotbase, S, q0, wave, lane);
                 if (tid < 64) {
-                    float* sl = reinterpret_cast<float*>(dst + 256 * HD * 2);
+                    float* sl = reinterpret_cast<float*>(dst + 128 * HD * 2);
                     const int qq = q0 + tid;
                     sl[tid] = qq < S ? lsebase[qq] * kLog2e : 0.f;
                     sl[64 + tid] = qq < S ? dltbase[qq] : 0.f;
@@ -565,8 +545,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dkv_kernel(AttnBwdArgs p) {
                 if (qt + 1 < nqt) stage(smem + ((it + 1) & 1) * TILE, q0 + 64);
                 const char* lds_q = smem + (it & 1) * TILE;
                 const char* lds_do = lds_q + 64 * HD * 2;
-                const char* lds_xt = lds_q + (role == 0 ? 192 : 128) * HD * 2;  // dO^T for dV, Q^T for dK
-                const float* lds_lse = reinterpret_cast<const float*>(lds_q + 256 * HD * 2);
+                const char* lds_x = role == 0 ? lds_do : lds_q;  // dV^T += dO^T.P   |   dK^T += Q^T.dS
+                const float* lds_lse = reinterpret_cast<const float*>(lds_q + 128 * HD * 2);
                 const float* lds_dlt = lds_lse + 64;
                 if (q0 + 63 < kw0) continue;  // every query of the tile is before this wave's keys
 #pragma unroll
@@ -580,20 +560,31 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dkv_kernel(AttnBwdArgs p) {
 #pragma unroll
                         for (int ks = 0; ks < KS; ++ks) dp = sf_mfma32(frag_rows<HD>(lds_do, qb * 32, ks, fo), vf[ks], dp);
                     }
+                    // rows crow(4j..4j+3) are consecutive: one 16-byte LDS read per 4 rows
+                    const bool need_mask = (q0 + qb * 32 < kw0 + 32) || (kw0 + 31 >= kvlen) || (q0 + 63 >= S);  // wave-uniform
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ql = qb * 32 + crow(r, hi);
-                        const int qq = q0 + ql;
-                        const bool ok = (ki <= qq) && (ki < kvlen) && (qq < S);
-                        const float pv = ok ? sf_exp2_raw(fmaf(s[r], sc, -lds_lse[ql])) : 0.f;
-                        s[r] = role == 0 ? pv : pv * (dp[r] - lds_dlt[ql]);  // P (dV waves) | dS (dK waves)
+                    for (int j = 0; j < 4; ++j) {
+                        const int ql0 = qb * 32 + 8 * j + 4 * hi;
+                        const sf_v4f l4 = *reinterpret_cast<const sf_v4f*>(lds_lse + ql0);
+                        sf_v4f d4 = l4;
+                        if (role == 1) d4 = *reinterpret_cast<const sf_v4f*>(lds_dlt + ql0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int r = 4 * j + t;
+                            float pv = sf_exp2_raw(fmaf(s[r], sc, -l4[t]));
+                            if (need_mask) {
+                                const int qq = q0 + ql0 + t;
+                                if (ki > qq || ki >= kvlen || qq >= S) pv = 0.f;
+                            }
+                            s[r] = role == 0 ? pv : pv * (dp[r] - d4[t]);  // P (dV waves) | dS (dK waves)
+                        }
                     }
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) {
                         const sf_v8s f = pack_bf16x8(s, 8 * jp);
 #pragma unroll
                         for (int d = 0; d < DB; ++d)
-                            acc[d] = sf_mfma32(frag_cols<HD>(lds_xt, d * 32, qb * 32 + 16 * jp, fo), f, acc[d]);
+                            acc[d] = sf_mfma32(frag_tr<HD>(lds_x, d, qb * 32 + 16 * jp, fo), f, acc[d]);
                     }
                 }
             }
@@ -639,7 +630,7 @@ constexpr int kAttnWaves = 8;  // waves per workgroup of the three MFMA attentio
     } while (0)
 #endif
 
-extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, const void* v0t, const void* const* kd,
+extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, const void* v0, const void* const* kd,
                            const void* const* vd, int ndiag, const int* kv_len, void* o, long ldo, float* lse, int B,
                            int S, int nh, int nkv, int hd, float scale, void* stream) {
     SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_fwd: bad shape");
@@ -649,7 +640,7 @@ extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, co
     memset(&p, 0, sizeof(p));
     p.q = (const sf_bf16*)q; p.ldq = ldq;
     p.k0 = (const sf_bf16*)k0; p.ldk = ldk;
-    p.v0t = (const sf_bf16*)v0t;
+    p.v0 = (const sf_bf16*)v0;
     for (int i = 0; i < ndiag; ++i) { p.kd[i] = (const sf_bf16*)kd[i]; p.vd[i] = (const sf_bf16*)vd[i]; }
     p.ndiag = ndiag; p.kv_len = kv_len;
     p.o = (sf_bf16*)o; p.ldo = ldo; p.lse = lse;
@@ -685,17 +676,15 @@ extern "C" int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo,
     return sf_check_launch("sf_attn_bwd_pre");
 }
 
-static int fill_bwd_args(AttnBwdArgs& p, const void* q, long ldq, const void* dout, long lddo, const void* qt,
-                         const void* dot, const void* k0, long ldk, const void* v0, long ldv, const void* k0t,
+static int fill_bwd_args(AttnBwdArgs& p, const void* q, long ldq, const void* dout, long lddo,
+                         const void* k0, long ldk, const void* v0, long ldv,
                          const int* kv_len, const float* lse, const float* delta, const float* dq_init, void* dq,
                          long lddq, float* dk, float* dv, long lddk, int B, int S, int nh, int nkv, float scale) {
     memset(&p, 0, sizeof(p));
     p.q = (const sf_bf16*)q; p.ldq = ldq;
     p.dout = (const sf_bf16*)dout; p.lddo = lddo;
-    p.qt = (const sf_bf16*)qt; p.dot = (const sf_bf16*)dot;
     p.k0 = (const sf_bf16*)k0; p.ldk = ldk;
     p.v0 = (const sf_bf16*)v0; p.ldv = ldv;
-    p.k0t = (const sf_bf16*)k0t;
     p.kv_len = kv_len; p.lse = lse; p.delta = delta; p.dq_init = dq_init;
     p.dq = (sf_bf16*)dq; p.lddq = lddq;
     p.dk = dk; p.dv = dv; p.lddk = lddk;
@@ -704,23 +693,23 @@ static int fill_bwd_args(AttnBwdArgs& p, const void* q, long ldq, const void* do
 }
 
 extern "C" int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long lddo, const void* k0, long ldk,
-                              const void* v0, long ldv, const void* k0t, const int* kv_len, const float* lse,
+                              const void* v0, long ldv, const int* kv_len, const float* lse,
                               const float* delta, const float* dq_init, void* dq, long lddq, int B, int S, int nh,
                               int nkv, int hd, float scale, void* stream) {
     SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_dq: bad shape");
     SF_CHECK_ARG(S % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0,
                  "sf_attn_bwd_dq: S and strides must be multiples of 8");
     AttnBwdArgs p;
-    fill_bwd_args(p, q, ldq, dout, lddo, nullptr, nullptr, k0, ldk, v0, ldv, k0t, kv_len, lse, delta, dq_init, dq, lddq,
+    fill_bwd_args(p, q, ldq, dout, lddo, k0, ldk, v0, ldv, kv_len, lse, delta, dq_init, dq, lddq,
                   nullptr, nullptr, 0, B, S, nh, nkv, scale);
     constexpr int NW = kAttnWaves;
     dim3 grid((S + NW * 32 - 1) / (NW * 32), nh, B);
-    SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dq_kernel<HD, NW>), 2 * 192 * HD * 2);
-                   SF_LAUNCH((attn_bwd_dq_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 192 * HD * 2, stream, p));
+    SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dq_kernel<HD, NW>), 2 * 128 * HD * 2);
+                   SF_LAUNCH((attn_bwd_dq_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
     return sf_check_launch("sf_attn_bwd_dq");
 }
 
-extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long lddo, const void* qt, const void* dot,
+extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long lddo,
                                const void* k0, long ldk, const void* v0, long ldv, const int* kv_len, const float* lse,
                                const float* delta, float* dk, float* dv, long lddk, int B, int S, int nh, int nkv,
                                int hd, float scale, void* stream) {
@@ -728,11 +717,11 @@ extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long l
     SF_CHECK_ARG(S % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddk % 4 == 0,
                  "sf_attn_bwd_dkv: S and strides must be multiples of 8");
     AttnBwdArgs p;
-    fill_bwd_args(p, q, ldq, dout, lddo, qt, dot, k0, ldk, v0, ldv, nullptr, kv_len, lse, delta, nullptr, nullptr, 0, dk,
+    fill_bwd_args(p, q, ldq, dout, lddo, k0, ldk, v0, ldv, kv_len, lse, delta, nullptr, nullptr, 0, dk,
                   dv, lddk, B, S, nh, nkv, scale);
     constexpr int NW = kAttnWaves;
     dim3 grid((S + NW * 16 - 1) / (NW * 16), nkv, B);  // NW/2 key sub-blocks of 32 keys per workgroup
-    SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, NW>), 2 * (256 * HD * 2 + 512));
-                   SF_LAUNCH((attn_bwd_dkv_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (256 * HD * 2 + 512), stream, p));
+    SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, NW>), 2 * (128 * HD * 2 + 512));
+                   SF_LAUNCH((attn_bwd_dkv_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (128 * HD * 2 + 512), stream, p));
     return sf_check_launch("sf_attn_bwd_dkv");
 }

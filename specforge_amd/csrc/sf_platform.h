@@ -42,6 +42,7 @@ SF_DEVICE sf_v4f sf_mfma16(sf_v8s a, sf_v8s b, sf_v4f c) { return sfemu::mfma_16
 SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) { return sfemu::mfma_32x32x16_bf16(a, b, c); }
 SF_DEVICE void sf_glds16(const void* g, void* l) { sfemu::global_load_lds16(g, l); }
 SF_DEVICE int sf_wave_id() { return sfemu::wave_index(); }
+SF_DEVICE sf_v4s sf_ds_read_tr16(const void* l) { return sfemu::ds_read_tr16_b64(l); }
 SF_DEVICE bool sf_all(bool pred) {
     int v = pred ? 1 : 0;
     for (int m = 32; m >= 1; m >>= 1) v &= sfemu::shfl_xor(v, m);
@@ -91,6 +92,12 @@ SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) {
 // pointers was lowered to two exec-masked loads.
 SF_DEVICE int sf_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 SF_DEVICE bool sf_all(bool pred) { return __all(pred ? 1 : 0) != 0; }
+// ds_read_b64_tr_b16: per 16-lane group, lane i passes the address of 8-byte piece i of a 4x16 bf16 block
+// (piece i = row i/4, columns 4*(i%4)..+3; any row stride) and receives column i (rows 0..3).  Verified on
+// MI355X by tools/probes/tr_probe.hip.
+SF_DEVICE sf_v4s sf_ds_read_tr16(const void* l) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sf_v4s*)l);
+}
 SF_DEVICE void sf_glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);

@@ -104,8 +104,6 @@ class Eagle3Engine:
         for nm in ("rstd_e", "rstd_h", "rstd_p", "rstd_n"):
             b[nm] = [self._e(N, dtype=f32) for _ in range(T)]
         b["rstd_fc"] = [self._e(N, dtype=f32) for _ in range(3)]
-        b["v0t"] = self._e(B, nkv, hd, S)
-        b["k0t"] = self._e(B, nkv, hd, S)
         # transient per-step work buffers
         b["xcat"] = self._e(N, 2 * H)
         b["pn"] = self._e(N, H)
@@ -133,8 +131,6 @@ class Eagle3Engine:
         b["dhs"] = self._e(N, Ht3) if c.fc_norm else None
         b["delta"] = self._e(B, nh, S, dtype=f32)
         b["dq_init"] = self._e(N, nh * hd, dtype=f32)
-        b["qt"] = self._e(B, nh, hd, S)
-        b["dot"] = self._e(B, nh, hd, S)
         b["dk"] = [self._e(N, nkv * hd, dtype=f32) for _ in range(T)]
         b["dv"] = [self._e(N, nkv * hd, dtype=f32) for _ in range(T)]
         b["nws"] = self._e(ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)
@@ -247,10 +243,7 @@ class Eagle3Engine:
             ops.rmsnorm_fwd(b["h"][k], f.view("midlayer.hidden_norm.weight"), eps, xcat[:, H:], b["rstd_h"][k])
             ops.gemm_nt(xcat, self.w_qkv, qkv)
             ops.rope_(qkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k)
-            if k == 0:
-                ops.transpose_heads(qkv[:, vcol], b["v0t"], B, S, nkv, hd)
-                ops.transpose_heads(qkv[:, kcol], b["k0t"], B, S, nkv, hd)
-            ops.attn_fwd(qkv[:, :nh * hd], b["qkv"][0][:, kcol], b["v0t"], [b["qkv"][i][:, kcol] for i in range(1, k + 1)],
+            ops.attn_fwd(qkv[:, :nh * hd], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], [b["qkv"][i][:, kcol] for i in range(1, k + 1)],
                          [b["qkv"][i][:, vcol] for i in range(1, k + 1)], b["kvlen"], b["o"][k], b["lse"][k],
                          B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
             ops.gemm_nt(b["o"][k], f.view("midlayer.self_attn.o_proj.weight"), b["h1"][k], residual=b["h"][k])
@@ -349,12 +342,10 @@ class Eagle3Engine:
             vd = [b["qkv"][i][:, vcol] for i in range(1, k + 1)]
             ops.attn_bwd_pre(q, b["o"][k], b["do"], kd, vd, b["dk"][1:k + 1], b["dv"][1:k + 1], b["lse"][k], b["delta"],
                              b["dq_init"] if k > 0 else None, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
-            ops.attn_bwd_dq(q, b["do"], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], b["k0t"], b["kvlen"], b["lse"][k],
+            ops.attn_bwd_dq(q, b["do"], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], b["kvlen"], b["lse"][k],
                             b["delta"], b["dq_init"] if k > 0 else None, dqkv[:, :nh * hd], B=B, S=S, nh=nh, nkv=nkv,
                             hd=hd, scale=scale)
-            ops.transpose_heads(q, b["qt"], B, S, nh, hd)
-            ops.transpose_heads(b["do"], b["dot"], B, S, nh, hd)
-            ops.attn_bwd_dkv(q, b["do"], b["qt"], b["dot"], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], b["kvlen"],
+            ops.attn_bwd_dkv(q, b["do"], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], b["kvlen"],
                              b["lse"][k], b["delta"], b["dk"][0], b["dv"][0], B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
             # K_k / V_k have now received every contribution (steps k..T-1)
             ops.cast_from_f32(b["dk"][k], dqkv[:, kcol])

@@ -183,12 +183,12 @@ def _ptr_array(ts: Sequence[torch.Tensor]):
     return arr
 
 
-def attn_fwd(q, k0, v0t, kd: List[torch.Tensor], vd: List[torch.Tensor], kv_len, o, lse, *, B, S, nh, nkv, hd, scale):
+def attn_fwd(q, k0, v0, kd: List[torch.Tensor], vd: List[torch.Tensor], kv_len, o, lse, *, B, S, nh, nkv, hd, scale):
     L = _lib.lib()
     ldk = _rowmajor(k0)
-    for t in list(kd) + list(vd):
+    for t in [v0] + list(kd) + list(vd):
         assert _rowmajor(t) == ldk
-    _lib.check(L.sf_attn_fwd(_p(q), _rowmajor(q), _p(k0), ldk, _p(v0t), _ptr_array(kd), _ptr_array(vd), len(kd),
+    _lib.check(L.sf_attn_fwd(_p(q), _rowmajor(q), _p(k0), ldk, _p(v0), _ptr_array(kd), _ptr_array(vd), len(kd),
                              _p(kv_len), _p(o), _rowmajor(o), _p(lse), B, S, nh, nkv, hd, scale, _stream()), "sf_attn_fwd")
 
 
@@ -201,17 +201,17 @@ def attn_bwd_pre(q, o, dout, kd, vd, dkd, dvd, lse, delta, dq_init, *, B, S, nh,
                                  _p(dq_init), B, S, nh, nkv, hd, scale, _stream()), "sf_attn_bwd_pre")
 
 
-def attn_bwd_dq(q, dout, k0, v0, k0t, kv_len, lse, delta, dq_init, dq, *, B, S, nh, nkv, hd, scale):
+def attn_bwd_dq(q, dout, k0, v0, kv_len, lse, delta, dq_init, dq, *, B, S, nh, nkv, hd, scale):
     L = _lib.lib()
     _lib.check(L.sf_attn_bwd_dq(_p(q), _rowmajor(q), _p(dout), _rowmajor(dout), _p(k0), _rowmajor(k0), _p(v0),
-                                _rowmajor(v0), _p(k0t), _p(kv_len), _p(lse), _p(delta), _p(dq_init), _p(dq),
+                                _rowmajor(v0), _p(kv_len), _p(lse), _p(delta), _p(dq_init), _p(dq),
                                 _rowmajor(dq), B, S, nh, nkv, hd, scale, _stream()), "sf_attn_bwd_dq")
 
 
-def attn_bwd_dkv(q, dout, qt, dot, k0, v0, kv_len, lse, delta, dk, dv, *, B, S, nh, nkv, hd, scale):
+def attn_bwd_dkv(q, dout, k0, v0, kv_len, lse, delta, dk, dv, *, B, S, nh, nkv, hd, scale):
     L = _lib.lib()
     assert dk.dtype == torch.float32 and dv.dtype == torch.float32 and _rowmajor(dk) == _rowmajor(dv)
-    _lib.check(L.sf_attn_bwd_dkv(_p(q), _rowmajor(q), _p(dout), _rowmajor(dout), _p(qt), _p(dot), _p(k0), _rowmajor(k0),
+    _lib.check(L.sf_attn_bwd_dkv(_p(q), _rowmajor(q), _p(dout), _rowmajor(dout), _p(k0), _rowmajor(k0),
                                  _p(v0), _rowmajor(v0), _p(kv_len), _p(lse), _p(delta), _p(dk), _p(dv), _rowmajor(dk),
                                  B, S, nh, nkv, hd, scale, _stream()), "sf_attn_bwd_dkv")
 

@@ -364,6 +364,22 @@ inline void global_load_lds16(const void* gsrc, void* lds_base) {
     memcpy((char*)lds_base + 16 * lane_id(), gsrc, 16);
 }
 
+// ds_read_b64_tr_b16 (transpose read): see sf_platform.h::sf_ds_read_tr16
+typedef short v4s __attribute__((ext_vector_type(4)));
+inline v4s ds_read_tr16_b64(const void* lds_ptr) {
+    v4s mine;
+    memcpy(&mine, lds_ptr, 8);
+    SlotRow* s = wave_exchange(&mine, 8);
+    const int l = lane_id(), g = l >> 4, i = l & 15;
+    v4s r;
+    for (int j = 0; j < 4; ++j) {
+        v4s o;
+        memcpy(&o, s[16 * g + 4 * j + (i >> 2)], 8);
+        r[j] = o[i & 3];
+    }
+    return r;
+}
+
 template <typename T>
 inline T atomic_add(T* p, T v) {
     if constexpr (std::is_floating_point<T>::value) {

@@ -63,13 +63,9 @@ def test_ttt_attention_fwd_bwd(backend, hd, B, S, nh, nkv, lengths, nsteps):
     kview = [t[:, nh * hd:(nh + nkv) * hd] for t in qkv]
     vview = [t[:, (nh + nkv) * hd:] for t in qkv]
     kv_len = d(torch.tensor(lengths, dtype=torch.int32))
-    v0t = torch.empty(B, nkv, hd, S, dtype=torch.bfloat16, device=backend)
-    k0t = torch.empty_like(v0t)
-    ops.transpose_heads(vview[0], v0t, B, S, nkv, hd)
-    ops.transpose_heads(kview[0], k0t, B, S, nkv, hd)
     o = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=backend)
     lse = torch.empty(B, nh, S, device=backend)
-    ops.attn_fwd(qv, kview[0], v0t, kview[1:], vview[1:], kv_len, o, lse, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+    ops.attn_fwd(qv, kview[0], vview[0], kview[1:], vview[1:], kv_len, o, lse, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
     torch.testing.assert_close(o.float().cpu(), o_ref, rtol=2e-2, atol=2e-2)
 
     # backward
@@ -81,13 +77,9 @@ def test_ttt_attention_fwd_bwd(backend, hd, B, S, nh, nkv, lengths, nsteps):
     ops.attn_bwd_pre(qv, o, dout, kview[1:], vview[1:], dk_acc[1:], dv_acc[1:], lse, delta, dq_init, B=B, S=S, nh=nh,
                      nkv=nkv, hd=hd, scale=scale)
     dq = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=backend)
-    ops.attn_bwd_dq(qv, dout, kview[0], vview[0], k0t, kv_len, lse, delta, dq_init, dq, B=B, S=S, nh=nh, nkv=nkv, hd=hd,
+    ops.attn_bwd_dq(qv, dout, kview[0], vview[0], kv_len, lse, delta, dq_init, dq, B=B, S=S, nh=nh, nkv=nkv, hd=hd,
                     scale=scale)
-    qt = torch.empty(B, nh, hd, S, dtype=torch.bfloat16, device=backend)
-    dot = torch.empty_like(qt)
-    ops.transpose_heads(qv, qt, B, S, nh, hd)
-    ops.transpose_heads(dout, dot, B, S, nh, hd)
-    ops.attn_bwd_dkv(qv, dout, qt, dot, kview[0], vview[0], kv_len, lse, delta, dk_acc[0], dv_acc[0], B=B, S=S, nh=nh,
+    ops.attn_bwd_dkv(qv, dout, kview[0], vview[0], kv_len, lse, delta, dk_acc[0], dv_acc[0], B=B, S=S, nh=nh,
                      nkv=nkv, hd=hd, scale=scale)
 
     def close(got, ref, what):
@@ -105,6 +97,6 @@ def test_ttt_attention_fwd_bwd(backend, hd, B, S, nh, nkv, lengths, nsteps):
         assert float(dv_acc[0].view(B, S, -1)[b, L:].abs().max() if L < S else 0.0) == 0.0
     # accumulation semantics: a second backward call adds into the fp32 buffers
     before = dk_acc[0].clone()
-    ops.attn_bwd_dkv(qv, dout, qt, dot, kview[0], vview[0], kv_len, lse, delta, dk_acc[0], dv_acc[0], B=B, S=S, nh=nh,
+    ops.attn_bwd_dkv(qv, dout, kview[0], vview[0], kv_len, lse, delta, dk_acc[0], dv_acc[0], B=B, S=S, nh=nh,
                      nkv=nkv, hd=hd, scale=scale)
     torch.testing.assert_close(dk_acc[0].cpu(), 2 * before.cpu(), rtol=1e-5, atol=1e-6)

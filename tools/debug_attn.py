@@ -22,26 +22,18 @@ def run(hd, B, S, nh, nkv, lengths, nsteps):
     kview = [t[:, nh * hd:(nh + nkv) * hd] for t in qkv]
     vview = [t[:, (nh + nkv) * hd:] for t in qkv]
     kv_len = d(torch.tensor(lengths, dtype=torch.int32))
-    v0t = torch.empty(B, nkv, hd, S, dtype=torch.bfloat16, device=backend)
-    k0t = torch.empty_like(v0t)
-    ops.transpose_heads(vview[0], v0t, B, S, nkv, hd)
-    ops.transpose_heads(kview[0], k0t, B, S, nkv, hd)
     o = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=backend)
     lse = torch.empty(B, nh, S, device=backend)
-    ops.attn_fwd(qv, kview[0], v0t, kview[1:], vview[1:], kv_len, o, lse, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+    ops.attn_fwd(qv, kview[0], vview[0], kview[1:], vview[1:], kv_len, o, lse, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
     dout = d(do.view(N, -1))
     delta = torch.empty(B, nh, S, device=backend)
     dq_init = torch.zeros(N, nh * hd, device=backend) if nsteps > 1 else None
     dk_acc = [torch.zeros(N, nkv * hd, device=backend) for _ in range(nsteps)]
     dv_acc = [torch.zeros(N, nkv * hd, device=backend) for _ in range(nsteps)]
     ops.attn_bwd_pre(qv, o, dout, kview[1:], vview[1:], dk_acc[1:], dv_acc[1:], lse, delta, dq_init, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
-    qt = torch.empty(B, nh, hd, S, dtype=torch.bfloat16, device=backend)
-    dot = torch.empty_like(qt)
-    ops.transpose_heads(qv, qt, B, S, nh, hd)
-    ops.transpose_heads(dout, dot, B, S, nh, hd)
     for rep in range(3):
         dk_acc[0].zero_(); dv_acc[0].zero_()
-        ops.attn_bwd_dkv(qv, dout, qt, dot, kview[0], vview[0], kv_len, lse, delta, dk_acc[0], dv_acc[0], B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+        ops.attn_bwd_dkv(qv, dout, kview[0], vview[0], kv_len, lse, delta, dk_acc[0], dv_acc[0], B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
         torch.cuda.synchronize()
         for name, got, ref in (("dk0", dk_acc[0], dk_ref[0]), ("dv0", dv_acc[0], dv_ref[0])):
             g = got.float().cpu()
@@ -59,7 +51,7 @@ def run(hd, B, S, nh, nkv, lengths, nsteps):
                 idx = big.nonzero()
                 msg += f" bigerr_rows={sorted(set(idx[:,0].tolist()))[:20]} cols={sorted(set(idx[:,1].tolist()))[:16]}"
             print(msg, flush=True)
-    print("finite lse", bool(torch.isfinite(lse).all()), "delta", bool(torch.isfinite(delta).all()), "qt", bool(torch.isfinite(qt.float()).all()), "dot", bool(torch.isfinite(dot.float()).all()))
+    print("finite lse", bool(torch.isfinite(lse).all()), "delta", bool(torch.isfinite(delta).all()))
 
 for hd in (64, 128):
     run(hd, 2, 48, 4, 2, [48, 23], 1)

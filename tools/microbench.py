@@ -49,14 +49,10 @@ def bench_attn(B, S, nh, nkv, hd, ndiag):
     q = qkv[-1][:, :nh * hd]
     kv = [t[:, nh * hd:(nh + nkv) * hd] for t in qkv]
     vv = [t[:, (nh + nkv) * hd:] for t in qkv]
-    v0t = torch.empty(B, nkv, hd, S, device=dev, dtype=torch.bfloat16)
-    k0t = torch.empty_like(v0t)
-    ops.transpose_heads(vv[0], v0t, B, S, nkv, hd)
-    ops.transpose_heads(kv[0], k0t, B, S, nkv, hd)
     o = torch.empty(N, nh * hd, device=dev, dtype=torch.bfloat16)
     lse = torch.empty(B, nh, S, device=dev)
     kw = dict(B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=1 / math.sqrt(hd))
-    f = lambda: ops.attn_fwd(q, kv[0], v0t, kv[1:], vv[1:], None, o, lse, **kw)
+    f = lambda: ops.attn_fwd(q, kv[0], vv[0], kv[1:], vv[1:], None, o, lse, **kw)
     ms = timeit(f)
     fl = 4.0 * B * nh * hd * S * S / 2
     emit(kernel="attn_fwd", B=B, S=S, nh=nh, nkv=nkv, hd=hd, ndiag=ndiag, ms=ms, tflops=fl / ms / 1e9)
@@ -66,15 +62,11 @@ def bench_attn(B, S, nh, nkv, hd, ndiag):
     dk = [torch.zeros(N, nkv * hd, device=dev) for _ in range(ndiag + 1)]
     dv = [torch.zeros(N, nkv * hd, device=dev) for _ in range(ndiag + 1)]
     dq = torch.empty(N, nh * hd, device=dev, dtype=torch.bfloat16)
-    qt = torch.empty(B, nh, hd, S, device=dev, dtype=torch.bfloat16)
-    dot = torch.empty_like(qt)
     ms = timeit(lambda: ops.attn_bwd_pre(q, o, do, kv[1:], vv[1:], dk[1:], dv[1:], lse, delta, dq_init, **kw))
     emit(kernel="attn_bwd_pre", ndiag=ndiag, ms=ms)
-    ms = timeit(lambda: ops.attn_bwd_dq(q, do, kv[0], vv[0], k0t, None, lse, delta, dq_init, dq, **kw))
+    ms = timeit(lambda: ops.attn_bwd_dq(q, do, kv[0], vv[0], None, lse, delta, dq_init, dq, **kw))
     emit(kernel="attn_bwd_dq", ms=ms, tflops=6.0 * B * nh * hd * S * S / 2 / ms / 1e9)
-    ms = timeit(lambda: (ops.transpose_heads(q, qt, B, S, nh, hd), ops.transpose_heads(do, dot, B, S, nh, hd)))
-    emit(kernel="transpose_heads_x2", ms=ms, gbs=4 * N * nh * hd * 2 / ms / 1e6)
-    ms = timeit(lambda: ops.attn_bwd_dkv(q, do, qt, dot, kv[0], vv[0], None, lse, delta, dk[0], dv[0], **kw))
+    ms = timeit(lambda: ops.attn_bwd_dkv(q, do, kv[0], vv[0], None, lse, delta, dk[0], dv[0], **kw))
     emit(kernel="attn_bwd_dkv", ms=ms, tflops=8.0 * B * nh * hd * S * S / 2 / ms / 1e9)
 
 
