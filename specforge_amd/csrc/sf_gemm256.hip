@@ -24,6 +24,7 @@
 //     barriers before they touch it -> RAW safe for both (staggered) groups.
 #include "sf_api_internal.h"
 #include "sf_util.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -45,6 +46,8 @@ struct Gemm256Args {
     int M, N, K;
     float alpha, beta;
     int tiles_m, tiles_n;
+    int gm;     // tile-rows per L2 group of the XCD-aware tile order
+    int flags;  // tuning experiments: bit0 = no s_setprio around the MFMA segment
 };
 
 #ifdef SF_EMU
@@ -59,10 +62,9 @@ SF_DEVICE void wait_vm4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 SF_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
 
-SF_DEVICE void tile_coords256(int bid, int nblk, int tiles_m, int tiles_n, int& tm, int& tn) {
+SF_DEVICE void tile_coords256(int bid, int nblk, int tiles_m, int tiles_n, int GM, int& tm, int& tn) {
     const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
-    const int GM = 4;
     const int per_group = GM * tiles_n;
     const int g = seq / per_group;
     const int first_m = g * GM;
@@ -72,13 +74,59 @@ SF_DEVICE void tile_coords256(int bid, int nblk, int tiles_m, int tiles_n, int& 
     tn = in_g / gsize;
 }
 
+// C[m][n..n+3] = alpha*v (+beta*C) (+R), bf16 or fp32 output, ragged N handled
+template <int OUT_F32>
+SF_DEVICE void store4(const Gemm256Args& p, int m, int n, float (&v)[4]) {
+    if (m >= p.M || n >= p.N) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+    const bool full = (n + 3 < p.N);
+    if (OUT_F32) {
+        float* c = (float*)p.C + (long)m * p.ldc + n;
+        if (full) {
+            if (p.beta != 0.f) {
+                sf_v4f o = *reinterpret_cast<const sf_v4f*>(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += p.beta * o[r];
+            }
+            *reinterpret_cast<sf_v4f*>(c) = sf_v4f{v[0], v[1], v[2], v[3]};
+        } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = v[r] + (p.beta != 0.f ? p.beta * c[r] : 0.f);
+        }
+    } else {
+        sf_bf16* c = (sf_bf16*)p.C + (long)m * p.ldc + n;
+        if (full) {
+            if (p.beta != 0.f) {
+                sf_v4s o = *reinterpret_cast<const sf_v4s*>(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += p.beta * sf_bf2f((sf_bf16)o[r]);
+            }
+            if (p.R) {  // round the projection first, then add the residual (bf16 + bf16)
+                sf_v4s rr = *reinterpret_cast<const sf_v4s*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = sf_round_bf(v[r]) + sf_bf2f((sf_bf16)rr[r]);
+            }
+            sf_v4s o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (short)sf_f2bf(v[r]);
+            *reinterpret_cast<sf_v4s*>(c) = o;
+        } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                float t2 = v[r] + (p.beta != 0.f ? p.beta * sf_bf2f(c[r]) : 0.f);
+                if (p.R) t2 = sf_round_bf(t2) + sf_bf2f(p.R[(long)m * p.ldr + n + r]);
+                c[r] = sf_f2bf(t2);
+            }
+        }
+    }
+}
+
 template <int OUT_F32>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256_kernel(Gemm256Args p) {
     SF_DYN_SMEM(smem);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
     const int wr = wave >> 2, wc = wave & 3;
     int tm, tn;
-    tile_coords256((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    tile_coords256((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
     const int m0 = tm * TM, n0 = tn * TN;
     const int nkt = p.K / TK;
 
@@ -174,7 +222,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256_kernel(Gemm256Args p) {
             // ------------------------------------------------ compute segment: one 64x32 quadrant
             const int mh = (ph >= 2) ? 1 : 0;
             const int nh = (ph == 1 || ph == 2) ? 1 : 0;
-            sf_setprio_hi();
+            if (!(p.flags & 1)) sf_setprio_hi();
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -183,7 +231,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256_kernel(Gemm256Args p) {
                     for (int nt = 0; nt < 2; ++nt)
                         acc[mh * 4 + mt][nh * 2 + nt] =
                             sf_mfma16(nh ? b1[nt][ks] : b0[nt][ks], a[mt][ks], acc[mh * 4 + mt][nh * 2 + nt]);
-            sf_setprio_lo();
+            if (!(p.flags & 1)) sf_setprio_lo();
             sched_fence();
             raw_barrier();
         }
@@ -192,56 +240,139 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256_kernel(Gemm256Args p) {
 
     // ---- epilogue: lane owns C[m][n..n+3]
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wc * 64 + j * 16 + 4 * (lane >> 4);
-            if (n >= p.N) continue;
-            float v[4];
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + 4 * (lane >> 4), v);
+        }
+}
+
+template <int OUT_F32>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256_mf32_kernel(Gemm256Args p) {
+    SF_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
+    const int wr = wave >> 2, wc = wave & 3;
+    int tm, tn;
+    tile_coords256((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int nkt = p.K / TK;
+
+    // ---- DMA sources: this wave stages pieces 2*wave, 2*wave+1 (8 rows x 128 B each) of every half-tile
+    const int srow = lane >> 3;                       // row inside a piece
+    // logical 16-byte chunk fetched into physical chunk lane&7: XOR with ((row>>1)&7), which is conflict-free
+    // for the 32-row fragments of mfma_32x32x16; piece parity j contributes bit 2
+    const int slc2[2] = {(lane & 7) ^ ((srow >> 1) & 7), (lane & 7) ^ ((4 + (srow >> 1)) & 7)};
+    const sf_bf16* srcA[2][2];
+    const sf_bf16* srcB[2][2];
+    long incA[2][2], incB[2][2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r];
-            const bool full = (n + 3 < p.N);
-            if (OUT_F32) {
-                float* c = (float*)p.C + (long)m * p.ldc + n;
-                if (full) {
-                    if (p.beta != 0.f) {
-                        sf_v4f o = *reinterpret_cast<const sf_v4f*>(c);
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += p.beta * o[r];
-                    }
-                    *reinterpret_cast<sf_v4f*>(c) = sf_v4f{v[0], v[1], v[2], v[3]};
+        for (int j = 0; j < 2; ++j) {
+            const int r = h * 128 + (2 * wave + j) * 8 + srow;
+            const bool okA = m0 + r < p.M, okB = n0 + r < p.N;
+            srcA[h][j] = okA ? p.A + (long)(m0 + r) * p.lda + slc2[j] * 8 : sf_zero16b;
+            srcB[h][j] = okB ? p.B + (long)(n0 + r) * p.ldb + slc2[j] * 8 : sf_zero16b;
+            incA[h][j] = okA ? TK : 0;
+            incB[h][j] = okB ? TK : 0;
+        }
+    auto issue = [&](int op, int h, int kt) {  // op 0 = A, 1 = B; K-tile kt into buffer kt&1
+        char* dst = smem + (kt & 1) * kBufBytes + (op * 2 + h) * kHalfBytes + (2 * wave) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const sf_bf16* s = op == 0 ? srcA[h][j] + (long)kt * incA[h][j] : srcB[h][j] + (long)kt * incB[h][j];
+            sf_glds16(s, dst + j * 1024);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a half-tile); (row & 7) == (lane & 7) for every fragment row
+    const int frow = lane & 31, hi = lane >> 5;
+    int swz[4];  // k-step ks of 16: chunk 2*ks + hi, XOR ((row>>1)&7) == (lane>>1)&7 for every 32-row fragment
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) swz[ks] = ((2 * ks + hi) ^ ((lane >> 1) & 7)) << 4;
+    const int a_off = frow * 128;                                 // + (mh*64 + mt*32)*128
+    const int b_off = ((wc & 1) * 64 + frow) * 128;               // + (nh*32)*128
+
+    sf_v16f acc[4][2];  // [m tile of 32 rows][n tile of 32 cols]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    sf_v8s a[2][4], b0[4], b1[4];
+
+    // ---- prologue: K-tile 0 complete, B halves of K-tile 1 in flight
+    issue(0, 0, 0); issue(0, 1, 0); issue(1, 0, 0); issue(1, 1, 0);
+    if (nkt > 1) { issue(1, 0, 1); issue(1, 1, 1); }
+    sf_wait_vm0();
+    raw_barrier();
+    if (wr == 1) raw_barrier();  // stagger: group 1 runs one barrier behind group 0
+
+    for (int t = 0; t < nkt; ++t) {
+        const char* bufA = smem + (t & 1) * kBufBytes + wr * kHalfBytes;
+        const char* bufB = smem + (t & 1) * kBufBytes + (2 + (wc >> 1)) * kHalfBytes;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            // ------------------------------------------------ load segment
+            if (ph == 0) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) b0[ks] = *reinterpret_cast<const sf_v8s*>(bufB + b_off + swz[ks]);
+            }
+            if (ph == 1) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) b1[ks] = *reinterpret_cast<const sf_v8s*>(bufB + b_off + 32 * 128 + swz[ks]);
+            }
+            if (ph == 0 || ph == 2) {
+                const int mh = ph >> 1;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        a[mt][ks] = *reinterpret_cast<const sf_v8s*>(bufA + a_off + (mh * 64 + mt * 32) * 128 + swz[ks]);
+            }
+            if (ph == 0 && t + 1 < nkt) issue(0, 0, t + 1);
+            if (ph == 1 && t + 1 < nkt) issue(0, 1, t + 1);
+            if (ph == 2 && t + 2 < nkt) issue(1, 0, t + 2);
+            if (ph == 3) {
+                if (t + 2 < nkt) {
+                    issue(1, 1, t + 2);
+                    wait_vm4();      // all of K-tile t+1 has landed (this wave's pieces)
                 } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = v[r] + (p.beta != 0.f ? p.beta * c[r] : 0.f);
-                }
-            } else {
-                sf_bf16* c = (sf_bf16*)p.C + (long)m * p.ldc + n;
-                if (full) {
-                    if (p.beta != 0.f) {
-                        sf_v4s o = *reinterpret_cast<const sf_v4s*>(c);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += p.beta * sf_bf2f((sf_bf16)o[r]);
-                    }
-                    if (p.R) {
-                        sf_v4s rr = *reinterpret_cast<const sf_v4s*>(p.R + (long)m * p.ldr + n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = sf_round_bf(v[r]) + sf_bf2f((sf_bf16)rr[r]);
-                    }
-                    sf_v4s o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (short)sf_f2bf(v[r]);
-                    *reinterpret_cast<sf_v4s*>(c) = o;
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) {
-                        float t2 = v[r] + (p.beta != 0.f ? p.beta * sf_bf2f(c[r]) : 0.f);
-                        if (p.R) t2 = sf_round_bf(t2) + sf_bf2f(p.R[(long)m * p.ldr + n + r]);
-                        c[r] = sf_f2bf(t2);
-                    }
+                    sf_wait_vm0();
                 }
             }
+            wait_lgkm0();            // my ds_reads are done before anyone may restage what I read
+            raw_barrier();
+            sched_fence();
+            // ------------------------------------------------ compute segment: one 64x32 quadrant
+            const int mh = (ph >= 2) ? 1 : 0;
+            const int nh = (ph == 1 || ph == 2) ? 1 : 0;
+            if (!(p.flags & 1)) sf_setprio_hi();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[mh * 2 + mt][nh] = sf_mfma32(nh ? b1[ks] : b0[ks], a[mt][ks], acc[mh * 2 + mt][nh]);
+            if (!(p.flags & 1)) sf_setprio_lo();
+            sched_fence();
+            raw_barrier();
         }
     }
+    if (wr == 0) raw_barrier();  // group 0 catches up (equal barrier counts)
+
+    // ---- epilogue: lane owns C[m][n..n+3]
+    // D[n][m] layout of the swapped 32x32 MFMA: lane owns m = lane&31 and, per register quad q, n = 8q + 4hi + 0..3
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                store4<OUT_F32>(p, m0 + wr * 128 + i * 32 + (lane & 31), n0 + wc * 64 + j * 32 + 8 * q + 4 * hi, v);
+            }
 }
 
 }  // namespace
@@ -258,17 +389,27 @@ int sf_gemm_nt_256_launch(const void* A, long lda, const void* B, long ldb, void
     p.alpha = alpha; p.beta = beta;
     p.tiles_m = (M + TM - 1) / TM;
     p.tiles_n = (N + TN - 1) / TN;
+    { const char* e = getenv("SF_GEMM_GM"); p.gm = e ? atoi(e) : 4; if (p.gm < 1) p.gm = 1; }
+    { const char* e = getenv("SF_GEMM_FLAGS"); p.flags = e ? atoi(e) : 0; }
     const long nblk = (long)p.tiles_m * p.tiles_n;
 #ifndef SF_EMU
     static bool attr_set = false;
     if (!attr_set) {  // 128 KiB of dynamic LDS needs the opt-in
         hipFuncSetAttribute((const void*)gemm_nt_256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes);
         hipFuncSetAttribute((const void*)gemm_nt_256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes);
+        hipFuncSetAttribute((const void*)gemm_nt_256_mf32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes);
+        hipFuncSetAttribute((const void*)gemm_nt_256_mf32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes);
         (void)hipGetLastError();
         attr_set = true;
     }
 #endif
-    if (c_dtype == SF_F32)
+    static const bool mf32 = [] { const char* e = getenv("SF_GEMM_MFMA"); return e ? atoi(e) == 32 : false; }();
+    if (mf32) {
+        if (c_dtype == SF_F32)
+            SF_LAUNCH((gemm_nt_256_mf32_kernel<1>), dim3((unsigned)nblk), dim3(512), 2 * kBufBytes, stream, p);
+        else
+            SF_LAUNCH((gemm_nt_256_mf32_kernel<0>), dim3((unsigned)nblk), dim3(512), 2 * kBufBytes, stream, p);
+    } else if (c_dtype == SF_F32)
         SF_LAUNCH((gemm_nt_256_kernel<1>), dim3((unsigned)nblk), dim3(512), 2 * kBufBytes, stream, p);
     else
         SF_LAUNCH((gemm_nt_256_kernel<0>), dim3((unsigned)nblk), dim3(512), 2 * kBufBytes, stream, p);
