@@ -1,0 +1,73 @@
+"""BASELINE-size checks (Llama-3-8B draft, seq 2048) through size-independent properties -- the CPU
+oracle cannot run this size in test time, so the path is held to invariants of the algorithm:
+run-to-run bitwise determinism, linearity of the backward in the upstream gradient, accumulation
+== 2x, soft targets are distributions, position_mask = t2d[argmax] * loss_mask, ploss >= 0 and close
+to ln(Vd) for a random-init draft, teacher ids == argmax of an independent torch GEMM."""
+import math
+
+import pytest
+import torch
+
+from bench import LLAMA3_8B, make_batch
+from specforge_amd.eagle3 import Eagle3TrainStrategy, OnlineEagle3Model, TargetHead, TrainBatch
+from specforge_amd.model import DraftConfig, LlamaForCausalLMEagle3
+
+
+@pytest.mark.gpu
+def test_llama3_8b_seq2048_invariants():
+    dev = torch.device("cuda", 0)
+    cfg, B, S, T = LLAMA3_8B, 2, 2048, 7
+    torch.manual_seed(0)
+    model = LlamaForCausalLMEagle3(DraftConfig(**cfg), device=dev)
+    ids = torch.randperm(cfg["vocab_size"], generator=torch.Generator().manual_seed(0))[:cfg["draft_vocab_size"]].sort().values
+    t2d = torch.zeros(cfg["vocab_size"], dtype=torch.bool)
+    t2d[ids] = True
+    model.load_vocab_mapping_tensors(t2d, ids - torch.arange(cfg["draft_vocab_size"]))
+    eagle = OnlineEagle3Model(model, length=T).train()
+    head_w = (torch.randn(cfg["vocab_size"], cfg["target_hidden_size"], device=dev) * 0.02).to(torch.bfloat16)
+    strat = Eagle3TrainStrategy(eagle, target_head=TargetHead(head_w))
+    raw = make_batch(cfg, B, S, dev, 7)
+    raw["loss_mask"][:, :100] = 0                       # a prompt region without loss
+    raw["attention_mask"][1, 1500:] = 0                 # right padding in sample 1
+    raw["loss_mask"][1, 1499:] = 0
+    batch = TrainBatch(raw, {"target_repr": "hidden_state"})
+    eng = eagle.engine
+
+    def run(scale):
+        eng.micro_in_window = 0
+        out = strat.forward_loss(batch)
+        (out.loss * scale).backward()
+        torch.cuda.synchronize()
+        return out, eng.flat.grad.clone()
+
+    out1, g1 = run(1.0)
+    out2, g2 = run(1.0)
+    assert torch.equal(g1, g2), "backward is not run-to-run deterministic"
+    assert torch.equal(torch.stack(out1.metrics["plosses"]), torch.stack(out2.metrics["plosses"]))
+    _, g3 = run(2.0)                                    # linear in the upstream gradient
+    torch.testing.assert_close(g3.float(), 2 * g1.float(), rtol=1e-2, atol=1e-2 * float(g1.float().abs().max()))
+    eng.micro_in_window = 0                             # accumulation: second micro-step adds
+    strat.forward_loss(batch).loss.backward()
+    strat.forward_loss(batch).loss.backward()
+    torch.testing.assert_close(eng.flat.grad.float(), 2 * g1.float(), rtol=2e-2, atol=2e-2 * float(g1.float().abs().max()))
+    assert torch.isfinite(g1.float()).all()
+
+    b = eng._buffers(B, S)
+    tp = b["tp"][:, :S]
+    torch.testing.assert_close(tp.sum(-1), torch.ones(B, S, device=dev), rtol=1e-4, atol=1e-4)   # distributions
+    assert float(tp.min()) >= 0.0
+    assert float((b["tp"][:, S:] - 1.0 / cfg["draft_vocab_size"]).abs().max()) == 0.0          # padded tail = 1/Vd
+    tid, pm, lm = b["tids"][:, :S], b["pm"][:, :S], b["lm"][:, :S]
+    assert torch.equal(pm, (t2d.to(dev)[tid].int() * lm))                                          # bit-exact
+    assert int(pm[:, :100].sum()) == 0 and int(pm[1, 1499:].sum()) == 0
+    # teacher ids vs an independent torch GEMM + argmax (bf16 logits like TargetHead.forward)
+    th = torch.cat((raw["target"][:, 1:], torch.zeros_like(raw["target"][:, -1:])), dim=1)        # preprocess shift
+    z = torch.matmul(th.reshape(B * S, -1), head_w.t())
+    agree = float((z.float().argmax(-1).view(B, S) == tid).float().mean())
+    assert agree >= 0.999, agree
+    pl = torch.stack(out1.metrics["plosses"]).float().cpu()
+    assert (pl >= 0).all()
+    frac = float(pm.float().mean())
+    assert abs(float(pl[0]) - frac * math.log(cfg["draft_vocab_size"])) < 0.35 * frac * math.log(cfg["draft_vocab_size"])
+    acc = torch.stack(out1.metrics["acces"]).float().cpu()
+    assert ((acc >= 0) & (acc <= 1)).all()
