@@ -187,11 +187,15 @@ teacher_reduce_kernel(const T* z, long ldz, int Vt, int Vd, const long long* d2t
     const T* x = z + (long)r * ldz;
     const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
     const int V8 = Vt >> 3;
-    float m = SF_NEG_BIG, d = 0.f;
+    float m = SF_NEG_BIG, d = 0.f, md = SF_NEG_BIG;  // md: max over the draft sub-vocabulary (t2d mask)
     ArgMax am{SF_NEG_BIG, 0x7fffffff};
     for (int c = tid; c < V8; c += nt) {
         float v[8];
         SfVec8<T>::ld(x + c * 8, v);
+        const unsigned long long mk = *reinterpret_cast<const unsigned long long*>(t2d + c * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if ((mk >> (8 * i)) & 0xffull) md = fmaxf(md, v[i]);
         float cm = v[0];
 #pragma unroll
         for (int i = 1; i < 8; ++i) cm = fmaxf(cm, v[i]);
@@ -208,6 +212,7 @@ teacher_reduce_kernel(const T* z, long ldz, int Vt, int Vd, const long long* d2t
     for (int j = V8 * 8 + tid; j < Vt; j += nt) {
         float v = SfElem<T>::ld(x + j);
         if (v > am.v) { am.v = v; am.i = j; }
+        if (t2d[j]) md = fmaxf(md, v);
         md_merge(m, d, v, 1.f);
     }
     for (int k = 32; k >= 1; k >>= 1) {
@@ -226,9 +231,8 @@ teacher_reduce_kernel(const T* z, long ldz, int Vt, int Vd, const long long* d2t
     }
     const float lse_full = m + sf_log(d);
     sf_syncthreads();
-    // draft sub-vocabulary: max, then exp-sum, then normalise (torch.softmax order)
-    float md = SF_NEG_BIG;
-    for (int j = tid; j < Vd; j += nt) md = fmaxf(md, SfElem<T>::ld(x + j + d2t[j]));
+    // draft sub-vocabulary: max (taken in the streaming pass above), exp-sum over ONE gathered pass,
+    // then normalise (torch.softmax order)
     md = sf_block_max(md, red);
     float* tp = target_p_pad + pr * (long)Vd;
     float sd = 0.f;
