@@ -203,10 +203,14 @@ class HipDPTrainingBackend:
     def scale_gradients(self, factor) -> None:
         raise NotImplementedError("loss_terms strategies (DFlash) are outside the EAGLE3 path")
 
-    def step(self):
+    def synchronize_gradients(self) -> None:
+        """wait for the bucket all-reduces launched by the last boundary backward"""
         for h in self._handles:
             h.wait()
         self._handles.clear()
+
+    def step(self):
+        self.synchronize_gradients()
         return self.optimizer.step()
 
     def state_dict(self) -> dict:

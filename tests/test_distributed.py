@@ -66,6 +66,7 @@ def _worker(rank, world, port, golden_dir, emu_path, out_dir):
     eagle, strat, backend, batch = _setup(golden_dir, emu_path)
     # optimizer window 1: one micro-step; window 2: two micro-steps (first one without the collective)
     backend.backward(strat.forward_loss(batch(10 + rank)).loss, is_boundary=True)
+    backend.synchronize_gradients()  # the bucket all-reduces are asynchronous
     g_after_first = eagle.engine.flat.grad.float().clone()
     backend.step()
     for i, boundary in enumerate((False, True)):
