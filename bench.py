@@ -177,6 +177,16 @@ def main():
     tokens = world * B * S * args.steps
     if rank == 0:
         ach = fl / gemm_ms / 1e9 if gemm_ms > 0 else 0.0
+        # HBM-side traffic of the GEMM kernel per launch: from the committed rocprofv3 --pmc passes of this same
+        # command (profiles/r1_pmc_fetch_write_summary.json; FETCH_SIZE doubled per the gfx950 correction of
+        # MI355X_MICROARCH.md, calibrated there on the AdamW kernel's known byte count).  PMC counters cannot be
+        # collected from inside the timed run, so this field is null when the summary is absent.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_write_summary.json")))["gemm256"]
+            traffic = (2.0 * pm["FETCH_SIZE_sum"] + pm["WRITE_SIZE_sum"]) * 1024.0 / pm["launches"]
+        except Exception:
+            pass
         line = {
             "metric": "EAGLE3 draft train tokens/sec, Llama-3-8B target, seq2048 at 1/2/4/8 MI355X",
             "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -185,8 +195,8 @@ def main():
             "config": {"workload": ("SMALL-debug" if args.small else "Llama-3-8B EAGLE3 offline draft")
                        + f", bf16, per-GPU batch {B} x seq {S}, ttt {args.ttt}, optimizer step included",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA GEMM)", "achieved": ach,
-                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256_kernel (bf16 MFMA GEMM, 256x256x64 ping-pong)", "achieved": ach,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "launches_per_step": nlaunch / max(1, args.steps),
                          "gemm_ms_per_step": gemm_ms / max(1, args.steps)},
             "final_loss": loss,
