@@ -51,6 +51,16 @@ struct AttnFwdArgs {
     int dbg;  // profiling experiments only (SF_ATTN_DBG): 1 = stage tile 0 only, 2 = skip the MFMA/softmax work
 };
 
+// ---- LDS tile swizzle -------------------------------------------------------
+// 16-byte chunk c of tile row r is stored at chunk c ^ swz<HD>(r).  HD = 128 (16 chunks per 256-byte row):
+// swz = ((r & 3) << 2) ^ ((r >> 2) & 3) is a bijection of r mod 16 onto 0..15, so a ds_read_b128 of 16
+// consecutive rows at one logical chunk is conflict-free, and the 8 (row, column-half) pieces of a 32-lane
+// ds_read_b64_tr_b16 pass land in 8 distinct 32-byte bank slots.  HD = 64 (8 chunks per row): r & 7.
+template <int HD>
+SF_DEVICE int swz(int r) {
+    return HD == 128 ? (((r & 3) << 2) ^ ((r >> 2) & 3)) : (r & 7);
+}
+
 // ---- LDS tile staging -------------------------------------------------------
 // natural tile: 64 rows (keys / queries) x HD, row-major, 16-byte chunks XOR-swizzled by row&7
 template <int HD, int NW>
@@ -64,7 +74,7 @@ SF_DEVICE void stage_rows64(char* lds, const sf_bf16* base, long ld, int row0, i
         if (NP % NW != 0 && wave * NI + t >= NP) break;  // wave-uniform
         const int rr = (wave * NI + t) * RPI + lane / CPR;
         const int pc = lane % CPR;
-        const int lc = pc ^ (rr & 7);
+        const int lc = pc ^ swz<HD>(rr);
         const sf_bf16* src = (row0 + rr < nrows_valid) ? base + (long)(row0 + rr) * ld + lc * 8 : sf_zero16a;
         sf_glds16(src, lds + (wave * NI + t) * 1024);  // uniform base; lane i lands at +16*i
     }
@@ -75,16 +85,21 @@ SF_DEVICE void stage_rows64(char* lds, const sf_bf16* base, long ld, int row0, i
 template <int HD>
 struct FragOff {
     int rows[HD / 16];  // natural tile, k-step ks: (lane&31)*rowbytes + swizzled chunk (2ks + hi)
-    int tr[HD / 32];    // transpose-read of a natural tile, 32-column block db: this lane's 8-byte piece
+    int tr[HD / 32][2]; // transpose-read of a natural tile, 32-column block db, rows r0+.. / r0+8+..: this lane's piece
     SF_DEVICE void init(int lane) {
-        const int c = lane & 31, hi = lane >> 5, x = lane & 7;
+        const int c = lane & 31, hi = lane >> 5;
 #pragma unroll
-        for (int ks = 0; ks < HD / 16; ++ks) rows[ks] = c * (HD * 2) + (((2 * ks + hi) ^ x) << 4);
+        for (int ks = 0; ks < HD / 16; ++ks) rows[ks] = c * (HD * 2) + (((2 * ks + hi) ^ swz<HD>(c)) << 4);
         // ds_read_b64_tr_b16: 16-lane group (lane>>4) covers tile rows r0 + 4*hi + 0..3 and columns
         // db*32 + 16*((lane>>4)&1) + 0..15; lane i of the group supplies piece i = (row i/4, cols 4*(i%4)..+3)
-        const int i = lane & 15, qx = 4 * hi + (i >> 2), t = 2 * ((lane >> 4) & 1) + ((i >> 1) & 1);
+        const int i = lane & 15, t = 2 * ((lane >> 4) & 1) + ((i >> 1) & 1);
 #pragma unroll
-        for (int db = 0; db < HD / 32; ++db) tr[db] = qx * (HD * 2) + ((((4 * db + t) ^ qx)) << 4) + (i & 1) * 8;
+        for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+            for (int sec = 0; sec < 2; ++sec) {
+                const int qx = 8 * sec + 4 * hi + (i >> 2);  // tile row (mod 16; r0 is a multiple of 16)
+                tr[db][sec] = qx * (HD * 2) + ((((4 * db + t) ^ swz<HD>(qx))) << 4) + (i & 1) * 8;
+            }
     }
 };
 // A fragment (32 rows x 16 k) from a natural tile: row = r0 + (lane&31), k = 16*ks + 8*(lane>>5)
@@ -97,9 +112,8 @@ SF_DEVICE sf_v8s frag_rows(const char* lds, int r0, int ks, const FragOff<HD>& f
 // {r0 + 4*hi + 0..3} and {r0 + 8 + 4*hi + 0..3}  (r0 multiple of 16)
 template <int HD>
 SF_DEVICE sf_v8s frag_tr(const char* lds, int db, int r0, const FragOff<HD>& fo) {
-    const char* base = lds + r0 * (HD * 2) + fo.tr[db];
-    const sf_v4s lo = sf_ds_read_tr16(base);
-    const sf_v4s up = sf_ds_read_tr16(base + 8 * (HD * 2));
+    const sf_v4s lo = sf_ds_read_tr16(lds + r0 * (HD * 2) + fo.tr[db][0]);
+    const sf_v4s up = sf_ds_read_tr16(lds + r0 * (HD * 2) + fo.tr[db][1]);
     return sf_v8s{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
 }
 SF_DEVICE sf_v8s pack_bf16x8(const sf_v16f& p, int r0) {
