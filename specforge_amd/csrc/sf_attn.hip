@@ -187,12 +187,15 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
         const bool need_mask = (key0 + 63 > qw0) || (key0 + 63 >= kvlen);
         sf_v16f s[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+        // the two 32-key blocks are independent accumulation chains: interleave them so that no MFMA has to
+        // wait for the result of the one issued right before it
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s[kb] = sf_mfma32(frag_rows<HD>(lds_k, kb * 32, ks, fo), qf[ks], s[kb]);
-        }
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) s[kb] = sf_mfma32(frag_rows<HD>(lds_k, kb * 32, ks, fo), qf[ks], s[kb]);
         // scores stay unscaled in the accumulators; only diagonal / padded tiles pay for masking
         if (need_mask) {
 #pragma unroll
@@ -441,15 +444,16 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         if (key0 > qw0 + 31) continue;
         sf_v16f s[2], dp[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[kb][r] = 0.f; dp[kb][r] = 0.f; }
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < KS; ++ks)  // four independent accumulation chains, round-robin
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
                 s[kb] = sf_mfma32(frag_rows<HD>(lds_k, kb * 32, ks, fo), qf[ks], s[kb]);
                 dp[kb] = sf_mfma32(frag_rows<HD>(lds_v, kb * 32, ks, fo), dof[ks], dp[kb]);
             }
-        }
         const bool need_mask = (key0 + 63 > qw0) || (key0 + 63 >= kvlen);  // wave-uniform
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
