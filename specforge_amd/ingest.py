@@ -1,0 +1,151 @@
+"""Hidden-state ingest: pre-captured ``.ckpt`` samples -> pinned host -> HBM, double-buffered.
+
+SURVEY.md section 8f rank 1 -- the step *before* the hot path.  At ~60 k tokens/s/GPU the trainer consumes
+~2 GB/s of bf16 hidden states per GPU; the reference's ``torch.load`` + Python collate + blocking
+``.to(device)`` on the compute stream (specforge/runtime/data_plane/feature_store.py:235-240,
+feature_dataloader.py:255-295, strategies/base.py:270-289) would serialise 0.54 GB of PCIe per micro-step
+(~9 ms at 63 GB/s) in front of every step.  Here a loader thread fills a pinned staging slot while the GPU
+works, a dedicated HIP copy stream moves it to a device slot, and the compute stream only waits on an event.
+
+Semantics mirrored from the reference (bit-for-bit on the produced tensors, see tests/test_ingest.py):
+* file format: ``torch.save`` dict with ``input_ids [S]``, ``loss_mask [S]``, ``hidden_state [1,S,Ht]``,
+  ``aux_hidden_state [1,S,3Ht]`` (scripts/prepare_hidden_states.py:446-480, tests/test_runtime/_fixtures.py:131-149)
+* sample normalisation (algorithms/eagle3/data.py:10-27): ``hidden_state <- aux_hidden_state[:max_len]``,
+  ``target <- hidden_state[:max_len]``, ``loss_mask[-1] = 0``, ``attention_mask = 1``
+* collation (data/utils.py:106-196): right-pad with zeros to the longest sample of the batch; the padded
+  length is additionally rounded up to a multiple of 8 (16-byte rows for the attention kernels) -- extra
+  right padding is masked out exactly like the collator's own padding
+* sharding (launch.py:174-239): ``distributed_sampler_indices`` (== torch DistributedSampler), ``drop_last``
+  batches (trainer.py:151)
+"""
+from __future__ import annotations
+
+import queue
+import threading
+from typing import Dict, Iterator, List, Optional, Sequence
+
+import torch
+
+from .eagle3 import TrainBatch
+from .training import distributed_sampler_indices
+
+
+def normalize_offline_sample(raw: Dict[str, torch.Tensor], max_len: int) -> Dict[str, torch.Tensor]:
+    hidden_state = raw["aux_hidden_state"].squeeze(0)[:max_len].unsqueeze(0)
+    target = raw["hidden_state"].squeeze(0)[:max_len].unsqueeze(0)
+    input_ids = raw["input_ids"][:max_len].unsqueeze(0)
+    loss_mask = raw["loss_mask"][:max_len].clone().unsqueeze(0)
+    if loss_mask.numel() > 0:
+        loss_mask[0, -1] = 0
+    return dict(attention_mask=torch.ones_like(loss_mask, dtype=torch.long), loss_mask=loss_mask, target=target,
+                hidden_state=hidden_state, input_ids=input_ids)
+
+
+class _Slot:
+    """one staging slot: pinned host tensors + device tensors sized for the largest possible batch"""
+
+    def dview(self, k, L):
+        h = self.h[k]
+        shape = (h.shape[0], L) + tuple(h.shape[2:])
+        n = 1
+        for x in shape:
+            n *= x
+        return self.d[k][:n].view(shape)
+
+    def __init__(self, B, L, Ht, device, pin):
+        def host(*shape, dtype):
+            t = torch.zeros(*shape, dtype=dtype)
+            return t.pin_memory() if pin else t
+
+        self.h = dict(input_ids=host(B, L, dtype=torch.int64), attention_mask=host(B, L, dtype=torch.int64),
+                      loss_mask=host(B, L, dtype=torch.int64), hidden_state=host(B, L, 3 * Ht, dtype=torch.bfloat16),
+                      target=host(B, L, Ht, dtype=torch.bfloat16))
+        # device side: flat buffers, viewed as a CONTIGUOUS [B, L, ...] tensor of the batch's actual padded length
+        self.d = {k: torch.zeros(v.numel(), dtype=v.dtype, device=device) for k, v in self.h.items()} if device.type == "cuda" else None
+        self.copied = None      # event on the copy stream: H2D of this slot finished
+        self.released = None    # event on the compute stream: the consumer moved past this slot
+
+
+class HiddenStateIngest:
+    def __init__(self, files: Sequence[str], *, batch_size: int, max_len: int, target_hidden_size: int, device,
+                 dp_rank: int = 0, dp_size: int = 1, seed: int = 0, shuffle: bool = True, pad_multiple: int = 8,
+                 slots: int = 2):
+        self.files = list(files)
+        self.B, self.max_len, self.Ht = batch_size, max_len, target_hidden_size
+        self.device = torch.device(device)
+        self.dp_rank, self.dp_size, self.seed, self.shuffle = dp_rank, dp_size, seed, shuffle
+        self.pad_multiple = pad_multiple
+        cuda = self.device.type == "cuda"
+        Lcap = (max_len + pad_multiple - 1) // pad_multiple * pad_multiple
+        self._slots = [_Slot(batch_size, Lcap, target_hidden_size, self.device, pin=cuda) for _ in range(max(2, slots))]
+        self._copy_stream = torch.cuda.Stream(device=self.device) if cuda else None
+
+    def batches_per_epoch(self) -> int:
+        n = len(distributed_sampler_indices(len(self.files), dp_rank=self.dp_rank, dp_size=self.dp_size, seed=self.seed,
+                                            epoch=0, shuffle=self.shuffle))
+        return n // self.B
+
+    def _fill(self, slot: _Slot, idxs: List[int]) -> int:
+        samples = [normalize_offline_sample(torch.load(self.files[i], mmap=True, weights_only=True), self.max_len) for i in idxs]
+        L = max(s["input_ids"].shape[1] for s in samples)
+        L = (L + self.pad_multiple - 1) // self.pad_multiple * self.pad_multiple
+        for k, buf in slot.h.items():
+            buf[:, :L].zero_()
+            for b, s in enumerate(samples):
+                n = s[k].shape[1]
+                buf[b, :n].copy_(s[k][0])
+        return L
+
+    def epoch(self, epoch: int = 0) -> Iterator[TrainBatch]:
+        idx = distributed_sampler_indices(len(self.files), dp_rank=self.dp_rank, dp_size=self.dp_size, seed=self.seed,
+                                          epoch=epoch, shuffle=self.shuffle)
+        groups = [idx[i:i + self.B] for i in range(0, len(idx) - self.B + 1, self.B)]  # drop_last
+        nslots = len(self._slots)
+        free: "queue.Queue[int]" = queue.Queue()
+        ready: "queue.Queue" = queue.Queue()
+        for i in range(nslots):
+            free.put(i)
+
+        def loader():
+            try:
+                for g in groups:
+                    si = free.get()
+                    slot = self._slots[si]
+                    if slot.released is not None:      # the consumer's stream must be past this slot's tensors
+                        slot.released.synchronize()
+                    L = self._fill(slot, g)
+                    if self._copy_stream is not None:
+                        with torch.cuda.stream(self._copy_stream):
+                            for k in slot.h:
+                                slot.dview(k, L).copy_(slot.h[k][:, :L], non_blocking=True)
+                            slot.copied = torch.cuda.Event()
+                            slot.copied.record()
+                    ready.put((si, L, g))
+                ready.put(None)
+            except BaseException as e:  # surface loader failures in the consumer
+                ready.put(e)
+
+        t = threading.Thread(target=loader, daemon=True)
+        t.start()
+        prev = None
+        while True:
+            item = ready.get()
+            if prev is not None:  # the consumer asked for the next batch: everything it enqueued on `prev` is ordered before this
+                if self._copy_stream is not None:
+                    self._slots[prev].released = torch.cuda.Event()
+                    self._slots[prev].released.record()
+                free.put(prev)
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            si, L, g = item
+            slot = self._slots[si]
+            if self._copy_stream is not None:
+                torch.cuda.current_stream().wait_event(slot.copied)
+                tensors = {k: slot.dview(k, L) for k in slot.d}
+            else:
+                tensors = {k: v[:, :L].clone() for k, v in slot.h.items()}
+            prev = si
+            yield TrainBatch(tensors, {"target_repr": "hidden_state", "sample_indices": list(g)})
+        t.join()

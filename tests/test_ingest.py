@@ -1,0 +1,80 @@
+"""Hidden-state ingest: files in the reference's offline-feature format
+(tests/test_runtime/_fixtures.py:131-149) -> normalised, right-padded, sharded batches; compared tensor for
+tensor with a straight restatement of the reference's normaliser + collator
+(algorithms/eagle3/data.py:10-27, data/utils.py:106-196) and with its shard indices (launch.py:174-239)."""
+import os
+
+import pytest
+import torch
+
+from specforge_amd.ingest import HiddenStateIngest, normalize_offline_sample
+from specforge_amd.training import distributed_sampler_indices
+
+HT, V = 64, 500
+
+
+def _write(d, lengths, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    files = []
+    for i, L in enumerate(lengths):
+        p = os.path.join(d, f"{i:04d}.ckpt")
+        torch.save({"input_ids": torch.randint(0, V, (L,), generator=g), "loss_mask": torch.ones(L, dtype=torch.long),
+                    "hidden_state": torch.randn(1, L, HT, generator=g).to(torch.bfloat16),
+                    "aux_hidden_state": torch.randn(1, L, 3 * HT, generator=g).to(torch.bfloat16)}, p)
+        files.append(p)
+    return files
+
+
+def _reference_collate(files, idxs, max_len):
+    """normalize_offline_sample + DataCollatorWithPadding semantics, written independently (loops, no slicing tricks)"""
+    samples = [torch.load(files[i]) for i in idxs]
+    Ls = [min(int(s["input_ids"].shape[0]), max_len) for s in samples]
+    L = (max(Ls) + 7) // 8 * 8
+    B = len(samples)
+    out = dict(input_ids=torch.zeros(B, L, dtype=torch.int64), attention_mask=torch.zeros(B, L, dtype=torch.int64),
+               loss_mask=torch.zeros(B, L, dtype=torch.int64), hidden_state=torch.zeros(B, L, 3 * HT, dtype=torch.bfloat16),
+               target=torch.zeros(B, L, HT, dtype=torch.bfloat16))
+    for b, (s, n) in enumerate(zip(samples, Ls)):
+        out["input_ids"][b, :n] = s["input_ids"][:n]
+        out["attention_mask"][b, :n] = 1
+        out["loss_mask"][b, :n] = s["loss_mask"][:n]
+        out["loss_mask"][b, n - 1] = 0
+        out["hidden_state"][b, :n] = s["aux_hidden_state"][0, :n]
+        out["target"][b, :n] = s["hidden_state"][0, :n]
+    return out
+
+
+@pytest.mark.parametrize("dev", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_ingest_matches_reference_normaliser_collator_and_sharding(tmp_path, dev):
+    lengths = [16, 9, 40, 33, 7, 24, 31, 12, 40, 5, 18]
+    files = _write(str(tmp_path), lengths)
+    max_len, B = 32, 2
+    seen = []
+    for rank in range(2):
+        ing = HiddenStateIngest(files, batch_size=B, max_len=max_len, target_hidden_size=HT, device=dev, dp_rank=rank,
+                                dp_size=2, seed=3)
+        for epoch in (0, 1):
+            want_idx = distributed_sampler_indices(len(files), dp_rank=rank, dp_size=2, seed=3, epoch=epoch)
+            groups = [want_idx[i:i + B] for i in range(0, len(want_idx) - B + 1, B)]
+            got = list(ing.epoch(epoch))
+            assert len(got) == len(groups) == ing.batches_per_epoch()
+            for batch, g in zip(got, groups):
+                assert batch.metadata["sample_indices"] == g
+                ref = _reference_collate(files, g, max_len)
+                for k, v in ref.items():
+                    t = batch.tensors[k]
+                    assert t.device.type == dev and t.is_contiguous() and t.shape == v.shape, (k, t.shape, v.shape)
+                    assert torch.equal(t.cpu(), v), k
+                if epoch == 0:
+                    seen.extend(g)
+    assert sorted(set(seen)) == sorted(set(range(len(files))) & set(seen))
+
+
+def test_normalizer_matches_reference_function():
+    g = torch.Generator().manual_seed(1)
+    raw = {"input_ids": torch.randint(0, V, (12,), generator=g), "loss_mask": torch.ones(12, dtype=torch.long),
+           "hidden_state": torch.randn(1, 12, HT, generator=g), "aux_hidden_state": torch.randn(1, 12, 3 * HT, generator=g)}
+    out = normalize_offline_sample(raw, 10)
+    assert out["hidden_state"].shape == (1, 10, 3 * HT) and out["target"].shape == (1, 10, HT)
+    assert out["loss_mask"][0, -1] == 0 and int(out["loss_mask"].sum()) == 9 and int(raw["loss_mask"].sum()) == 12
+    assert torch.equal(out["attention_mask"], torch.ones(1, 10, dtype=torch.long))
