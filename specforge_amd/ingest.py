@@ -97,6 +97,9 @@ class HiddenStateIngest:
         return L
 
     def epoch(self, epoch: int = 0) -> Iterator[TrainBatch]:
+        """Yields device-resident batches.  A batch's tensors are views of a staging slot: they stay valid until
+        the NEXT batch is requested (by then the consumer has enqueued all work that reads them; the slot is
+        refilled only after an event on the consumer's stream has passed)."""
         idx = distributed_sampler_indices(len(self.files), dp_rank=self.dp_rank, dp_size=self.dp_size, seed=self.seed,
                                           epoch=epoch, shuffle=self.shuffle)
         groups = [idx[i:i + self.B] for i in range(0, len(idx) - self.B + 1, self.B)]  # drop_last
