@@ -117,3 +117,19 @@ def test_accumulation_window_and_eval_mode(backend, golden_dir):
         out = strat.forward_loss(_batch(blob, backend))
     assert not out.loss.requires_grad
     torch.testing.assert_close(torch.stack(out.metrics["plosses"]).float().cpu(), blob["plosses"], rtol=2e-2, atol=2e-2)
+
+
+def test_logits_teacher_path_equals_hidden_state_path(backend, golden_dir):
+    """target_repr == logits (online capture delivers target logits, strategies/base.py:246-268) must give the same
+    step as the streaming hidden-state teacher when the logits are the head's own bf16 output"""
+    blob = torch.load(os.path.join(golden_dir, "eagle3_tiny_bf16.pt"), weights_only=False)
+    cfg, model, eagle, strat = _build(blob, backend)
+    eagle.train()
+    batch = _batch(blob, backend)
+    out_h = strat.forward_loss(batch)
+    ids_h = eagle.last_artifacts["target_token_ids"].clone()
+    t = dict(batch.tensors)
+    t["target"] = torch.nn.functional.linear(t["target"].cpu().to(torch.bfloat16), blob["head_w"].to(torch.bfloat16)).to(backend)
+    out_l = strat.forward_loss(TrainBatch(t, {"target_repr": "logits"}))
+    assert torch.equal(eagle.last_artifacts["target_token_ids"], ids_h)
+    torch.testing.assert_close(torch.stack(out_l.metrics["plosses"]), torch.stack(out_h.metrics["plosses"]), rtol=2e-2, atol=2e-2)
