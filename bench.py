@@ -122,7 +122,8 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # torch.distributed.run
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -209,7 +210,7 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {e}"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -16,6 +16,7 @@
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional
 
@@ -174,8 +175,10 @@ class HipDPTrainingBackend:
 
     def prepare_model(self, model: OnlineEagle3Model, *, wrap: bool = True, optimizer_target=None) -> nn.Module:
         self.module = model
-        model.engine.on_bucket_ready = self._bucket_ready if self.world > 1 else None
-        if self.world > 1:  # replicas must start identical (DDP broadcasts rank 0's parameters)
+        # SF_FORCE_DP=1: run the collectives even at world_size 1 (exercises the RCCL path on a single-GPU box)
+        use_dp = self.world > 1 or (os.environ.get("SF_FORCE_DP") == "1" and dist.is_available() and dist.is_initialized())
+        model.engine.on_bucket_ready = self._bucket_ready if use_dp else None
+        if use_dp:  # replicas must start identical (DDP broadcasts rank 0's parameters)
             dist.broadcast(model.engine.flat.data, src=0, group=self.group)
         if self._optimizer_factory is not None:
             self.optimizer = self._optimizer_factory(optimizer_target if optimizer_target is not None else model)
