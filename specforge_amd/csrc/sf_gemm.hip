@@ -175,6 +175,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) gemm_nt_kernel(GemmArgs p) {
 
 int sf_gemm_nt_256_launch(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
                           int K, float alpha, float beta, const void* R, long ldr, void* stream);
+int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M,
+                            int N, int K, float alpha, float beta, const void* R, long ldr, void* stream);
 // tuning knob for A/B measurements only: SF_GEMM_TILE=128 pins the 128x128 kernel
 static bool sf_gemm_use_256() {
     static const bool use = [] {
@@ -193,6 +195,13 @@ extern "C" int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void
     SF_CHECK_ARG(!(R && c_dtype == SF_F32), "sf_gemm_nt: residual epilogue is bf16-only");
     if (M == 0 || N == 0) return 0;
     // big, 64-aligned-K shapes (every GEMM of the training step) take the 256x256 ping-pong kernel
+    // chip-filling shapes (>= one 256x256 tile per CU, long K: every GEMM of the training step) take the 4-wave
+    // software-pipelined kernel; smaller ones the 8-wave ping-pong kernel, whose prologue/epilogue is shorter.
+    // SF_GEMM_W4=0 pins the ping-pong kernel, =1 forces the 4-wave kernel for every 256-tile shape (A/B knob).
+    static const int w4_mode = [] { const char* e = getenv("SF_GEMM_W4"); return e ? atoi(e) : -1; }();
+    const bool big = (long)((M + 255) / 256) * ((N + 255) / 256) >= 256 && K >= 512;
+    if (K % 64 == 0 && K >= 64 && M >= 192 && N >= 192 && sf_gemm_use_256() && (w4_mode == 1 || (w4_mode < 0 && big)))
+        return sf_gemm_nt_256w4_launch(A, lda, B, ldb, C, c_dtype, ldc, M, N, K, alpha, beta, R, ldr, stream);
     if (K % 64 == 0 && K >= 64 && M >= 192 && N >= 192 && sf_gemm_use_256())
         return sf_gemm_nt_256_launch(A, lda, B, ldb, C, c_dtype, ldc, M, N, K, alpha, beta, R, ldr, stream);
     GemmArgs p;

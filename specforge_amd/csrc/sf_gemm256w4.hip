@@ -1,0 +1,390 @@
+// 256x256x64 bf16 MFMA GEMM (NT form), 4 waves x (128 x 128) -- one wave per SIMD, software-pipelined
+// in ONE instruction stream per wave instead of the two barrier-staggered wave groups of sf_gemm256.hip.
+//
+// Why: the ping-pong kernel needs 8 workgroup barriers per K-tile to hand the matrix pipe from one wave
+// group to the other; measured on MI355X an MFMA+barrier-only ablation of that loop tops out at ~80 % of
+// the sustained MFMA rate (each barrier costs ~45 cycles against 256 cycles of MFMA), and the load
+// segments only partially hide under the partner's MFMAs.  Here every SIMD runs one wave that owns the
+// pipe for the whole K loop; ds_reads and LDS-DMA issues are threaded between its MFMAs (one per 4 MFMAs),
+// and there is ONE barrier per K-tile.
+//
+//   * 256 threads; wave (wr, wc) of a 2 x 2 grid owns a 128 x 128 output block = 8 x 8
+//     mfma_f32_16x16x32_bf16 tiles (256 accumulator registers; the kernel runs at one wave per SIMD with
+//     the full 512-entry unified VGPR/AGPR file).
+//   * LDS = 2 K-tile buffers x {A 256 rows, B 256 rows} x 128 B, XOR-swizzled 16-byte chunks = 128 KiB.
+//   * a K-tile is two half-steps (k = 0..31, 32..63) of 64 MFMAs; fragments are double-buffered in
+//     registers: half-step h computes from set h&1 while the 16 ds_read_b128 of half-step h+1 fill the
+//     other set.
+//   * per K-tile t:   half-step 2t   : 64 MFMA | 16 ds_read (tile t, k-half 1), front-loaded
+//                                      vmcnt(0) lgkmcnt(0) s_barrier      <- tile t+1 visible, buffer t&1 free
+//                     half-step 2t+1 : 64 MFMA | 16 ds_read (tile t+1, k-half 0) | 16 LDS-DMA (tile t+2)
+//     RAW: a tile's DMA is issued one full half-step (>= 1000 cycles) before the vmcnt(0)+barrier that
+//     publishes it.  WAR: every ds_read of buffer t&1 has returned (lgkmcnt(0)) before the barrier that
+//     precedes its restaging.
+#include "sf_api_internal.h"
+#include "sf_util.h"
+#include <stdlib.h>
+#include <type_traits>
+
+#define SF_INLINE_LAMBDA __attribute__((always_inline))
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int kOpBytes = 256 * TK * 2;       // 32 KiB: one operand's K-tile
+constexpr int kBufBytes = 2 * kOpBytes;      // A + B
+
+struct GemmW4Args {
+    const sf_bf16* A; long lda;
+    const sf_bf16* B; long ldb;
+    void* C; long ldc;
+    const sf_bf16* R; long ldr;
+    int M, N, K;
+    float alpha, beta;
+    int tiles_m, tiles_n;
+    int gm;
+};
+
+#ifdef SF_EMU
+SF_DEVICE void w4_barrier() { sfemu::block_barrier(); }
+SF_DEVICE void w4_wait_all() {}
+SF_DEVICE void w4_fence() {}
+#else
+SF_DEVICE void w4_barrier() { __builtin_amdgcn_s_barrier(); }
+SF_DEVICE void w4_wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+SF_DEVICE void w4_fence() { __builtin_amdgcn_sched_barrier(0); }
+#endif
+
+SF_DEVICE void w4_tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int GM, int& tm, int& tn) {
+    const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    const int per_group = GM * tiles_n;
+    const int g = seq / per_group;
+    const int first_m = g * GM;
+    const int gsize = (tiles_m - first_m < GM) ? (tiles_m - first_m) : GM;
+    const int in_g = seq - g * per_group;
+    tm = first_m + in_g % gsize;
+    tn = in_g / gsize;
+}
+
+// C[m][n..n+3] = alpha*v (+beta*C) (+R), bf16 or fp32 output, ragged N handled
+template <int OUT_F32>
+SF_DEVICE void w4_store4(const GemmW4Args& p, int m, int n, sf_v4f acc) {
+    if (m >= p.M || n >= p.N) return;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] * p.alpha;
+    const bool full = (n + 3 < p.N);
+    if (OUT_F32) {
+        float* c = (float*)p.C + (long)m * p.ldc + n;
+        if (full) {
+            if (p.beta != 0.f) {
+                sf_v4f o = *reinterpret_cast<const sf_v4f*>(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += p.beta * o[r];
+            }
+            *reinterpret_cast<sf_v4f*>(c) = sf_v4f{v[0], v[1], v[2], v[3]};
+        } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = v[r] + (p.beta != 0.f ? p.beta * c[r] : 0.f);
+        }
+    } else {
+        sf_bf16* c = (sf_bf16*)p.C + (long)m * p.ldc + n;
+        if (full) {
+            if (p.beta != 0.f) {
+                sf_v4s o = *reinterpret_cast<const sf_v4s*>(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += p.beta * sf_bf2f((sf_bf16)o[r]);
+            }
+            if (p.R) {  // round the projection first, then add the residual (bf16 + bf16)
+                sf_v4s rr = *reinterpret_cast<const sf_v4s*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = sf_round_bf(v[r]) + sf_bf2f((sf_bf16)rr[r]);
+            }
+            sf_v4s o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (short)sf_f2bf(v[r]);
+            *reinterpret_cast<sf_v4s*>(c) = o;
+        } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                float t2 = v[r] + (p.beta != 0.f ? p.beta * sf_bf2f(c[r]) : 0.f);
+                if (p.R) t2 = sf_round_bf(t2) + sf_bf2f(p.R[(long)m * p.ldr + n + r]);
+                c[r] = sf_f2bf(t2);
+            }
+        }
+    }
+}
+
+template <int OUT_F32>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
+    SF_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
+    const int wr = wave >> 1, wc = wave & 1;
+    int tm, tn;
+    w4_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int nkt = p.K / TK;
+
+    // ---- DMA sources: this wave stages pieces 8*wave .. 8*wave+7 (8 rows x 128 B each) of A and of B.
+    // Rows past the matrix edge re-read the last valid row: they only feed accumulators that are never stored.
+    // (Register allocation of this kernel is fragile: running 64-bit pointers + a peeled tail allocate cleanly --
+    // 188 VGPR + 256 AGPR, no copies in the loop; a uniform loop body with clamped tile indices made the
+    // compiler shuffle accumulators through VGPRs and lost 30 %.)
+    const int srow = lane >> 3;
+    const int slc = (lane & 7) ^ (srow & 7);  // logical 16-byte chunk fetched into physical chunk lane&7
+    const sf_bf16* src[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int ra = m0 + (8 * wave + j) * 8 + srow, rb = n0 + (8 * wave + j) * 8 + srow;
+        ra = ra < p.M ? ra : p.M - 1;
+        rb = rb < p.N ? rb : p.N - 1;
+        src[j] = p.A + (long)ra * p.lda + slc * 8;
+        src[8 + j] = p.B + (long)rb * p.ldb + slc * 8;
+    }
+    auto dma = [&](int g, int kt) {  // piece g (0..7 A, 8..15 B) of the next un-issued K-tile into buffer kt&1
+        char* dst = smem + (kt & 1) * kBufBytes + (g >> 3) * kOpBytes + (8 * wave + (g & 7)) * 1024;
+        sf_glds16(src[g], dst);
+        src[g] += TK;
+    };
+
+    // ---- fragment read offsets; (row & 7) == (lane & 7) for every fragment row
+    const int frow = lane & 15;
+    int swz[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) swz[ks] = ((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
+    const int a_off = (wr * 128 + frow) * 128;
+    const int b_off = kOpBytes + (wc * 128 + frow) * 128;
+
+    sf_v4f acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
+    sf_v8s f[2][16];  // [set][0..7 = B n-tiles, 8..15 = A m-tiles]
+
+    auto read_frag = [&](int set, int g, const char* buf, int ks) {
+        if (g < 8) f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + b_off + g * 2048 + swz[ks]);
+        else f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + a_off + (g - 8) * 2048 + swz[ks]);
+    };
+
+    // ---- prologue: K-tiles 0 and 1 staged, fragments of half-step 0 in registers
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dma(g, 0);
+    if (nkt > 1) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dma(g, 1);
+    }
+    w4_wait_all();
+    w4_barrier();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) read_frag(0, g, smem, 0);
+
+    // one K-tile: READ_NEXT = tile t+1 exists, DO_DMA = tile t+2 exists
+    auto tile = [&](auto READ_NEXT, auto DO_DMA, int t) {
+        const char* cur = smem + (t & 1) * kBufBytes;
+        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
+        // ---- half-step 2t: compute set 0; fragments of k-half 1 -> set 1 (two reads per group, front-loaded)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
+                acc[mt][nt] = sf_mfma16(f[0][nt], f[0][8 + mt], acc[mt][nt]);
+            }
+            if (g < 8) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
+            w4_fence();
+        }
+        w4_wait_all();   // my pieces of tile t+1 have landed; my reads of buffer t&1 have returned
+        w4_barrier();    // -> tile t+1 visible to everyone, buffer t&1 free for tile t+2
+        // ---- half-step 2t+1: compute set 1; fragments of (t+1, k-half 0) -> set 0; stage tile t+2
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
+                acc[mt][nt] = sf_mfma16(f[1][nt], f[1][8 + mt], acc[mt][nt]);
+            }
+            // reads front-loaded (groups 0..11) so that the next half-step's first MFMA never waits on them
+            if constexpr (decltype(READ_NEXT)::value) {
+                if (g < 4) { read_frag(0, 2 * g, nxt, 0); read_frag(0, 2 * g + 1, nxt, 0); }
+                else if (g < 12) read_frag(0, g + 4, nxt, 0);
+            }
+            if constexpr (decltype(DO_DMA)::value) dma(g, t + 2);
+            w4_fence();
+        }
+    };
+
+    int t = 0;
+    for (; t + 2 < nkt; ++t) tile(std::true_type{}, std::true_type{}, t);
+    if (t + 1 < nkt) { tile(std::true_type{}, std::false_type{}, t); ++t; }
+    tile(std::false_type{}, std::false_type{}, t);
+
+    // ---- epilogue: lane owns C[m][n..n+3]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            w4_store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Same structure with mfma_f32_32x32x16_bf16: per flop it reads half the operand and accumulator
+// registers of the 16x16x32 form and issues half the instructions.  Every GEMM of the training step is
+// POWER-limited on real (non-zero) data -- zero-filled operands run the same kernels ~20 % faster at a
+// higher clock -- so energy per flop, not issue slots, is what this variant buys.
+//   wave block 128 x 128 = 4 x 4 tiles of 32 x 32 (16 accumulator registers each);
+//   a K-tile is four k16-steps of 16 MFMAs; fragment sets (4 B + 4 A ds_read_b128) are double-buffered;
+//   the barrier sits after k16-step 2 (all reads of the tile issued and returned); k16-step 3 reads the next
+//   tile's first fragments and stages the A pieces of tile t+2, k16-step 0 of the next tile stages its B pieces.
+//   LDS chunk swizzle: physical = logical ^ ((row >> 1) & 7) (conflict-free for 32-row fragments).
+template <int OUT_F32>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4m32_kernel(GemmW4Args p) {
+    SF_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
+    const int wr = wave >> 1, wc = wave & 1;
+    int tm, tn;
+    w4_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int nkt = p.K / TK;
+
+    const int srow = lane >> 3;
+    const char* tileA = (const char*)(p.A + (long)m0 * p.lda);
+    const char* tileB = (const char*)(p.B + (long)n0 * p.ldb);
+    unsigned off[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = (8 * wave + j) * 8 + srow;               // LDS row of this lane's 16 bytes
+        const int slc = (lane & 7) ^ ((r >> 1) & 7);           // logical chunk fetched into physical chunk lane&7
+        const int ra = m0 + r < p.M ? r : p.M - 1 - m0;
+        const int rb = n0 + r < p.N ? r : p.N - 1 - n0;
+        off[j] = (unsigned)(((long)ra * p.lda + slc * 8) * 2);
+        off[8 + j] = (unsigned)(((long)rb * p.ldb + slc * 8) * 2);
+    }
+    // piece g (0..7 A, 8..15 B) of K-tile kt into buffer kt&1.  A "tile" past the end re-fetches tile nkt-1 into a
+    // buffer nobody reads again, which keeps the loop body free of tail cases (2 redundant L2-resident tiles per
+    // workgroup).
+    auto dma = [&](int g, int kt) {
+        char* dst = smem + (kt & 1) * kBufBytes + (g >> 3) * kOpBytes + (8 * wave + (g & 7)) * 1024;
+        const int kc = kt < nkt ? kt : nkt - 1;
+        sf_glds16((g < 8 ? tileA : tileB) + (long)kc * (TK * 2) + off[g], dst);
+    };
+
+    const int frow = lane & 31, hi = lane >> 5;
+    int swz[4];  // k16-step ks: logical chunk 2*ks + hi
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) swz[ks] = ((2 * ks + hi) ^ ((lane >> 1) & 7)) << 4;
+    const int a_off = (wr * 128 + frow) * 128;
+    const int b_off = kOpBytes + (wc * 128 + frow) * 128;
+
+    sf_v16f acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    sf_v8s f[2][8];  // [set][0..3 = B n-tiles, 4..7 = A m-tiles]
+
+    auto read_frag = [&](int set, int g, const char* buf, int ks) {
+        if (g < 4) f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + b_off + g * 4096 + swz[ks]);
+        else f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + a_off + (g - 4) * 4096 + swz[ks]);
+    };
+
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dma(g, 0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) dma(g, 1);   // A pieces of tile 1; its B pieces follow in k16-step 0 of tile 0
+    w4_wait_all();
+    w4_barrier();
+#pragma unroll
+    for (int g = 0; g < 8; ++g) read_frag(0, g, smem, 0);
+
+    for (int t = 0; t < nkt; ++t) {
+        const char* cur = smem + (t & 1) * kBufBytes;
+        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
+        auto quarter = [&](auto QC) SF_INLINE_LAMBDA {
+            constexpr int q = decltype(QC)::value;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int mt = i >> 2, nt = i & 3;
+                acc[mt][nt] = sf_mfma32(f[q & 1][nt], f[q & 1][4 + mt], acc[mt][nt]);
+                if (i < 8) {  // the next k16-step's fragments, front-loaded
+                    if constexpr (q < 3) read_frag((q + 1) & 1, i, cur, q + 1);
+                    else read_frag(0, i, nxt, 0);
+                } else {
+                    if constexpr (q == 0) dma(8 + (i - 8), t + 1);   // B pieces of tile t+1
+                    if constexpr (q == 3) dma(i - 8, t + 2);         // A pieces of tile t+2
+                }
+                w4_fence();
+            }
+        };
+        quarter(std::integral_constant<int, 0>{});
+        quarter(std::integral_constant<int, 1>{});
+        quarter(std::integral_constant<int, 2>{});
+        w4_wait_all();   // my pieces of tile t+1 have landed; my reads of buffer t&1 have returned
+        w4_barrier();    // -> tile t+1 visible to everyone, buffer t&1 free for tile t+2
+        quarter(std::integral_constant<int, 3>{});
+    }
+    sf_wait_vm0();  // no LDS-DMA may land after this workgroup's LDS has been handed to the next one
+
+    // ---- epilogue: D[n][m] layout of the swapped 32x32 MFMA: lane owns m = lane&31 and, per register quad q,
+    // n = 8q + 4hi + 0..3
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w4_store4<OUT_F32>(p, m0 + wr * 128 + i * 32 + (lane & 31), n0 + wc * 128 + j * 32 + 8 * q + 4 * hi,
+                                   sf_v4f{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
+}
+
+}  // namespace
+
+#ifdef SF_EMU
+#define SF_W4_SMEM(kernel)
+#else
+#define SF_W4_SMEM(kernel)                                                                                       \
+    do {                                                                                                         \
+        static bool done_ = false;                                                                               \
+        if (!done_) {                                                                                            \
+            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes); \
+            (void)hipGetLastError();                                                                             \
+            done_ = true;                                                                                        \
+        }                                                                                                        \
+    } while (0)
+#endif
+
+// launched by sf_gemm_nt (sf_gemm.hip) when the shape qualifies
+int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M,
+                            int N, int K, float alpha, float beta, const void* R, long ldr, void* stream) {
+    GemmW4Args p;
+    p.A = (const sf_bf16*)A; p.lda = lda;
+    p.B = (const sf_bf16*)B; p.ldb = ldb;
+    p.C = C; p.ldc = ldc;
+    p.R = (const sf_bf16*)R; p.ldr = ldr;
+    p.M = M; p.N = N; p.K = K;
+    p.alpha = alpha; p.beta = beta;
+    p.tiles_m = (M + TM - 1) / TM;
+    p.tiles_n = (N + TN - 1) / TN;
+    { const char* e = getenv("SF_GEMM_GM"); p.gm = e ? atoi(e) : 4; if (p.gm < 1) p.gm = 1; }
+    const long nblk = (long)p.tiles_m * p.tiles_n;
+    static const bool m32 = [] { const char* e = getenv("SF_GEMM_MFMA"); return e ? atoi(e) == 32 : false; }();
+    if (m32) {
+        if (c_dtype == SF_F32) {
+            SF_W4_SMEM((gemm_nt_256w4m32_kernel<1>));
+            SF_LAUNCH((gemm_nt_256w4m32_kernel<1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+        } else {
+            SF_W4_SMEM((gemm_nt_256w4m32_kernel<0>));
+            SF_LAUNCH((gemm_nt_256w4m32_kernel<0>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+        }
+        return sf_check_launch("sf_gemm_nt(256w4m32)");
+    }
+    if (c_dtype == SF_F32) {
+        SF_W4_SMEM((gemm_nt_256w4_kernel<1>));
+        SF_LAUNCH((gemm_nt_256w4_kernel<1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+    } else {
+        SF_W4_SMEM((gemm_nt_256w4_kernel<0>));
+        SF_LAUNCH((gemm_nt_256w4_kernel<0>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+    }
+    return sf_check_launch("sf_gemm_nt(256w4)");
+}
