@@ -58,6 +58,19 @@ int sf_ce_fused(void* logits, int dtype, long ld, int rows, int V, const float* 
                 int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred,
                 void* stream);
 
+/* ---- LK-loss gradient (optional objective, lk_loss_type in {"alpha","lambda"}) ----------------
+ * replaces the autograd path through specforge/core/lk_loss.py:43-99 selected at
+ * specforge/algorithms/eagle3/model.py:78-96.  Overwrites the logits of one TTT step with
+ * d(step_scale * lk_loss)/d(logits).  lk_mode 1 = "alpha" (-masked mean log acceptance), 2 = "lambda"
+ * (w*KL + (1-w)(1-acceptance), w = kl_scale*exp(-kl_decay*acceptance) detached).  kl_row_scale is
+ * the KL mean factor 1/(B*S); accept_sum / mask_sum are device scalars: sum_r pos_mask_r*accept_r
+ * (third output of sf_ce_fused, reduced) and sum_r pos_mask_r over the rows of this step.
+ * Masked rows get zero gradient; ties of torch.minimum split the gradient evenly as torch does. */
+int sf_ce_lk_grad(void* logits, int dtype, long ld, int rows, int V, const float* target, int S, int Spad, int off,
+                  const int* pos_mask_pad, const float* pod_scale_pad, const float* tsum_pad, int lk_mode,
+                  float kl_scale, float kl_decay, float step_scale, float kl_row_scale, const float* accept_sum,
+                  const float* mask_sum, void* stream);
+
 /* out[i] = scale * sum(in[i*n : (i+1)*n]) in a fixed order (double accumulation): deterministic
  * replacement of the .sum()/.mean() reductions in eagle3/model.py:161-190. */
 int sf_reduce_sum(const float* in, long n, int nsegments, float* out, float scale, void* stream);
@@ -98,6 +111,9 @@ int sf_swiglu_bwd(const void* dact, int dtype, long lddact, const void* gu, long
  * images of the attention kernels (no reference equivalent: autograd transposes are views). */
 int sf_transpose(const void* in, int dtype, long in_b1, long in_b2, long in_ld, void* out, long out_b1, long out_b2,
                  long out_ld, int nb1, int nb2, int R, int C, void* stream);
+/* out = a + b over n bf16 elements (n % 8 == 0; fp32 add, one rounding): the gradient sum autograd forms where the
+ * un-normed hidden state feeds both lm_head and the next TTT step when norm_output=False (llama3_eagle.py:1772-1777). */
+int sf_add_bf16(long n, const void* a, const void* b, void* out, void* stream);
 /* y = (accumulate ? y : 0) + alpha*x, fp32: carries norm-weight gradients across micro-steps. */
 int sf_axpy_f32(long n, float alpha, const float* x, float* y, int accumulate, void* stream);
 int sf_cast_from_f32(const float* in, long ldin, void* out, int dtype, long ldout, long rows, int C, float scale,

@@ -127,8 +127,8 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     return w * xf.to(dt)
 
 
-def rope_inv_freq(cfg: DraftConfig) -> torch.Tensor:
-    """inv_freq incl. the llama3 / linear variants (llama3_eagle.py:235-276,315-340)."""
+def rope_inv_freq(cfg: DraftConfig, n_pos: Optional[int] = None) -> torch.Tensor:
+    """inv_freq incl. the llama3 / linear / dynamic-NTK / yarn variants (llama3_eagle.py:235-276,315-540)."""
     dim = cfg.head_dim
     inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, dim, 2).float() / dim))
     rs = cfg.rope_scaling
@@ -151,20 +151,45 @@ def rope_inv_freq(cfg: DraftConfig) -> torch.Tensor:
         )
     if rtype == "linear":
         return inv_freq  # positions are scaled instead, see rope_tables
+    if rtype == "dynamic":  # llama3_eagle.py:361-372, evaluated for the pre-built cache length (281-285)
+        seq_len = n_pos if n_pos is not None else cfg.max_position_embeddings + 20
+        if seq_len <= cfg.max_position_embeddings:
+            return inv_freq
+        f = rs["factor"]
+        base = cfg.rope_theta * ((f * seq_len / cfg.max_position_embeddings) - (f - 1)) ** (dim / (dim - 2))
+        return 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+    if rtype == "yarn":  # llama3_eagle.py:430-508
+        f, orig, base = rs["factor"], rs["original_max_position_embeddings"], cfg.rope_theta
+
+        def corr(rot):
+            return (dim * math.log(orig / (rot * 2 * math.pi))) / (2 * math.log(base))
+
+        low, high = max(math.floor(corr(rs["beta_fast"])), 0), min(math.ceil(corr(rs["beta_slow"])), dim - 1)
+        if low == high:
+            high += 0.001
+        ramp = torch.clamp((torch.arange(dim // 2, dtype=torch.float32) - low) / (high - low), 0, 1)
+        mask = 1.0 - ramp
+        pw = base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim)
+        return (1.0 / (f * pw)) * (1 - mask) + (1.0 / pw) * mask
     raise NotImplementedError(f"oracle: rope type {rtype}")
 
 
 def rope_tables(cfg: DraftConfig, n_pos: int, dtype=torch.float32) -> Tuple[torch.Tensor, torch.Tensor]:
     """cos/sin cache ``[n_pos, head_dim]`` built in fp32 then cast to the activation
-    dtype (llama3_eagle.py:287-312)."""
-    inv_freq = rope_inv_freq(cfg)
+    dtype (llama3_eagle.py:287-312); yarn scales both by mscale/mscale_all_dim (510-540)."""
+    inv_freq = rope_inv_freq(cfg, n_pos)
     t = torch.arange(n_pos, dtype=inv_freq.dtype)
     rs = cfg.rope_scaling or {}
-    if rs.get("rope_type", rs.get("type")) == "linear":
+    rtype = rs.get("rope_type", rs.get("type"))
+    if rtype == "linear":
         t = t / rs["factor"]
+    amp = 1.0
+    if rtype == "yarn":
+        ms = lambda scale, m: 1.0 if scale <= 1 else 0.1 * m * math.log(scale) + 1.0
+        amp = float(ms(rs["factor"], rs["mscale"]) / ms(rs["factor"], rs["mscale_all_dim"]))
     freqs = torch.einsum("i,j->ij", t, inv_freq)
     emb = torch.cat((freqs, freqs), dim=-1)
-    return emb.cos().to(dtype), emb.sin().to(dtype)
+    return (emb.cos() * amp).to(dtype), (emb.sin() * amp).to(dtype)
 
 
 def rotate_half(x: torch.Tensor) -> torch.Tensor:
@@ -304,6 +329,26 @@ def acceptance_rate(logits, target_p_on_draft, position_mask, eps=1e-8):
     return (per_tok * mask).sum() / mask.sum().clamp_min(eps)
 
 
+def acceptance_and_log_rate(logits, target_p_on_draft, position_mask, eps=1e-8):
+    """both outputs of ``compute_acceptance_rate`` (core/lk_loss.py:52-80), differentiable."""
+    dp = torch.softmax(logits.to(torch.float32), dim=-1).to(target_p_on_draft.dtype)
+    per_tok = torch.minimum(target_p_on_draft, dp).sum(-1)
+    mask = position_mask.squeeze(-1).to(per_tok.dtype)
+    den = mask.sum().clamp_min(eps)
+    log_tok = torch.where(per_tok > 0, torch.log(per_tok), torch.zeros_like(per_tok))
+    return (per_tok * mask).sum() / den, (log_tok * mask).sum() / den
+
+
+def lk_loss(kl_loss, acc_rate, log_acc_rate, lk_loss_type: str, kl_scale: float, kl_decay: float):
+    """``compute_lk_loss`` (core/lk_loss.py:83-99)."""
+    if lk_loss_type == "alpha":
+        return -log_acc_rate
+    if lk_loss_type == "lambda":
+        w = kl_scale * torch.exp(-kl_decay * acc_rate.detach())
+        return w * kl_loss + (1 - w) * (1 - acc_rate)
+    raise ValueError(f"Unknown lk loss type: {lk_loss_type}")
+
+
 @dataclass
 class Eagle3Out:
     plosses: List[torch.Tensor] = field(default_factory=list)
@@ -334,6 +379,9 @@ def eagle3_forward(
     ploss_decay: float = 0.8,
     position_ids: Optional[torch.Tensor] = None,
     keep_logits: bool = False,
+    lk_loss_type: Optional[str] = None,
+    kl_scale: float = 1.0,
+    kl_decay: float = 1.0,
 ) -> Eagle3Out:
     """``Eagle3TrainStrategy.forward_loss`` -> ``OnlineEagle3Model.forward``
     (training/strategies/base.py:237-304; algorithms/eagle3/model.py:244-442),
@@ -378,8 +426,15 @@ def eagle3_forward(
             out.acc_corrects.append(correct)
             out.acc_denoms.append(denom)
             out.acces.append(correct / denom)
-            out.acceptance_rates.append(acceptance_rate(logits, tpod, g_pm))
-        out.plosses.append(soft_ce_loss(logits, tp, g_pm))
+        kl = soft_ce_loss(logits, tp, g_pm)
+        if lk_loss_type is None:   # eagle3/model.py:78: acceptance under no_grad unless an LK objective is on
+            with torch.no_grad():
+                out.acceptance_rates.append(acceptance_rate(logits, tpod, g_pm))
+            out.plosses.append(kl)
+        else:
+            acc_rate, log_acc = acceptance_and_log_rate(logits, tpod, g_pm)
+            out.acceptance_rates.append(acc_rate.detach())
+            out.plosses.append(lk_loss(kl, acc_rate, log_acc, lk_loss_type, kl_scale, kl_decay))
         if idx != ttt_length - 1:
             g_ids = padding_left_shift(g_ids)
             g_pm = padding_left_shift(g_pm)

@@ -44,7 +44,8 @@ from oracle.eagle3_oracle import make_batch, make_vocab_mapping, DraftConfig  # 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
-def run_case(name, *, H, Ht, I, nh, nkv, hd, Vt, Vd, B, S, lengths, ttt, dtype, fc_norm=False, rope_scaling=None, seed=0):
+def run_case(name, *, H, Ht, I, nh, nkv, hd, Vt, Vd, B, S, lengths, ttt, dtype, fc_norm=False, rope_scaling=None, seed=0,
+             lk_loss_type=None, kl_scale=1.0, kl_decay=1.0, norm_output=True):
     torch.manual_seed(seed)
     cfg = LlamaConfig(
         hidden_size=H, intermediate_size=I, num_attention_heads=nh, num_key_value_heads=nkv,
@@ -56,6 +57,7 @@ def run_case(name, *, H, Ht, I, nh, nkv, hd, Vt, Vd, B, S, lengths, ttt, dtype, 
     cfg.draft_vocab_size = Vd
     cfg.target_hidden_size = Ht
     cfg.fc_norm = fc_norm
+    cfg.norm_output = norm_output
     model = LlamaForCausalLMEagle3(cfg, attention_backend="sdpa")
     # non-trivial norm weights so their gradients are exercised
     with torch.no_grad():
@@ -70,10 +72,12 @@ def run_case(name, *, H, Ht, I, nh, nkv, hd, Vt, Vd, B, S, lengths, ttt, dtype, 
     head_w = torch.randn(Vt, Ht).to(dtype)
     ocfg = DraftConfig(hidden_size=H, intermediate_size=I, num_attention_heads=nh, num_key_value_heads=nkv,
                        vocab_size=Vt, draft_vocab_size=Vd, head_dim=hd, target_hidden_size=Ht,
-                       max_position_embeddings=128, rms_norm_eps=1e-5, fc_norm=fc_norm, rope_scaling=rope_scaling)
+                       max_position_embeddings=128, rms_norm_eps=1e-5, fc_norm=fc_norm, rope_scaling=rope_scaling,
+                       norm_output=norm_output)
     batch = make_batch(ocfg, B, S, seed=seed + 1, dtype=dtype, lengths=lengths)
 
-    eagle = ref_model.OnlineEagle3Model(model, length=ttt, attention_backend="sdpa")
+    eagle = ref_model.OnlineEagle3Model(model, length=ttt, attention_backend="sdpa", lk_loss_type=lk_loss_type,
+                                        kl_scale=kl_scale, kl_decay=kl_decay)
     # Eagle3TrainStrategy.forward_loss glue (training/strategies/base.py:237-304)
     input_ids, target, loss_mask = TargetHead.preprocess(None, batch["input_ids"], batch["target"], batch["loss_mask"])
     target_logits = F.linear(target, head_w)
@@ -92,10 +96,12 @@ def run_case(name, *, H, Ht, I, nh, nkv, hd, Vt, Vd, B, S, lengths, ttt, dtype, 
     assert torch.equal(cids, ids) and torch.equal(cpm, pm)
 
     params = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
-    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+    grads = {n: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+             for n, p in model.named_parameters() if p.requires_grad}
     blob = dict(
         cfg=dict(H=H, Ht=Ht, I=I, nh=nh, nkv=nkv, hd=hd, Vt=Vt, Vd=Vd, ttt=ttt, eps=1e-5, fc_norm=fc_norm,
-                 max_pos=128, rope_scaling=rope_scaling),
+                 max_pos=128, rope_scaling=rope_scaling, lk_loss_type=lk_loss_type, kl_scale=kl_scale, kl_decay=kl_decay,
+                 norm_output=norm_output),
         dtype=str(dtype), params=params, grads=grads,
         embed=model.embed_tokens.weight.detach().clone(), head_w=head_w, t2d=t2d, d2t=d2t, batch=batch,
         plosses=torch.stack([p.detach().float() for p in plosses]),
@@ -153,13 +159,29 @@ def run_sampler_case():
 
 
 if __name__ == "__main__":
+    import sys
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])   # e.g. `python oracle/gen_golden.py lk rope` regenerates just those groups
+    want = lambda g: not only or g in only
     common = dict(Ht=128, I=256, nh=2, nkv=1, hd=128, Vt=512, Vd=128, B=2, S=32, lengths=[32, 23])
-    run_case("eagle3_tiny_fp32", H=128, ttt=4, dtype=torch.float32, **common)
-    run_case("eagle3_tiny_bf16", H=128, ttt=4, dtype=torch.bfloat16, **common)
-    run_case("eagle31_gqa_fp32", H=128, Ht=96, I=192, nh=4, nkv=2, hd=64, Vt=640, Vd=256, B=1, S=48,
-             lengths=[48], ttt=7, dtype=torch.float32, fc_norm=True,
-             rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
-                               original_max_position_embeddings=64))
-    run_optimizer_case()
-    run_sampler_case()
+    if want("base"):
+        run_case("eagle3_tiny_fp32", H=128, ttt=4, dtype=torch.float32, **common)
+        run_case("eagle3_tiny_bf16", H=128, ttt=4, dtype=torch.bfloat16, **common)
+        run_case("eagle31_gqa_fp32", H=128, Ht=96, I=192, nh=4, nkv=2, hd=64, Vt=640, Vd=256, B=1, S=48,
+                 lengths=[48], ttt=7, dtype=torch.float32, fc_norm=True,
+                 rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                   original_max_position_embeddings=64))
+        run_optimizer_case()
+        run_sampler_case()
+    if want("lk"):   # LK objectives (core/lk_loss.py:83-99) and norm_output=False (llama3_eagle.py:1772-1777)
+        run_case("eagle3_lk_alpha_fp32", H=128, ttt=3, dtype=torch.float32, lk_loss_type="alpha", seed=5, **common)
+        run_case("eagle3_lk_lambda_fp32", H=128, ttt=3, dtype=torch.float32, lk_loss_type="lambda", kl_scale=0.7,
+                 kl_decay=1.5, seed=6, **common)
+        run_case("eagle3_nonorm_fp32", H=128, ttt=3, dtype=torch.float32, norm_output=False, seed=7, **common)
+    if want("rope"):  # yarn / dynamic-NTK tables (llama3_eagle.py:347-386,430-540)
+        small = dict(H=128, Ht=96, I=192, nh=4, nkv=2, hd=64, Vt=640, Vd=256, B=1, S=48, lengths=[40], ttt=2,
+                     dtype=torch.float32)
+        run_case("eagle3_rope_yarn_fp32", rope_scaling=dict(rope_type="yarn", factor=4.0, beta_fast=32, beta_slow=1,
+                                                             mscale=1.0, mscale_all_dim=0.5,
+                                                             original_max_position_embeddings=32), seed=8, **small)
+        run_case("eagle3_rope_dynamic_fp32", rope_scaling=dict(rope_type="dynamic", factor=2.0), seed=9, **small)

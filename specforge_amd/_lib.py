@@ -25,6 +25,8 @@ _SIGS = {
     "sf_gemm_nt": (c_int, [P, c_long, P, c_long, P, c_int, c_long, c_int, c_int, c_int, c_float, c_float, P, c_long, P]),
     "sf_ce_fused": (c_int, [P, c_int, c_long, c_int, c_int, P, c_int, c_int, c_int, P, P, P, P, P, P, c_float, c_int,
                             P, P, P, P, P]),
+    "sf_ce_lk_grad": (c_int, [P, c_int, c_long, c_int, c_int, P, c_int, c_int, c_int, P, P, P, c_int, c_float, c_float,
+                              c_float, c_float, P, P, P]),
     "sf_reduce_sum": (c_int, [P, c_long, c_int, P, c_float, P]),
     "sf_teacher_reduce": (c_int, [P, c_int, c_long, c_int, c_int, c_int, P, P, P, c_int, c_int, P, P, P, P, P, P]),
     "sf_rmsnorm_fwd": (c_int, [P, c_int, c_long, P, c_int, c_int, c_int, P, c_float, c_int, c_int, P, c_long, P, P]),
@@ -36,6 +38,7 @@ _SIGS = {
     "sf_swiglu_bwd": (c_int, [P, c_int, c_long, P, c_long, c_long, c_int, P, c_long, P]),
     "sf_transpose": (c_int, [P, c_int, c_long, c_long, c_long, P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P]),
     "sf_axpy_f32": (c_int, [c_long, c_float, P, P, c_int, P]),
+    "sf_add_bf16": (c_int, [c_long, P, P, P, P]),
     "sf_cast_from_f32": (c_int, [P, c_long, P, c_int, c_long, c_long, c_int, c_float, P]),
     "sf_attn_fwd": (c_int, [P, c_long, P, c_long, P, P, P, c_int, P, P, c_long, P, c_int, c_int, c_int, c_int, c_int,
                             c_float, P]),

@@ -48,10 +48,12 @@ struct GemmW4Args {
 #ifdef SF_EMU
 SF_DEVICE void w4_barrier() { sfemu::block_barrier(); }
 SF_DEVICE void w4_wait_all() {}
+SF_DEVICE void w4_wait_lgkm() {}
 SF_DEVICE void w4_fence() {}
 #else
 SF_DEVICE void w4_barrier() { __builtin_amdgcn_s_barrier(); }
 SF_DEVICE void w4_wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+SF_DEVICE void w4_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 SF_DEVICE void w4_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
 
@@ -114,7 +116,8 @@ SF_DEVICE void w4_store4(const GemmW4Args& p, int m, int n, sf_v4f acc) {
     }
 }
 
-template <int OUT_F32>
+// ABL (timing ablations only, results are wrong): bit0 = no ds_reads after the first tile, bit1 = no DMA in the loop
+template <int OUT_F32, int ABL = 0>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     SF_DYN_SMEM(smem);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
@@ -190,9 +193,10 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                 const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
                 acc[mt][nt] = sf_mfma16(f[0][nt], f[0][8 + mt], acc[mt][nt]);
             }
-            if (g < 8) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
+            if (g < 8 && !((ABL & 1) && t > 0)) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
             w4_fence();
         }
+        if constexpr (ABL & 8) w4_wait_lgkm(); else
         w4_wait_all();   // my pieces of tile t+1 have landed; my reads of buffer t&1 have returned
         w4_barrier();    // -> tile t+1 visible to everyone, buffer t&1 free for tile t+2
         // ---- half-step 2t+1: compute set 1; fragments of (t+1, k-half 0) -> set 0; stage tile t+2
@@ -204,11 +208,14 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                 acc[mt][nt] = sf_mfma16(f[1][nt], f[1][8 + mt], acc[mt][nt]);
             }
             // reads front-loaded (groups 0..11) so that the next half-step's first MFMA never waits on them
-            if constexpr (decltype(READ_NEXT)::value) {
+            if constexpr (decltype(READ_NEXT)::value && !(ABL & 1)) {
                 if (g < 4) { read_frag(0, 2 * g, nxt, 0); read_frag(0, 2 * g + 1, nxt, 0); }
                 else if (g < 12) read_frag(0, g + 4, nxt, 0);
             }
-            if constexpr (decltype(DO_DMA)::value) dma(g, t + 2);
+            if constexpr (decltype(DO_DMA)::value && !(ABL & 2)) {
+                if constexpr (ABL & 4) { if (g < 8) { dma(2 * g, t + 2); dma(2 * g + 1, t + 2); } }
+                else dma(g, t + 2);
+            }
             w4_fence();
         }
     };
@@ -224,6 +231,113 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             w4_store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// 8-wave form of the same loop (2 x 4 waves, 128 x 64 per wave, two waves per SIMD): identical
+// single-barrier-per-K-tile software pipeline, but every SIMD has a second wave whose MFMAs cover the
+// ~60 cycles a wave is stuck issuing each LDS-DMA instruction (measured: in the 4-wave form the DMA issue
+// alone costs 25 % of the MFMA-only rate).  Unlike the ping-pong kernel nothing alternates the two waves
+// explicitly; the hardware arbitrates.
+template <int OUT_F32>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256w8_kernel(GemmW4Args p) {
+    SF_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
+    const int wr = wave >> 2, wc = wave & 3;
+    int tm, tn;
+    w4_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int nkt = p.K / TK;
+
+    // ---- DMA sources: this wave stages pieces 4*wave .. 4*wave+3 (8 rows x 128 B each) of A and of B
+    const int srow = lane >> 3;
+    const int slc = (lane & 7) ^ (srow & 7);
+    const sf_bf16* src[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ra = m0 + (4 * wave + j) * 8 + srow, rb = n0 + (4 * wave + j) * 8 + srow;
+        ra = ra < p.M ? ra : p.M - 1;
+        rb = rb < p.N ? rb : p.N - 1;
+        src[j] = p.A + (long)ra * p.lda + slc * 8;
+        src[4 + j] = p.B + (long)rb * p.ldb + slc * 8;
+    }
+    auto dma = [&](int g, int kt) {  // piece g (0..3 A, 4..7 B) of the next un-issued K-tile into buffer kt&1
+        char* dst = smem + (kt & 1) * kBufBytes + (g >> 2) * kOpBytes + (4 * wave + (g & 3)) * 1024;
+        sf_glds16(src[g], dst);
+        src[g] += TK;
+    };
+
+    const int frow = lane & 15;
+    int swz[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) swz[ks] = ((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
+    const int a_off = (wr * 128 + frow) * 128;
+    const int b_off = kOpBytes + (wc * 64 + frow) * 128;
+
+    sf_v4f acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
+    sf_v8s f[2][12];  // [set][0..3 = B n-tiles, 4..11 = A m-tiles]
+
+    auto read_frag = [&](int set, int g, const char* buf, int ks) {
+        if (g < 4) f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + b_off + g * 2048 + swz[ks]);
+        else f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + a_off + (g - 4) * 2048 + swz[ks]);
+    };
+
+#pragma unroll
+    for (int g = 0; g < 8; ++g) dma(g, 0);
+    if (nkt > 1) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) dma(g, 1);
+    }
+    w4_wait_all();
+    w4_barrier();
+#pragma unroll
+    for (int g = 0; g < 12; ++g) read_frag(0, g, smem, 0);
+
+    auto tile = [&](auto READ_NEXT, auto DO_DMA, int t) {
+        const char* cur = smem + (t & 1) * kBufBytes;
+        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = g * 4 + q, mt = idx >> 2, nt = idx & 3;
+                acc[mt][nt] = sf_mfma16(f[0][nt], f[0][4 + mt], acc[mt][nt]);
+            }
+            if (g < 6) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
+            w4_fence();
+        }
+        w4_wait_all();
+        w4_barrier();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = g * 4 + q, mt = idx >> 2, nt = idx & 3;
+                acc[mt][nt] = sf_mfma16(f[1][nt], f[1][4 + mt], acc[mt][nt]);
+            }
+            if constexpr (decltype(READ_NEXT)::value) {
+                if (g < 6) { read_frag(0, 2 * g, nxt, 0); read_frag(0, 2 * g + 1, nxt, 0); }
+            }
+            if constexpr (decltype(DO_DMA)::value) dma(g, t + 2);
+            w4_fence();
+        }
+    };
+
+    int t = 0;
+    for (; t + 2 < nkt; ++t) tile(std::true_type{}, std::true_type{}, t);
+    if (t + 1 < nkt) { tile(std::true_type{}, std::false_type{}, t); ++t; }
+    tile(std::false_type{}, std::false_type{}, t);
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w4_store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + 4 * (lane >> 4), acc[i][j]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -379,6 +493,22 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, vo
         }
         return sf_check_launch("sf_gemm_nt(256w4m32)");
     }
+    static const bool w8 = [] { const char* e = getenv("SF_GEMM_W8"); return e ? atoi(e) == 1 : false; }();
+    if (w8) {
+        if (c_dtype == SF_F32) {
+            SF_W4_SMEM((gemm_nt_256w8_kernel<1>));
+            SF_LAUNCH((gemm_nt_256w8_kernel<1>), dim3((unsigned)nblk), dim3(512), 2 * kBufBytes, stream, p);
+        } else {
+            SF_W4_SMEM((gemm_nt_256w8_kernel<0>));
+            SF_LAUNCH((gemm_nt_256w8_kernel<0>), dim3((unsigned)nblk), dim3(512), 2 * kBufBytes, stream, p);
+        }
+        return sf_check_launch("sf_gemm_nt(256w8)");
+    }
+    static const int abl = [] { const char* e = getenv("SF_GEMM_ABL"); return e ? atoi(e) : 0; }();
+#define SF_ABL_CASE(V) \
+    if (abl == V) { SF_W4_SMEM((gemm_nt_256w4_kernel<0, V>)); SF_LAUNCH((gemm_nt_256w4_kernel<0, V>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p); return sf_check_launch("abl"); }
+    SF_ABL_CASE(1) SF_ABL_CASE(2) SF_ABL_CASE(3) SF_ABL_CASE(4) SF_ABL_CASE(8) SF_ABL_CASE(9) SF_ABL_CASE(12)
+#undef SF_ABL_CASE
     if (c_dtype == SF_F32) {
         SF_W4_SMEM((gemm_nt_256w4_kernel<1>));
         SF_LAUNCH((gemm_nt_256w4_kernel<1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);

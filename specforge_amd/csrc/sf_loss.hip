@@ -155,6 +155,89 @@ ce_fused_kernel(T* logits, long ld, int V, const float* target, int S, int Spad,
     }
 }
 
+
+// ---------------------------------------------------------------- LK-loss gradient
+// d(step loss)/d(logits) for the LK objectives (specforge/core/lk_loss.py:83-99, eagle3/model.py:78-96),
+// written in place of the logits like the CE gradient.  Per row r (position mask m_r in {0,1}):
+//   s = softmax(x_r), q = target_p * pod_scale (= target_p_on_draft), a_r = sum_v min(q_v, s_v),
+//   ind_v = d min(q_v, s_v)/d s_v = [s_v < q_v] (1/2 on exact ties, torch.minimum's rule), c_r = sum_v ind_v s_v
+//   d a_r / d x_j = s_j (ind_j - c_r)                                      (softmax Jacobian)
+//   D = max(sum_r m_r, 1e-8), alpha = sum_r m_r a_r / D                    (masked means, lk_loss.py:21-38)
+//   "alpha":  loss = -sum_r m_r log a_r / D          -> g_rj = -step * m_r / (D a_r) * s_j (ind_j - c_r)
+//   "lambda": w = kl_scale exp(-kl_decay alpha) (detached); loss = w KL + (1 - w)(1 - alpha)
+//             -> g_rj = step * m_r * [ w * kl_row_scale * (s_j tsum_r - p_j) - (1 - w) / D * s_j (ind_j - c_r) ]
+// accept_sum = sum_r m_r a_r and mask_sum = sum_r m_r are device scalars produced by sf_ce_fused +
+// sf_reduce_sum (the global reductions must finish before any gradient can be scaled).
+template <typename T>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2)
+ce_lk_grad_kernel(T* logits, long ld, int V, const float* target, int S, int Spad, int off, const int* pos_mask_pad,
+                  const float* pod_scale_pad, const float* tsum_pad, int lk_mode, float kl_scale, float kl_decay,
+                  float step_scale, float kl_row_scale, const float* accept_sum, const float* mask_sum) {
+    SF_SHARED float red[32];
+    const int r = (int)blockIdx.x;
+    const int b = r / S, s = r - b * S;
+    const long pr = (long)b * Spad + s + off;
+    T* x = logits + (long)r * ld;
+    const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+    const int pm = pos_mask_pad[pr];
+    if (pm == 0) {
+        for (int j = tid; j < V; j += nt) SfElem<T>::st(x + j, 0.f);
+        return;
+    }
+    // pass 1: log-sum-exp
+    float m = SF_NEG_BIG;
+    for (int j = tid; j < V; j += nt) m = fmaxf(m, SfElem<T>::ld(x + j));
+    m = sf_block_max(m, red);
+    sf_syncthreads();
+    float d = 0.f;
+    for (int j = tid; j < V; j += nt) d += sf_exp(SfElem<T>::ld(x + j) - m);
+    d = sf_block_sum(d, red);
+    sf_syncthreads();
+    const float lse = m + sf_log(d);
+    // pass 2: a_r and c_r
+    const float* tp = target + pr * (long)V;
+    const float podc = pod_scale_pad[pr];
+    float a = 0.f, c = 0.f;
+    for (int j = tid; j < V; j += nt) {
+        const float sm = sf_exp(SfElem<T>::ld(x + j) - lse), q = tp[j] * podc;
+        a += fminf(q, sm);
+        c += sm < q ? sm : (sm == q ? 0.5f * sm : 0.f);
+    }
+    a = sf_block_sum(a, red);
+    sf_syncthreads();
+    c = sf_block_sum(c, red);
+    sf_syncthreads();
+    const float D = fmaxf(mask_sum[0], 1e-8f);
+    float ka, kb;  // g = ka * (s tsum - p) + kb * s (ind - c)
+    if (lk_mode == 1) {
+        ka = 0.f;
+        kb = a > 0.f ? -step_scale / (D * a) : 0.f;
+    } else {
+        const float alpha = accept_sum[0] / D;
+        const float w = kl_scale * sf_exp(-kl_decay * alpha);
+        ka = step_scale * kl_row_scale * w;
+        kb = -step_scale * (1.f - w) / D;
+    }
+    float tsum = 0.f;
+    if (ka != 0.f) {
+        if (tsum_pad) tsum = tsum_pad[pr];
+        else {
+            float t = 0.f;
+            for (int j = tid; j < V; j += nt) t += tp[j];
+            tsum = sf_block_sum(t, red);
+            sf_syncthreads();
+        }
+    }
+    // pass 3: gradient in place
+    const float pmf = (float)pm;
+    for (int j = tid; j < V; j += nt) {
+        const float p = tp[j];
+        const float sm = sf_exp(SfElem<T>::ld(x + j) - lse), q = p * podc;
+        const float ind = sm < q ? 1.f : (sm == q ? 0.5f : 0.f);
+        SfElem<T>::st(x + j, pmf * (ka * (sm * tsum - p) + kb * sm * (ind - c)));
+    }
+}
+
 // deterministic sum of n floats (fixed order, double accumulation): out[0] = sum
 SF_GLOBAL void reduce_sum_kernel(const float* in, long n, float* out, float scale) {
     SF_SHARED double part[256];
@@ -278,6 +361,27 @@ extern "C" int sf_ce_fused(void* logits, int dtype, long ld, int rows, int V, co
                   off, pos_mask_pad, loss_mask_pad, tgt_ids_pad, pod_scale_pad, tsum_pad, d2t, grad_scale, write_grad,
                   row_loss, row_correct, row_accept, row_pred);
     return sf_check_launch("sf_ce_fused");
+}
+
+
+extern "C" int sf_ce_lk_grad(void* logits, int dtype, long ld, int rows, int V, const float* target, int S, int Spad,
+                             int off, const int* pos_mask_pad, const float* pod_scale_pad, const float* tsum_pad,
+                             int lk_mode, float kl_scale, float kl_decay, float step_scale, float kl_row_scale,
+                             const float* accept_sum, const float* mask_sum, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && V > 0 && S > 0 && Spad >= S && off >= 0 && off + S <= Spad, "sf_ce_lk_grad: bad shape");
+    SF_CHECK_ARG(dtype == SF_BF16 || dtype == SF_F32, "sf_ce_lk_grad: dtype");
+    SF_CHECK_ARG(lk_mode == 1 || lk_mode == 2, "sf_ce_lk_grad: lk_mode must be 1 (alpha) or 2 (lambda)");
+    SF_CHECK_ARG(pos_mask_pad && pod_scale_pad && accept_sum && mask_sum, "sf_ce_lk_grad: missing input");
+    if (rows == 0) return 0;
+    if (dtype == SF_BF16)
+        SF_LAUNCH((ce_lk_grad_kernel<sf_bf16>), dim3(rows), dim3(256), 0, stream, (sf_bf16*)logits, ld, V, target, S,
+                  Spad, off, pos_mask_pad, pod_scale_pad, tsum_pad, lk_mode, kl_scale, kl_decay, step_scale,
+                  kl_row_scale, accept_sum, mask_sum);
+    else
+        SF_LAUNCH((ce_lk_grad_kernel<float>), dim3(rows), dim3(256), 0, stream, (float*)logits, ld, V, target, S, Spad,
+                  off, pos_mask_pad, pod_scale_pad, tsum_pad, lk_mode, kl_scale, kl_decay, step_scale, kl_row_scale,
+                  accept_sum, mask_sum);
+    return sf_check_launch("sf_ce_lk_grad");
 }
 
 extern "C" int sf_reduce_sum(const float* in, long n, int nsegments, float* out, float scale, void* stream) {

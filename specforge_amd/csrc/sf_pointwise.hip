@@ -469,6 +469,28 @@ SF_GLOBAL void axpy_f32_kernel(long n, float alpha, const float* x, float* y, in
 }
 }  // namespace
 
+namespace {
+// out = a + b (bf16 operands, fp32 add, one rounding) -- the gradient sum at a residual fork
+SF_GLOBAL void add_bf16_kernel(long n8, const sf_bf16* a, const sf_bf16* b, sf_bf16* out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float x[8], y[8];
+        SfVec8<sf_bf16>::ld(a + i * 8, x);
+        SfVec8<sf_bf16>::ld(b + i * 8, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] += y[j];
+        SfVec8<sf_bf16>::st(out + i * 8, x);
+    }
+}
+}  // namespace
+
+extern "C" int sf_add_bf16(long n, const void* a, const void* b, void* out, void* stream) {
+    SF_CHECK_ARG(n >= 0 && n % 8 == 0, "sf_add_bf16: n must be a non-negative multiple of 8");
+    if (n == 0) return 0;
+    SF_LAUNCH(add_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, stream, n / 8, (const sf_bf16*)a, (const sf_bf16*)b,
+              (sf_bf16*)out);
+    return sf_check_launch("sf_add_bf16");
+}
+
 extern "C" int sf_axpy_f32(long n, float alpha, const float* x, float* y, int accumulate, void* stream) {
     SF_CHECK_ARG(n >= 0, "sf_axpy_f32: bad size");
     if (n == 0) return 0;

@@ -56,13 +56,12 @@ class OnlineEagle3Model(nn.Module):
                  lk_loss_type: Optional[str] = None, kl_scale: float = 1.0, kl_decay: float = 1.0,
                  ploss_decay: float = 0.8):
         super().__init__()
-        if lk_loss_type is not None:
-            raise NotImplementedError("lk_loss_type is a 'next' row (SURVEY.md 8f rank 4); the HIP path trains the default CE objective")
         self.draft_model = draft_model
         self.length = length
         self.attention_backend = attention_backend
         self.lk_loss_type, self.kl_scale, self.kl_decay = lk_loss_type, kl_scale, kl_decay
-        self.engine = Eagle3Engine(draft_model, ttt_length=length, ploss_decay=ploss_decay)
+        self.engine = Eagle3Engine(draft_model, ttt_length=length, ploss_decay=ploss_decay, lk_loss_type=lk_loss_type,
+                                   kl_scale=kl_scale, kl_decay=kl_decay)
         self._anchor = nn.Parameter(torch.zeros((), device=self.engine.dev), requires_grad=True)
 
     def forward(self, input_ids, attention_mask, target=None, loss_mask=None, hidden_states=None, past_key_values=None,

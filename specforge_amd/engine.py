@@ -34,12 +34,14 @@ from .model import DraftConfig, FlatParams, LlamaForCausalLMEagle3, rope_tables
 
 class Eagle3Engine:
     def __init__(self, model: LlamaForCausalLMEagle3, *, ttt_length: int = 7, ploss_decay: float = 0.8,
-                 teacher_rows: int = 4096):
+                 teacher_rows: int = 4096, lk_loss_type: Optional[str] = None, kl_scale: float = 1.0,
+                 kl_decay: float = 1.0):
         self.model = model
         self.cfg: DraftConfig = model.config
         c = self.cfg
-        if not c.norm_output:
-            raise NotImplementedError("norm_output=False is not on the HIP path yet (every reference recipe uses True)")
+        if lk_loss_type not in (None, "alpha", "lambda"):
+            raise ValueError(f"Unknown lk loss type: {lk_loss_type}")  # core/lk_loss.py:99
+        self.lk_loss_type, self.kl_scale, self.kl_decay = lk_loss_type, float(kl_scale), float(kl_decay)
         if c.head_dim not in (64, 128):
             raise NotImplementedError("TTT attention kernels are built for head_dim 64 and 128")
         self.T = int(ttt_length)
@@ -113,6 +115,8 @@ class Eagle3Engine:
         b["hsn"] = self._e(N, Ht3) if c.fc_norm else None
         b["rows"] = self._e(3, N, dtype=f32)
         b["metrics"] = torch.zeros(T, 3, dtype=f32, device=self.dev)
+        b["msum"] = torch.zeros(T, dtype=f32, device=self.dev)        # LK: sum of the position mask per TTT step
+        b["lk_logsum"] = torch.zeros(T, dtype=f32, device=self.dev)   # LK: sum_r m_r log(accept_r) per TTT step
         # transposed stashes for the deferred, K-concatenated wgrad GEMMs: [features, T*N]
         TN = T * N
         for nm, feat in (("xcatT", 2 * H), ("oT", nh * hd), ("pnT", H), ("actT", I), ("lnT", H), ("dlogT", Vd),
@@ -234,6 +238,10 @@ class Eagle3Engine:
             ops.transpose2d(fc_in, b["hsT"])
 
         kcol, vcol = slice(nh * hd, (nh + nkv) * hd), slice((nh + nkv) * hd, self.QW)
+        lk = self.lk_loss_type
+        if lk is not None:
+            for k in range(T):
+                b["msum"][k] = b["pm"][:, k:k + S].sum()
         for k in range(T):
             cols = slice(k * N, (k + 1) * N)
             xcat, qkv = b["xcat"], b["qkv"][k]
@@ -251,18 +259,32 @@ class Eagle3Engine:
             ops.gemm_nt(b["pn"], self.w_gu, b["gu"][k])
             ops.swiglu_fwd(b["gu"][k], b["act"])
             ops.gemm_nt(b["act"], f.view("midlayer.mlp.down_proj.weight"), b["h"][k + 1], residual=b["h1"][k])
-            ops.rmsnorm_fwd(b["h"][k + 1], f.view("norm.weight"), eps, b["ln"], b["rstd_n"][k])
-            ops.gemm_nt(b["ln"], f.view("lm_head.weight"), b["logits"])
+            if c.norm_output:   # compute_logits (llama3_eagle.py:1772-1777)
+                ln = b["ln"]
+                ops.rmsnorm_fwd(b["h"][k + 1], f.view("norm.weight"), eps, ln, b["rstd_n"][k])
+            else:
+                ln = b["h"][k + 1]
+            ops.gemm_nt(ln, f.view("lm_head.weight"), b["logits"])
             # loss + d(logits) in place + accuracy + acceptance; ploss_k = mean over ALL B*S rows
             ops.ce_fused(b["logits"], b["tp"], S=S, Spad=Spad, off=k, pos_mask_pad=b["pm"], loss_mask_pad=b["lm"],
                          tgt_ids_pad=b["tids"], pod_scale_pad=b["pod"], tsum_pad=b["tsum"], d2t=self._d2t,
-                         grad_scale=(self.decay ** k) / N, write_grad=train, row_loss=b["rows"][0],
+                         grad_scale=(self.decay ** k) / N, write_grad=train and lk is None, row_loss=b["rows"][0],
                          row_correct=b["rows"][1], row_accept=b["rows"][2])
             ops.reduce_sum(b["rows"], N, 3, b["metrics"][k], 1.0)
+            if lk is not None:
+                # LK objectives (core/lk_loss.py:83-99): the step loss needs the masked MEANS over all rows, so the
+                # gradient is a second pass once the row sums are reduced (device scalars, no host sync)
+                ra = b["rows"][2]
+                b["lk_logsum"][k] = torch.where(ra > 0, torch.log(ra), torch.zeros_like(ra)).sum()
+                if train:
+                    ops.ce_lk_grad(b["logits"], b["tp"], S=S, Spad=Spad, off=k, pos_mask_pad=b["pm"],
+                                   pod_scale_pad=b["pod"], tsum_pad=b["tsum"], lk_loss_type=lk, kl_scale=self.kl_scale,
+                                   kl_decay=self.kl_decay, step_scale=self.decay ** k, kl_row_scale=1.0 / N,
+                                   accept_sum=b["metrics"][k][2:3], mask_sum=b["msum"][k:k + 1])
             if train:
                 ops.gemm_nt(b["logits"], self.wlmT, b["dln"][k])        # lm_head dgrad, taken now
                 ops.transpose2d(b["logits"], b["dlogT"][:, cols])
-                ops.transpose2d(b["ln"], b["lnT"][:, cols])
+                ops.transpose2d(ln, b["lnT"][:, cols])
                 ops.transpose2d(xcat, b["xcatT"][:, cols])
                 ops.transpose2d(b["o"][k], b["oT"][:, cols])
                 ops.transpose2d(b["pn"], b["pnT"][:, cols])
@@ -278,6 +300,12 @@ class Eagle3Engine:
             denom = lm_f[:, k:k + S].sum().clamp_min(1e-6)
             pden = pm_f[:, k:k + S].sum().clamp_min(1e-8)
             ploss = met[k, 0] / N
+            if lk == "alpha":      # -masked mean of log acceptance (core/lk_loss.py:92-93)
+                ploss = -b["lk_logsum"][k] / pden
+            elif lk == "lambda":   # w*KL + (1-w)*(1-acceptance), w detached (core/lk_loss.py:94-97)
+                acc_rate = met[k, 2] / pden
+                w = self.kl_scale * torch.exp(-self.kl_decay * acc_rate)
+                ploss = w * ploss + (1 - w) * (1 - acc_rate)
             out["plosses"].append(ploss)
             out["acc_corrects"].append(met[k, 1].clone())
             out["acc_denoms"].append(denom)
@@ -321,9 +349,14 @@ class Eagle3Engine:
             cols = slice(k * N, (k + 1) * N)
             # final norm + (already taken) lm_head dgrad; residual-stream gradient of step k+1 joins here
             dh = b["dh_a"]
-            acc, a = nacc("norm.weight")
-            ops.rmsnorm_bwd(b["dln"][k], b["h"][k + 1], f.view("norm.weight"), b["rstd_n"][k], dx=dh, add=dh_next,
-                            dw_acc=acc, dw_accumulate=a, workspace=ws)
+            if c.norm_output:
+                acc, a = nacc("norm.weight")
+                ops.rmsnorm_bwd(b["dln"][k], b["h"][k + 1], f.view("norm.weight"), b["rstd_n"][k], dx=dh, add=dh_next,
+                                dw_acc=acc, dw_accumulate=a, workspace=ws)
+            elif dh_next is None:   # lm_head reads the un-normed hidden state; `norm` gets no gradient
+                dh = b["dln"][k]
+            else:
+                ops.add_bf16(b["dln"][k], dh_next, dh)
             ops.transpose2d(dh, b["dhT"][:, cols])
             # MLP
             ops.gemm_nt(dh, self.wdT, b["dact"])

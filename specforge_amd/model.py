@@ -74,13 +74,26 @@ class DraftConfig:
         )
 
 
+def _yarn_correction_dim(num_rotations, dim, base, max_pos):
+    return (dim * math.log(max_pos / (num_rotations * 2 * math.pi))) / (2 * math.log(base))
+
+
+def _yarn_mscale(scale, mscale):
+    return 1.0 if scale <= 1 else 0.1 * mscale * math.log(scale) + 1.0
+
+
 def rope_tables(cfg: DraftConfig, dtype=torch.bfloat16) -> Tuple[torch.Tensor, torch.Tensor]:
     """cos/sin caches [max_pos+20, head_dim]: fp32 then cast to the activation dtype
-    (llama3_eagle.py:218-312; llama3 variant 315-340; linear variant scales positions)."""
+    (llama3_eagle.py:218-312).  Variants: llama3 frequency smoothing (235-276), linear position scaling
+    (315-344), dynamic NTK (347-386: the cache is pre-built for max_pos+20 > max_pos positions, so the base is
+    already rescaled for that length), yarn (430-540: blended frequencies and an amplitude factor on cos/sin).
+    mrope (3-D position ids) is not on the text-only EAGLE3 path."""
     dim = cfg.head_dim
+    n_pos = cfg.max_position_embeddings + 20
     inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, dim, 2).float() / dim))
     rs = cfg.rope_scaling or {}
     rtype = rs.get("rope_type", rs.get("type"))
+    amp = 1.0
     if rtype == "llama3":
         factor = rs.get("factor") or 1.0
         lo, hi = rs["low_freq_factor"], rs["high_freq_factor"]
@@ -90,14 +103,31 @@ def rope_tables(cfg: DraftConfig, dtype=torch.bfloat16) -> Tuple[torch.Tensor, t
         inv_freq = torch.where(wl < orig / hi, inv_freq,
                                torch.where(wl > orig / lo, inv_freq / factor,
                                            (1 - smooth) * inv_freq / factor + smooth * inv_freq))
+    elif rtype == "dynamic":
+        f = rs["factor"]
+        mp = cfg.max_position_embeddings
+        base = cfg.rope_theta * ((f * n_pos / mp) - (f - 1)) ** (dim / (dim - 2))
+        inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+    elif rtype == "yarn":
+        f = rs["factor"]
+        orig = rs["original_max_position_embeddings"]
+        pw = cfg.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim)
+        freq_extra, freq_inter = 1.0 / pw, 1.0 / (f * pw)
+        low = max(math.floor(_yarn_correction_dim(rs["beta_fast"], dim, cfg.rope_theta, orig)), 0)
+        high = min(math.ceil(_yarn_correction_dim(rs["beta_slow"], dim, cfg.rope_theta, orig)), dim - 1)
+        hi_ = high + 0.001 if low == high else high
+        ramp = torch.clamp((torch.arange(dim // 2, dtype=torch.float32) - low) / (hi_ - low), 0, 1)
+        mask = 1.0 - ramp
+        inv_freq = freq_inter * (1 - mask) + freq_extra * mask
+        amp = float(_yarn_mscale(f, rs["mscale"]) / _yarn_mscale(f, rs["mscale_all_dim"]))
     elif rtype not in (None, "default", "linear"):
-        raise NotImplementedError(f"specforge_amd: rope type {rtype!r} is not on the EAGLE3 offline path yet")
-    t = torch.arange(cfg.max_position_embeddings + 20, dtype=inv_freq.dtype)
+        raise NotImplementedError(f"specforge_amd: rope type {rtype!r} is not on the EAGLE3 offline path")
+    t = torch.arange(n_pos, dtype=inv_freq.dtype)
     if rtype == "linear":
         t = t / rs["factor"]
     freqs = torch.einsum("i,j->ij", t, inv_freq)
     emb = torch.cat((freqs, freqs), dim=-1)
-    return emb.cos().to(dtype).contiguous(), emb.sin().to(dtype).contiguous()
+    return (emb.cos() * amp).to(dtype).contiguous(), (emb.sin() * amp).to(dtype).contiguous()
 
 
 class _W(nn.Module):

@@ -72,6 +72,20 @@ def ce_fused(logits: torch.Tensor, target_pad: torch.Tensor, *, S: int, Spad: in
                              _p(row_pred), _stream()), "sf_ce_fused")
 
 
+def ce_lk_grad(logits: torch.Tensor, target_pad: torch.Tensor, *, S: int, Spad: int, off: int, pos_mask_pad, pod_scale_pad,
+               tsum_pad=None, lk_loss_type: str, kl_scale: float, kl_decay: float, step_scale: float, kl_row_scale: float,
+               accept_sum: torch.Tensor, mask_sum: torch.Tensor):
+    """in-place d(step_scale * lk_loss)/d(logits); see include/specforge_amd.h"""
+    L = _lib.lib()
+    rows, V = logits.shape
+    mode = {"alpha": 1, "lambda": 2}[lk_loss_type]
+    assert target_pad.dtype == torch.float32 and target_pad.is_contiguous() and target_pad.shape[-1] == V
+    assert accept_sum.dtype == torch.float32 and mask_sum.dtype == torch.float32
+    _lib.check(L.sf_ce_lk_grad(_p(logits), _dt(logits), _rowmajor(logits), rows, V, _p(target_pad), S, Spad, off,
+                               _p(pos_mask_pad), _p(pod_scale_pad), _p(tsum_pad), mode, kl_scale, kl_decay, step_scale,
+                               kl_row_scale, _p(accept_sum), _p(mask_sum), _stream()), "sf_ce_lk_grad")
+
+
 def reduce_sum(inp: torch.Tensor, n: int, nseg: int, out: torch.Tensor, scale: float = 1.0):
     L = _lib.lib()
     assert inp.dtype == torch.float32 and out.dtype == torch.float32 and inp.numel() >= n * nseg and out.numel() >= nseg
@@ -166,6 +180,14 @@ def cast_from_f32(inp: torch.Tensor, out: torch.Tensor, scale: float = 1.0):
     assert inp.dtype == torch.float32 and out.shape == (rows, C)
     _lib.check(L.sf_cast_from_f32(_p(inp), _rowmajor(inp), _p(out), _dt(out), _rowmajor(out), rows, C, scale, _stream()),
                "sf_cast_from_f32")
+    return out
+
+
+def add_bf16(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor):
+    L = _lib.lib()
+    assert a.dtype == b.dtype == out.dtype == torch.bfloat16 and a.numel() == b.numel() == out.numel()
+    assert a.is_contiguous() and b.is_contiguous() and out.is_contiguous()
+    _lib.check(L.sf_add_bf16(a.numel(), _p(a), _p(b), _p(out), _stream()), "sf_add_bf16")
     return out
 
 

@@ -23,13 +23,14 @@ def _build(blob, dev):
     cfg = DraftConfig(hidden_size=c["H"], intermediate_size=c["I"], num_attention_heads=c["nh"], num_key_value_heads=c["nkv"],
                       vocab_size=c["Vt"], draft_vocab_size=c["Vd"], head_dim=c["hd"], target_hidden_size=c["Ht"],
                       max_position_embeddings=c["max_pos"], rms_norm_eps=c["eps"], fc_norm=c["fc_norm"],
-                      rope_scaling=c["rope_scaling"])
+                      rope_scaling=c["rope_scaling"], norm_output=c.get("norm_output", True))
     model = LlamaForCausalLMEagle3(cfg, device=dev)
     sd = {k: v.to(torch.bfloat16) for k, v in blob["params"].items()}
     sd["embed_tokens.weight"] = blob["embed"].to(torch.bfloat16)
     sd["t2d"], sd["d2t"] = blob["t2d"], blob["d2t"]
     missing, unexpected = model.load_state_dict(sd, strict=True), None
-    eagle = OnlineEagle3Model(model, length=c["ttt"])
+    eagle = OnlineEagle3Model(model, length=c["ttt"], lk_loss_type=c.get("lk_loss_type"), kl_scale=c.get("kl_scale", 1.0),
+                              kl_decay=c.get("kl_decay", 1.0))
     head = TargetHead(blob["head_w"].to(torch.bfloat16).to(dev))
     return cfg, model, eagle, Eagle3TrainStrategy(eagle, target_head=head)
 
@@ -50,24 +51,28 @@ def _oracle_bf16(blob):
     cfg = O.DraftConfig(hidden_size=c["H"], intermediate_size=c["I"], num_attention_heads=c["nh"], num_key_value_heads=c["nkv"],
                         vocab_size=c["Vt"], draft_vocab_size=c["Vd"], head_dim=c["hd"], target_hidden_size=c["Ht"],
                         max_position_embeddings=c["max_pos"], rms_norm_eps=c["eps"], fc_norm=c["fc_norm"],
-                        rope_scaling=c["rope_scaling"])
+                        rope_scaling=c["rope_scaling"], norm_output=c.get("norm_output", True))
     bf = torch.bfloat16
     p = {k: v.to(bf).clone().requires_grad_(True) for k, v in blob["params"].items()}
     b = blob["batch"]
     out = O.eagle3_forward(p, cfg, embed_weight=blob["embed"].to(bf), target_head_weight=blob["head_w"].to(bf), t2d=blob["t2d"],
                            d2t=blob["d2t"], input_ids=b["input_ids"], attention_mask=b["attention_mask"],
                            loss_mask=b["loss_mask"], hidden_state=b["hidden_state"].to(bf), target_hidden=b["target"].to(bf),
-                           ttt_length=c["ttt"])
+                           ttt_length=c["ttt"], lk_loss_type=c.get("lk_loss_type"), kl_scale=c.get("kl_scale", 1.0),
+                           kl_decay=c.get("kl_decay", 1.0))
     out.loss.backward()
     new = dict(blob)
     new.update(plosses=torch.stack([x.detach().float() for x in out.plosses]), loss=out.loss.detach().float(),
                acces=torch.stack(out.acces).float(), acceptance_rates=torch.stack(out.acceptance_rates).float(),
                acc_denoms=torch.stack(out.acc_denoms).float(), target_token_ids=out.target_token_ids,
-               position_mask=out.position_mask, grads={k: v.grad.detach() for k, v in p.items()})
+               position_mask=out.position_mask,
+               grads={k: (v.grad.detach() if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()})
     return new
 
 
-@pytest.mark.parametrize("name", ["eagle3_tiny_bf16", "eagle3_tiny_fp32", "eagle31_gqa_fp32"])
+@pytest.mark.parametrize("name", ["eagle3_tiny_bf16", "eagle3_tiny_fp32", "eagle31_gqa_fp32", "eagle3_lk_alpha_fp32",
+                                  "eagle3_lk_lambda_fp32", "eagle3_nonorm_fp32", "eagle3_rope_yarn_fp32",
+                                  "eagle3_rope_dynamic_fp32"])
 def test_micro_step_matches_reference_run(backend, golden_dir, name):
     blob = torch.load(os.path.join(golden_dir, f"{name}.pt"), weights_only=False)
     if "fp32" in name:

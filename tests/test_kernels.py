@@ -123,6 +123,59 @@ def test_ce_fused(backend, dtype, tol, B, S, V, T, off):
     torch.testing.assert_close(out.cpu()[0], rl.mean(), rtol=1e-5, atol=1e-6)
 
 
+# ------------------------------------------------------------------ LK-loss gradient
+@pytest.mark.parametrize("lk,dtype,tol", [("alpha", torch.float32, 1e-3), ("lambda", torch.float32, 1e-3),
+                                          ("alpha", torch.bfloat16, 2e-2), ("lambda", torch.bfloat16, 2e-2)])
+def test_ce_lk_grad(backend, lk, dtype, tol):
+    """d(step_scale * lk_loss)/d(logits) vs autograd through the reference formulas
+    (core/lk_loss.py:43-99, eagle3/model.py:74-96) on the same (rounded) logits."""
+    B, S, V, T, off = 2, 8, 136, 3, 1
+    Spad = S + T
+    g = torch.Generator().manual_seed(11)
+    logits = (torch.randn(B * S, V, generator=g) * 2).to(dtype)
+    target_pad = torch.softmax(torch.randn(B, Spad, V, generator=g) * 3, -1)
+    pos_pad = (torch.rand(B, Spad, generator=g) > 0.3).int()
+    pod_pad = torch.rand(B, Spad, generator=g)
+    tsum_pad = target_pad.sum(-1)
+    sl = lambda t: t[:, off:off + S].reshape(B * S, *t.shape[2:])
+    kl_scale, kl_decay, step = 0.7, 1.5, 0.64
+    # ---- reference maths, autograd
+    x = logits.float().clone().requires_grad_(True)
+    p, m = sl(target_pad), sl(pos_pad).float()
+    q = p * sl(pod_pad)[:, None]
+    kl = -(m[:, None] * p * torch.log_softmax(x, -1)).sum(-1).mean()
+    a_tok = torch.minimum(q, torch.softmax(x, -1)).sum(-1)
+    den = m.sum().clamp_min(1e-8)
+    alpha = (a_tok * m).sum() / den
+    log_alpha = (torch.where(a_tok > 0, torch.log(a_tok), torch.zeros_like(a_tok)) * m).sum() / den
+    if lk == "alpha":
+        loss = -log_alpha
+    else:
+        w = kl_scale * torch.exp(-kl_decay * alpha.detach())
+        loss = w * kl + (1 - w) * (1 - alpha)
+    (step * loss).backward()
+    # ---- kernel
+    d = lambda t: t.to(backend)
+    xk = d(logits.clone())
+    accept_sum = d((a_tok.detach() * m).sum().reshape(1))
+    mask_sum = d(m.sum().reshape(1))
+    ops.ce_lk_grad(xk, d(target_pad), S=S, Spad=Spad, off=off, pos_mask_pad=d(pos_pad), pod_scale_pad=d(pod_pad),
+                   tsum_pad=d(tsum_pad), lk_loss_type=lk, kl_scale=kl_scale, kl_decay=kl_decay, step_scale=step,
+                   kl_row_scale=1.0 / (B * S), accept_sum=accept_sum, mask_sum=mask_sum)
+    gtol = tol * float(x.grad.abs().max())
+    torch.testing.assert_close(xk.float().cpu(), x.grad, rtol=tol, atol=gtol)
+    assert float(xk.float().cpu()[sl(pos_pad) == 0].abs().max()) == 0.0   # masked rows: exactly zero
+
+
+def test_add_bf16(backend):
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(40, 24, generator=g).to(torch.bfloat16)
+    b = torch.randn(40, 24, generator=g).to(torch.bfloat16)
+    out = torch.empty(40, 24, dtype=torch.bfloat16, device=backend)
+    ops.add_bf16(a.to(backend), b.to(backend), out)
+    assert torch.equal(out.cpu(), a + b)   # fp32 add, one rounding == torch's bf16 add
+
+
 # ------------------------------------------------------------------ teacher
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_teacher_reduce(backend, dtype):

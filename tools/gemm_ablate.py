@@ -8,6 +8,12 @@ a = torch.randn(M, K, device="cuda").to(torch.bfloat16); b = torch.randn(N, K, d
 c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 if os.environ.get("ZERO"): a.zero_(); b.zero_()
 IT = int(os.environ.get("IT", "10"))
+if os.environ.get("TORCH"):
+    bt = b.t()
+    class _O:
+        @staticmethod
+        def gemm_nt(a, b, c): torch.matmul(a, bt, out=c)
+    ops = _O
 for _ in range(3): ops.gemm_nt(a, b, c)
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
