@@ -298,81 +298,112 @@ struct AttnBwdPreArgs {
     const float* lse;   // [B, nh, S]
     float* delta;       // [B, nh, S]
     float* dq_init;     // [B*S, nh*hd] fp32, written when ndiag > 0
+    int dq_accumulate;  // this launch handles a later chunk of diagonals: dq_init += instead of =
     int B, S, nh, nkv, hd;
     float scale;
 };
 
-// one workgroup per token row; wave w handles kv groups w, w+4, ...; lane owns hd/64 consecutive d
+// A group of HD/8 lanes owns one token row (8 consecutive d per lane, 16-byte loads), so a wave covers 4 (HD=128)
+// or 8 (HD=64) rows; wave w handles kv groups w, w+4, ... and walks the query heads of a group serially, which
+// keeps the dK_i / dV_i sums over those heads in registers.  Every dot product is an all-reduce over the lane group
+// done with DPP row operations (sf_row_sum) -- no LDS crossbar traffic.  One launch handles at most kPreChunk
+// diagonals (their K/V/dK/dV slices live in registers); the host splits longer lists into chunks, later chunks
+// accumulate into dq_init.
+constexpr int kPreChunk = 4;
 template <int HD>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_pre_kernel(AttnBwdPreArgs p) {
-    constexpr int E = HD / 64;  // elements per lane (1 or 2)
-    const int row = (int)blockIdx.x, lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    constexpr int ND = kPreChunk;
+    constexpr int LPH = HD / 8;     // lanes per row
+    constexpr int RPW = 64 / LPH;   // rows per wave
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int sub = lane / LPH, li = lane % LPH;
+    const int N = p.B * p.S;
+    const int row_raw = (int)blockIdx.x * RPW + sub;
+    const bool live = row_raw < N;
+    const int row = live ? row_raw : N - 1;   // dead lane groups shadow a valid row and skip every store
     const int b = row / p.S, t = row - b * p.S;
     const int nrep = p.nh / p.nkv;
+    const int d0 = li * 8;
     for (int g = wave; g < p.nkv; g += 4) {
-        float dk[kMaxDiag][E], dv[kMaxDiag][E], kv[kMaxDiag][E], vv[kMaxDiag][E];
+        sf_v8s kv[ND], vv[ND];
+        float dk[ND][8], dv[ND][8];
 #pragma unroll
-        for (int i = 0; i < kMaxDiag; ++i)
+        for (int i = 0; i < ND; ++i) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                dk[i][e] = 0.f; dv[i][e] = 0.f; kv[i][e] = 0.f; vv[i][e] = 0.f;
-                if (i < p.ndiag) {
-                    kv[i][e] = sf_bf2f(p.kd[i][(long)row * p.ldk + g * HD + lane * E + e]);
-                    vv[i][e] = sf_bf2f(p.vd[i][(long)row * p.ldk + g * HD + lane * E + e]);
-                }
+            for (int e = 0; e < 8; ++e) { dk[i][e] = 0.f; dv[i][e] = 0.f; }
+            if (i < p.ndiag) {
+                kv[i] = *reinterpret_cast<const sf_v8s*>(p.kd[i] + (long)row * p.ldk + g * HD + d0);
+                vv[i] = *reinterpret_cast<const sf_v8s*>(p.vd[i] + (long)row * p.ldk + g * HD + d0);
+            } else {
+                kv[i] = sf_v8s{0, 0, 0, 0, 0, 0, 0, 0};
+                vv[i] = kv[i];
             }
+        }
         for (int hh = 0; hh < nrep; ++hh) {
             const int h = g * nrep + hh;
-            float qv[E], ov[E], dov[E];
+            const int col = h * HD + d0;
+            float qv[8], ov[8], dov[8];
+            SfVec8<sf_bf16>::ld(p.q + (long)row * p.ldq + col, qv);
+            SfVec8<sf_bf16>::ld(p.o + (long)row * p.ldo + col, ov);
+            SfVec8<sf_bf16>::ld(p.dout + (long)row * p.lddo + col, dov);
             float dl = 0.f;
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int col = h * HD + lane * E + e;
-                qv[e] = sf_bf2f(p.q[(long)row * p.ldq + col]);
-                ov[e] = sf_bf2f(p.o[(long)row * p.ldo + col]);
-                dov[e] = sf_bf2f(p.dout[(long)row * p.lddo + col]);
-                dl += ov[e] * dov[e];
-            }
-            dl = sf_wave_sum(dl);
-            const long li = ((long)b * p.nh + h) * p.S + t;
-            if (lane == 0) p.delta[li] = dl;
+            for (int e = 0; e < 8; ++e) dl += ov[e] * dov[e];
+            dl = sf_row_sum<LPH>(dl);
+            const long lidx = ((long)b * p.nh + h) * p.S + t;
+            if (li == 0 && live) p.delta[lidx] = dl;
             if (p.ndiag > 0) {
-                const float lse = p.lse[li];
-                float dq[E];
+                const float lse = p.lse[lidx];
+                float dq[8];
 #pragma unroll
-                for (int e = 0; e < E; ++e) dq[e] = 0.f;
+                for (int e = 0; e < 8; ++e) dq[e] = 0.f;
 #pragma unroll
-                for (int i = 0; i < kMaxDiag; ++i) {
+                for (int i = 0; i < ND; ++i) {
                     if (i < p.ndiag) {
                         float sdot = 0.f, pdot = 0.f;
 #pragma unroll
-                        for (int e = 0; e < E; ++e) { sdot += qv[e] * kv[i][e]; pdot += dov[e] * vv[i][e]; }
-                        sdot = sf_wave_sum(sdot);
-                        pdot = sf_wave_sum(pdot);
+                        for (int e = 0; e < 8; ++e) {
+                            sdot += qv[e] * sf_bf2f((sf_bf16)kv[i][e]);
+                            pdot += dov[e] * sf_bf2f((sf_bf16)vv[i][e]);
+                        }
+                        sdot = sf_row_sum<LPH>(sdot);
+                        pdot = sf_row_sum<LPH>(pdot);
                         const float pi = sf_exp(sdot * p.scale - lse);
                         const float ds = pi * (pdot - dl) * p.scale;
 #pragma unroll
-                        for (int e = 0; e < E; ++e) {
-                            dq[e] += ds * kv[i][e];
+                        for (int e = 0; e < 8; ++e) {
+                            dq[e] += ds * sf_bf2f((sf_bf16)kv[i][e]);
                             dk[i][e] += ds * qv[e];
                             dv[i][e] += pi * dov[e];
                         }
                     }
                 }
+                if (live) {
+                    float* dqp = p.dq_init + (long)row * (p.nh * HD) + col;
+                    if (p.dq_accumulate) {   // later chunk of diagonals: add to what the first chunk wrote
+                        float prev[8];
+                        SfVec8<float>::ld(dqp, prev);
 #pragma unroll
-                for (int e = 0; e < E; ++e) p.dq_init[(long)row * (p.nh * HD) + h * HD + lane * E + e] = dq[e];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < kMaxDiag; ++i)
-            if (i < p.ndiag) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const long idx = (long)row * p.lddk + g * HD + lane * E + e;
-                    p.dkd[i][idx] += dk[i][e];
-                    p.dvd[i][idx] += dv[i][e];
+                        for (int e = 0; e < 8; ++e) dq[e] += prev[e];
+                    }
+                    SfVec8<float>::st(dqp, dq);
                 }
             }
+        }
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+                if (i < p.ndiag) {
+                    const long idx = (long)row * p.lddk + g * HD + d0;
+                    float a[8], c[8];
+                    SfVec8<float>::ld(p.dkd[i] + idx, a);
+                    SfVec8<float>::ld(p.dvd[i] + idx, c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { a[e] += dk[i][e]; c[e] += dv[i][e]; }
+                    SfVec8<float>::st(p.dkd[i] + idx, a);
+                    SfVec8<float>::st(p.dvd[i] + idx, c);
+                }
+        }
     }
 }
 
@@ -694,19 +725,27 @@ extern "C" int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo,
     SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_pre: bad shape");
     SF_CHECK_ARG(ndiag >= 0 && ndiag <= kMaxDiag, "sf_attn_bwd_pre: at most 8 diagonal branches");
     SF_CHECK_ARG(ndiag == 0 || dq_init, "sf_attn_bwd_pre: dq_init required with diagonal branches");
-    AttnBwdPreArgs p;
-    memset(&p, 0, sizeof(p));
-    p.q = (const sf_bf16*)q; p.ldq = ldq;
-    p.o = (const sf_bf16*)o; p.ldo = ldo;
-    p.dout = (const sf_bf16*)dout; p.lddo = lddo;
-    for (int i = 0; i < ndiag; ++i) {
-        p.kd[i] = (const sf_bf16*)kd[i]; p.vd[i] = (const sf_bf16*)vd[i];
-        p.dkd[i] = dkd[i]; p.dvd[i] = dvd[i];
+    SF_CHECK_ARG(hd == 64 || hd == 128, "head_dim must be 64 or 128");
+    SF_CHECK_ARG(ldq % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldk % 8 == 0 && lddk % 4 == 0,
+                 "sf_attn_bwd_pre: strides must be multiples of 8 (16-byte row segments)");
+    const int rows_per_block = 64 / (hd / 8);
+    const dim3 grid((unsigned)((B * S + rows_per_block - 1) / rows_per_block));
+    for (int lo = 0; lo == 0 || lo < ndiag; lo += kPreChunk) {
+        AttnBwdPreArgs p;
+        memset(&p, 0, sizeof(p));
+        p.q = (const sf_bf16*)q; p.ldq = ldq;
+        p.o = (const sf_bf16*)o; p.ldo = ldo;
+        p.dout = (const sf_bf16*)dout; p.lddo = lddo;
+        const int n = ndiag - lo < kPreChunk ? ndiag - lo : kPreChunk;
+        for (int i = 0; i < n; ++i) {
+            p.kd[i] = (const sf_bf16*)kd[lo + i]; p.vd[i] = (const sf_bf16*)vd[lo + i];
+            p.dkd[i] = dkd[lo + i]; p.dvd[i] = dvd[lo + i];
+        }
+        p.ldk = ldk; p.lddk = lddk; p.ndiag = n > 0 ? n : 0;
+        p.lse = lse; p.delta = delta; p.dq_init = dq_init; p.dq_accumulate = lo > 0;
+        p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.hd = hd; p.scale = scale;
+        SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_pre_kernel<HD>), grid, dim3(256), 0, stream, p));
     }
-    p.ldk = ldk; p.lddk = lddk; p.ndiag = ndiag;
-    p.lse = lse; p.delta = delta; p.dq_init = dq_init;
-    p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.hd = hd; p.scale = scale;
-    SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_pre_kernel<HD>), dim3(B * S), dim3(256), 0, stream, p));
     return sf_check_launch("sf_attn_bwd_pre");
 }
 

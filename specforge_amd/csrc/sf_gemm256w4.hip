@@ -117,7 +117,7 @@ SF_DEVICE void w4_store4(const GemmW4Args& p, int m, int n, sf_v4f acc) {
 }
 
 // ABL (timing ablations only, results are wrong): bit0 = no ds_reads after the first tile, bit1 = no DMA in the loop
-template <int OUT_F32, int ABL = 0>
+template <int OUT_F32, int ABL = 0, int BUF = 0>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     SF_DYN_SMEM(smem);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
@@ -143,10 +143,29 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
         src[j] = p.A + (long)ra * p.lda + slc * 8;
         src[8 + j] = p.B + (long)rb * p.ldb + slc * 8;
     }
+    // BUF: the same pieces through raw buffer descriptors rooted at the tile origin -- one 32-bit voffset per piece
+    // and lane, the K advance in soffset (scalar), no per-DMA vector arithmetic
+    const SfBuf bufA = sf_make_buf(p.A + (long)m0 * p.lda, 0x7fffffffu);
+    const SfBuf bufB = sf_make_buf(p.B + (long)n0 * p.ldb, 0x7fffffffu);
+    unsigned voff[16];
+    if (BUF) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int ra = (8 * wave + j) * 8 + srow, rb = ra;
+            ra = m0 + ra < p.M ? ra : p.M - 1 - m0;
+            rb = n0 + rb < p.N ? rb : p.N - 1 - n0;
+            voff[j] = (unsigned)(((long)ra * p.lda + slc * 8) * 2);
+            voff[8 + j] = (unsigned)(((long)rb * p.ldb + slc * 8) * 2);
+        }
+    }
     auto dma = [&](int g, int kt) {  // piece g (0..7 A, 8..15 B) of the next un-issued K-tile into buffer kt&1
         char* dst = smem + (kt & 1) * kBufBytes + (g >> 3) * kOpBytes + (8 * wave + (g & 7)) * 1024;
-        sf_glds16(src[g], dst);
-        src[g] += TK;
+        if (BUF) {
+            sf_buf_glds16(g < 8 ? bufA : bufB, voff[g], (unsigned)kt * (TK * 2), dst);
+        } else {
+            sf_glds16(src[g], dst);
+            src[g] += TK;
+        }
     };
 
     // ---- fragment read offsets; (row & 7) == (lane & 7) for every fragment row
@@ -509,6 +528,17 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, vo
     if (abl == V) { SF_W4_SMEM((gemm_nt_256w4_kernel<0, V>)); SF_LAUNCH((gemm_nt_256w4_kernel<0, V>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p); return sf_check_launch("abl"); }
     SF_ABL_CASE(1) SF_ABL_CASE(2) SF_ABL_CASE(3) SF_ABL_CASE(4) SF_ABL_CASE(8) SF_ABL_CASE(9) SF_ABL_CASE(12)
 #undef SF_ABL_CASE
+    static const bool bufdma = [] { const char* e = getenv("SF_GEMM_BUF"); return e ? atoi(e) == 1 : false; }();
+    if (bufdma) {
+        if (c_dtype == SF_F32) {
+            SF_W4_SMEM((gemm_nt_256w4_kernel<1, 0, 1>));
+            SF_LAUNCH((gemm_nt_256w4_kernel<1, 0, 1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+        } else {
+            SF_W4_SMEM((gemm_nt_256w4_kernel<0, 0, 1>));
+            SF_LAUNCH((gemm_nt_256w4_kernel<0, 0, 1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+        }
+        return sf_check_launch("sf_gemm_nt(256w4 buf)");
+    }
     if (c_dtype == SF_F32) {
         SF_W4_SMEM((gemm_nt_256w4_kernel<1>));
         SF_LAUNCH((gemm_nt_256w4_kernel<1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);

@@ -41,6 +41,12 @@ template <typename T> SF_DEVICE T sf_shfl(T v, int l) { return sfemu::shfl(v, l)
 SF_DEVICE sf_v4f sf_mfma16(sf_v8s a, sf_v8s b, sf_v4f c) { return sfemu::mfma_16x16x32_bf16(a, b, c); }
 SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) { return sfemu::mfma_32x32x16_bf16(a, b, c); }
 SF_DEVICE void sf_glds16(const void* g, void* l) { sfemu::global_load_lds16(g, l); }
+struct SfBuf { const char* base; unsigned bytes; };
+SF_DEVICE SfBuf sf_make_buf(const void* base, unsigned bytes) { return SfBuf{(const char*)base, bytes}; }
+SF_DEVICE void sf_buf_glds16(SfBuf b, unsigned voff, unsigned soff, void* l) {
+    static const char zero16[16] = {0};
+    sfemu::global_load_lds16(voff + 16 <= b.bytes ? b.base + voff + soff : zero16, l);
+}
 SF_DEVICE int sf_wave_id() { return sfemu::wave_index(); }
 SF_DEVICE sf_v4s sf_ds_read_tr16(const void* l) { return sfemu::ds_read_tr16_b64(l); }
 SF_DEVICE bool sf_all(bool pred) {
@@ -102,6 +108,19 @@ SF_DEVICE void sf_glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+// LDS-DMA through a raw buffer descriptor (buffer_load_dwordx4 ... lds): the address is
+// SGPR descriptor base + 32-bit per-lane voffset + SGPR soffset, so a lane carries one dword of address instead of a
+// 64-bit pointer and a K-loop advances with scalar adds only.  The descriptor must be wave-uniform.  gfx9 raw buffers
+// range-check voffset (not soffset) against `bytes` and return zeros past it.
+struct SfBuf { __amdgpu_buffer_rsrc_t r; };
+SF_DEVICE SfBuf sf_make_buf(const void* base, unsigned bytes) {
+    SfBuf b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+    return b;
+}
+SF_DEVICE void sf_buf_glds16(SfBuf b, unsigned voff, unsigned soff, void* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)l, 16, (int)voff, (int)soff, 0, 0);
+}
 SF_DEVICE void sf_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 SF_DEVICE void sf_setprio_hi() { __builtin_amdgcn_s_setprio(1); }
 SF_DEVICE void sf_setprio_lo() { __builtin_amdgcn_s_setprio(0); }
@@ -141,6 +160,27 @@ template <> struct SfElem<float> {
     static SF_HD void st(float* p, float v) { *p = v; }
     static SF_HD float rnd(float v) { return v; }
 };
+
+// all-reduce sum inside aligned groups of LANES (8 or 16) lanes.  Product build: DPP (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror) -- plain VALU ops, no LDS crossbar; the emulator's xor butterfly adds the same pairs
+// in the same order, so both are bit-identical.
+#ifdef SF_EMU
+template <int LANES> SF_DEVICE float sf_row_sum(float v) {
+    for (int m = 1; m < LANES; m <<= 1) v += sf_shfl_xor(v, m);
+    return v;
+}
+#else
+template <int CTRL> SF_DEVICE float sf_dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int LANES> SF_DEVICE float sf_row_sum(float v) {
+    v += sf_dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += sf_dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += sf_dpp_f32<0x141>(v);   // row_half_mirror
+    if (LANES == 16) v += sf_dpp_f32<0x140>(v);  // row_mirror
+    return v;
+}
+#endif
 
 // block-wide reductions over 256-thread (or any multiple-of-64) workgroups
 SF_DEVICE float sf_wave_sum(float v) {
