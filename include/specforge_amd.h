@@ -45,6 +45,16 @@ const char* sf_last_error(void);
 int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
                int K, float alpha, float beta, const void* R, long ldr, void* stream);
 
+/* Same GEMM with an fp32 row-mapped addend joined to the accumulator before the single rounding:
+ *   C[r][n] = round( alpha * (A.B^T)[r][n] + Cadd[(r / S) * Spad + r % S + off][n] )
+ * The TTT step k projects cat(input_layernorm(embed(ids << k)), hidden_norm(h_k)) through q/k/v
+ * (specforge/modeling/draft/llama3_eagle.py:1625-1630, 661-700).  The embedding half of that product depends only
+ * on the token, and step k's token at position s is step 0's token at s + k, so it is computed once over the
+ * padded [B, S+T] positions (Cadd) and re-used by every step through this epilogue; the GEMM itself then
+ * contracts over the hidden half only. */
+int sf_gemm_nt_rowadd(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
+                      int K, float alpha, const float* Cadd, long ldadd, int S, int Spad, int off, void* stream);
+
 /* ---- fused soft-target CE step: loss + in-place dlogits + accuracy + acceptance -----------
  * replaces specforge/core/loss.py:173-228 (LogSoftmaxLoss fwd/bwd), eagle3/model.py:161-173
  * (accuracy), core/lk_loss.py:43-80 (acceptance rate).  Per row r=b*S+s (padded index

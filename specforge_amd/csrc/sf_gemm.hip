@@ -16,6 +16,7 @@
 // Workgroup ids are remapped so that each XCD (private L2) walks a compact group of tiles.
 #include "sf_api_internal.h"
 #include "sf_util.h"
+#include "sf_gemm_epilogue.h"
 #include <stdlib.h>
 
 namespace {
@@ -34,12 +35,8 @@ struct GemmArgs {
     long lda;
     const sf_bf16* B;
     long ldb;
-    void* C;
-    long ldc;
-    const sf_bf16* R;
-    long ldr;
+    SfGemmEpi e;
     int M, N, K;
-    float alpha, beta;
     int tiles_m, tiles_n;
 };
 
@@ -119,64 +116,18 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) gemm_nt_kernel(GemmArgs p) {
 
     // epilogue: lane owns C[m][n .. n+3], m = 16-row tile row (lane&15), n = 4*(lane>>4)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wr * 64 + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wc * 64 + j * 16 + 4 * (lane >> 4);
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r];
-            const bool full = (n + 3 < p.N);
-            if (OUT_F32) {
-                float* c = (float*)p.C + (long)m * p.ldc + n;
-                if (full) {
-                    if (p.beta != 0.f) {
-                        sf_v4f o = *reinterpret_cast<const sf_v4f*>(c);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += p.beta * o[r];
-                    }
-                    *reinterpret_cast<sf_v4f*>(c) = sf_v4f{v[0], v[1], v[2], v[3]};
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = v[r] + (p.beta != 0.f ? p.beta * c[r] : 0.f);
-                }
-            } else {
-                sf_bf16* c = (sf_bf16*)p.C + (long)m * p.ldc + n;
-                if (full) {
-                    if (p.beta != 0.f) {
-                        sf_v4s o = *reinterpret_cast<const sf_v4s*>(c);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += p.beta * sf_bf2f((sf_bf16)o[r]);
-                    }
-                    if (p.R) {  // round the projection first, then add the residual (bf16 + bf16)
-                        sf_v4s rr = *reinterpret_cast<const sf_v4s*>(p.R + (long)m * p.ldr + n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = sf_round_bf(v[r]) + sf_bf2f((sf_bf16)rr[r]);
-                    }
-                    sf_v4s o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (short)sf_f2bf(v[r]);
-                    *reinterpret_cast<sf_v4s*>(c) = o;
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) {
-                        float t = v[r] + (p.beta != 0.f ? p.beta * sf_bf2f(c[r]) : 0.f);
-                        if (p.R) t = sf_round_bf(t) + sf_bf2f(p.R[(long)m * p.ldr + n + r]);
-                        c[r] = sf_f2bf(t);
-                    }
-                }
-            }
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            sf_gemm_store4<OUT_F32>(p.e, m0 + wr * 64 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + 4 * (lane >> 4), v);
         }
-    }
 }
 
 }  // namespace
 
-int sf_gemm_nt_256_launch(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
-                          int K, float alpha, float beta, const void* R, long ldr, void* stream);
-int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M,
-                            int N, int K, float alpha, float beta, const void* R, long ldr, void* stream);
+int sf_gemm_nt_256_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, void* stream);
+int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, void* stream);
 // tuning knob for A/B measurements only: SF_GEMM_TILE=128 pins the 128x128 kernel
 static bool sf_gemm_use_256() {
     static const bool use = [] {
@@ -186,31 +137,23 @@ static bool sf_gemm_use_256() {
     return use;
 }
 
-extern "C" int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
-                          int K, float alpha, float beta, const void* R, long ldr, void* stream) {
-    SF_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sf_gemm_nt: negative shape");
-    SF_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sf_gemm_nt: K, lda, ldb must be multiples of 8 (16-byte rows)");
-    SF_CHECK_ARG(ldc % 4 == 0 && ldr % 4 == 0, "sf_gemm_nt: ldc, ldr must be multiples of 4");
-    SF_CHECK_ARG(c_dtype == SF_BF16 || c_dtype == SF_F32, "sf_gemm_nt: c_dtype");
-    SF_CHECK_ARG(!(R && c_dtype == SF_F32), "sf_gemm_nt: residual epilogue is bf16-only");
-    if (M == 0 || N == 0) return 0;
-    // big, 64-aligned-K shapes (every GEMM of the training step) take the 256x256 ping-pong kernel
+static int sf_gemm_dispatch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype,
+                            void* stream) {
+    const int M = e.M, N = e.N;
     // chip-filling shapes (>= one 256x256 tile per CU, long K: every GEMM of the training step) take the 4-wave
     // software-pipelined kernel; smaller ones the 8-wave ping-pong kernel, whose prologue/epilogue is shorter.
     // SF_GEMM_W4=0 pins the ping-pong kernel, =1 forces the 4-wave kernel for every 256-tile shape (A/B knob).
-    static const int w4_mode = [] { const char* e = getenv("SF_GEMM_W4"); return e ? atoi(e) : -1; }();
+    static const int w4_mode = [] { const char* en = getenv("SF_GEMM_W4"); return en ? atoi(en) : -1; }();
     const bool big = (long)((M + 255) / 256) * ((N + 255) / 256) >= 256 && K >= 512;
     if (K % 64 == 0 && K >= 64 && M >= 192 && N >= 192 && sf_gemm_use_256() && (w4_mode == 1 || (w4_mode < 0 && big)))
-        return sf_gemm_nt_256w4_launch(A, lda, B, ldb, C, c_dtype, ldc, M, N, K, alpha, beta, R, ldr, stream);
+        return sf_gemm_nt_256w4_launch(A, lda, B, ldb, K, e, c_dtype, stream);
     if (K % 64 == 0 && K >= 64 && M >= 192 && N >= 192 && sf_gemm_use_256())
-        return sf_gemm_nt_256_launch(A, lda, B, ldb, C, c_dtype, ldc, M, N, K, alpha, beta, R, ldr, stream);
+        return sf_gemm_nt_256_launch(A, lda, B, ldb, K, e, c_dtype, stream);
     GemmArgs p;
     p.A = (const sf_bf16*)A; p.lda = lda;
     p.B = (const sf_bf16*)B; p.ldb = ldb;
-    p.C = C; p.ldc = ldc;
-    p.R = (const sf_bf16*)R; p.ldr = ldr;
+    p.e = e;
     p.M = M; p.N = N; p.K = K;
-    p.alpha = alpha; p.beta = beta;
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
     const long nblk = (long)p.tiles_m * p.tiles_n;
@@ -220,4 +163,38 @@ extern "C" int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void
     else
         SF_LAUNCH((gemm_nt_kernel<0>), dim3((unsigned)nblk), dim3(256), 2 * kStageBytes, stream, p);
     return sf_check_launch("sf_gemm_nt");
+}
+
+static int sf_gemm_check(long lda, long ldb, long ldc, long ldr, int M, int N, int K, int c_dtype, const void* R) {
+    SF_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sf_gemm_nt: negative shape");
+    SF_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sf_gemm_nt: K, lda, ldb must be multiples of 8 (16-byte rows)");
+    SF_CHECK_ARG(ldc % 4 == 0 && ldr % 4 == 0, "sf_gemm_nt: ldc, ldr must be multiples of 4");
+    SF_CHECK_ARG(c_dtype == SF_BF16 || c_dtype == SF_F32, "sf_gemm_nt: c_dtype");
+    SF_CHECK_ARG(!(R && c_dtype == SF_F32), "sf_gemm_nt: residual epilogue is bf16-only");
+    return 0;
+}
+
+extern "C" int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
+                          int K, float alpha, float beta, const void* R, long ldr, void* stream) {
+    if (int st = sf_gemm_check(lda, ldb, ldc, ldr, M, N, K, c_dtype, R)) return st;
+    if (M == 0 || N == 0) return 0;
+    SfGemmEpi e;
+    e.C = C; e.ldc = ldc; e.R = (const sf_bf16*)R; e.ldr = ldr;
+    e.Cadd = nullptr; e.ldadd = 0; e.add_S = 1; e.add_Spad = 1; e.add_off = 0;
+    e.M = M; e.N = N; e.alpha = alpha; e.beta = beta;
+    return sf_gemm_dispatch(A, lda, B, ldb, K, e, c_dtype, stream);
+}
+
+extern "C" int sf_gemm_nt_rowadd(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M,
+                                 int N, int K, float alpha, const float* Cadd, long ldadd, int S, int Spad, int off,
+                                 void* stream) {
+    if (int st = sf_gemm_check(lda, ldb, ldc, 0, M, N, K, c_dtype, nullptr)) return st;
+    SF_CHECK_ARG(Cadd && ldadd % 4 == 0 && S > 0 && Spad >= S && off >= 0 && off + S <= Spad && M % S == 0,
+                 "sf_gemm_nt_rowadd: bad addend layout");
+    if (M == 0 || N == 0) return 0;
+    SfGemmEpi e;
+    e.C = C; e.ldc = ldc; e.R = nullptr; e.ldr = 0;
+    e.Cadd = Cadd; e.ldadd = ldadd; e.add_S = S; e.add_Spad = Spad; e.add_off = off;
+    e.M = M; e.N = N; e.alpha = alpha; e.beta = 0.f;
+    return sf_gemm_dispatch(A, lda, B, ldb, K, e, c_dtype, stream);
 }

@@ -24,6 +24,7 @@
 //     barriers before they touch it -> RAW safe for both (staggered) groups.
 #include "sf_api_internal.h"
 #include "sf_util.h"
+#include "sf_gemm_epilogue.h"
 #include <stdlib.h>
 
 namespace {
@@ -41,10 +42,8 @@ constexpr int kBufBytes = 4 * kHalfBytes;      // A0 A1 B0 B1 of one K-tile
 struct Gemm256Args {
     const sf_bf16* A; long lda;
     const sf_bf16* B; long ldb;
-    void* C; long ldc;
-    const sf_bf16* R; long ldr;
+    SfGemmEpi e;
     int M, N, K;
-    float alpha, beta;
     int tiles_m, tiles_n;
     int gm;     // tile-rows per L2 group of the XCD-aware tile order
     int flags;  // tuning experiments: bit0 = no s_setprio around the MFMA segment
@@ -74,52 +73,6 @@ SF_DEVICE void tile_coords256(int bid, int nblk, int tiles_m, int tiles_n, int G
     const int in_g = seq - g * per_group;
     tm = first_m + in_g % gsize;
     tn = in_g / gsize;
-}
-
-// C[m][n..n+3] = alpha*v (+beta*C) (+R), bf16 or fp32 output, ragged N handled
-template <int OUT_F32>
-SF_DEVICE void store4(const Gemm256Args& p, int m, int n, float (&v)[4]) {
-    if (m >= p.M || n >= p.N) return;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
-    const bool full = (n + 3 < p.N);
-    if (OUT_F32) {
-        float* c = (float*)p.C + (long)m * p.ldc + n;
-        if (full) {
-            if (p.beta != 0.f) {
-                sf_v4f o = *reinterpret_cast<const sf_v4f*>(c);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += p.beta * o[r];
-            }
-            *reinterpret_cast<sf_v4f*>(c) = sf_v4f{v[0], v[1], v[2], v[3]};
-        } else {
-            for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = v[r] + (p.beta != 0.f ? p.beta * c[r] : 0.f);
-        }
-    } else {
-        sf_bf16* c = (sf_bf16*)p.C + (long)m * p.ldc + n;
-        if (full) {
-            if (p.beta != 0.f) {
-                sf_v4s o = *reinterpret_cast<const sf_v4s*>(c);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += p.beta * sf_bf2f((sf_bf16)o[r]);
-            }
-            if (p.R) {  // round the projection first, then add the residual (bf16 + bf16)
-                sf_v4s rr = *reinterpret_cast<const sf_v4s*>(p.R + (long)m * p.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = sf_round_bf(v[r]) + sf_bf2f((sf_bf16)rr[r]);
-            }
-            sf_v4s o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (short)sf_f2bf(v[r]);
-            *reinterpret_cast<sf_v4s*>(c) = o;
-        } else {
-            for (int r = 0; r < 4 && n + r < p.N; ++r) {
-                float t2 = v[r] + (p.beta != 0.f ? p.beta * sf_bf2f(c[r]) : 0.f);
-                if (p.R) t2 = sf_round_bf(t2) + sf_bf2f(p.R[(long)m * p.ldr + n + r]);
-                c[r] = sf_f2bf(t2);
-            }
-        }
-    }
 }
 
 template <int OUT_F32>
@@ -246,7 +199,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256_kernel(Gemm256Args p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + 4 * (lane >> 4), v);
+            sf_gemm_store4<OUT_F32>(p.e, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + 4 * (lane >> 4), v);
         }
 }
 
@@ -386,7 +339,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256v2_kernel(Gemm256Args p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + 4 * (lane >> 4), v);
+            sf_gemm_store4<OUT_F32>(p.e, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + 4 * (lane >> 4), v);
         }
 }
 
@@ -513,7 +466,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256_mf32_kernel(Gemm256Args p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                store4<OUT_F32>(p, m0 + wr * 128 + i * 32 + (lane & 31), n0 + wc * 64 + j * 32 + 8 * q + 4 * hi, v);
+                sf_gemm_store4<OUT_F32>(p.e, m0 + wr * 128 + i * 32 + (lane & 31), n0 + wc * 64 + j * 32 + 8 * q + 4 * hi, v);
             }
 }
 
@@ -534,15 +487,14 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256_mf32_kernel(Gemm256Args p) {
 #endif
 
 // launched by sf_gemm_nt (sf_gemm.hip) when the shape qualifies
-int sf_gemm_nt_256_launch(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
-                          int K, float alpha, float beta, const void* R, long ldr, void* stream) {
+int sf_gemm_nt_256_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype,
+                          void* stream) {
+    const int M = e.M, N = e.N;
     Gemm256Args p;
     p.A = (const sf_bf16*)A; p.lda = lda;
     p.B = (const sf_bf16*)B; p.ldb = ldb;
-    p.C = C; p.ldc = ldc;
-    p.R = (const sf_bf16*)R; p.ldr = ldr;
+    p.e = e;
     p.M = M; p.N = N; p.K = K;
-    p.alpha = alpha; p.beta = beta;
     p.tiles_m = (M + TM - 1) / TM;
     p.tiles_n = (N + TN - 1) / TN;
     { const char* e = getenv("SF_GEMM_GM"); p.gm = e ? atoi(e) : 4; if (p.gm < 1) p.gm = 1; }

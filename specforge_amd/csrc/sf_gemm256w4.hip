@@ -23,6 +23,7 @@
 //     precedes its restaging.
 #include "sf_api_internal.h"
 #include "sf_util.h"
+#include "sf_gemm_epilogue.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -37,10 +38,8 @@ constexpr int kBufBytes = 2 * kOpBytes;      // A + B
 struct GemmW4Args {
     const sf_bf16* A; long lda;
     const sf_bf16* B; long ldb;
-    void* C; long ldc;
-    const sf_bf16* R; long ldr;
+    SfGemmEpi e;
     int M, N, K;
-    float alpha, beta;
     int tiles_m, tiles_n;
     int gm;
 };
@@ -69,55 +68,14 @@ SF_DEVICE void w4_tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int G
     tn = in_g / gsize;
 }
 
-// C[m][n..n+3] = alpha*v (+beta*C) (+R), bf16 or fp32 output, ragged N handled
-template <int OUT_F32>
+template <int OUT_F32, int ADD = 1>
 SF_DEVICE void w4_store4(const GemmW4Args& p, int m, int n, sf_v4f acc) {
-    if (m >= p.M || n >= p.N) return;
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = acc[r] * p.alpha;
-    const bool full = (n + 3 < p.N);
-    if (OUT_F32) {
-        float* c = (float*)p.C + (long)m * p.ldc + n;
-        if (full) {
-            if (p.beta != 0.f) {
-                sf_v4f o = *reinterpret_cast<const sf_v4f*>(c);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += p.beta * o[r];
-            }
-            *reinterpret_cast<sf_v4f*>(c) = sf_v4f{v[0], v[1], v[2], v[3]};
-        } else {
-            for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = v[r] + (p.beta != 0.f ? p.beta * c[r] : 0.f);
-        }
-    } else {
-        sf_bf16* c = (sf_bf16*)p.C + (long)m * p.ldc + n;
-        if (full) {
-            if (p.beta != 0.f) {
-                sf_v4s o = *reinterpret_cast<const sf_v4s*>(c);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += p.beta * sf_bf2f((sf_bf16)o[r]);
-            }
-            if (p.R) {  // round the projection first, then add the residual (bf16 + bf16)
-                sf_v4s rr = *reinterpret_cast<const sf_v4s*>(p.R + (long)m * p.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = sf_round_bf(v[r]) + sf_bf2f((sf_bf16)rr[r]);
-            }
-            sf_v4s o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (short)sf_f2bf(v[r]);
-            *reinterpret_cast<sf_v4s*>(c) = o;
-        } else {
-            for (int r = 0; r < 4 && n + r < p.N; ++r) {
-                float t2 = v[r] + (p.beta != 0.f ? p.beta * sf_bf2f(c[r]) : 0.f);
-                if (p.R) t2 = sf_round_bf(t2) + sf_bf2f(p.R[(long)m * p.ldr + n + r]);
-                c[r] = sf_f2bf(t2);
-            }
-        }
-    }
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    sf_gemm_store4<OUT_F32, ADD>(p.e, m, n, v);
 }
 
 // ABL (timing ablations only, results are wrong): bit0 = no ds_reads after the first tile, bit1 = no DMA in the loop
-template <int OUT_F32, int ABL = 0, int BUF = 0>
+template <int OUT_F32, int ABL = 0, int BUF = 0, int ADD = 0>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     SF_DYN_SMEM(smem);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
@@ -249,7 +207,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            w4_store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
+            w4_store4<OUT_F32, ADD>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
 }
 
 
@@ -488,15 +446,14 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4m32_kernel(GemmW4Args p) {
 #endif
 
 // launched by sf_gemm_nt (sf_gemm.hip) when the shape qualifies
-int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M,
-                            int N, int K, float alpha, float beta, const void* R, long ldr, void* stream) {
+int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype,
+                            void* stream) {
+    const int M = e.M, N = e.N;
     GemmW4Args p;
     p.A = (const sf_bf16*)A; p.lda = lda;
     p.B = (const sf_bf16*)B; p.ldb = ldb;
-    p.C = C; p.ldc = ldc;
-    p.R = (const sf_bf16*)R; p.ldr = ldr;
+    p.e = e;
     p.M = M; p.N = N; p.K = K;
-    p.alpha = alpha; p.beta = beta;
     p.tiles_m = (M + TM - 1) / TM;
     p.tiles_n = (N + TN - 1) / TN;
     { const char* e = getenv("SF_GEMM_GM"); p.gm = e ? atoi(e) : 4; if (p.gm < 1) p.gm = 1; }
@@ -538,6 +495,16 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, vo
             SF_LAUNCH((gemm_nt_256w4_kernel<0, 0, 1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
         }
         return sf_check_launch("sf_gemm_nt(256w4 buf)");
+    }
+    if (p.e.Cadd) {
+        if (c_dtype == SF_F32) {
+            SF_W4_SMEM((gemm_nt_256w4_kernel<1, 0, 0, 1>));
+            SF_LAUNCH((gemm_nt_256w4_kernel<1, 0, 0, 1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+        } else {
+            SF_W4_SMEM((gemm_nt_256w4_kernel<0, 0, 0, 1>));
+            SF_LAUNCH((gemm_nt_256w4_kernel<0, 0, 0, 1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+        }
+        return sf_check_launch("sf_gemm_nt(256w4 rowadd)");
     }
     if (c_dtype == SF_F32) {
         SF_W4_SMEM((gemm_nt_256w4_kernel<1>));

@@ -60,6 +60,19 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, alpha: float
     return out
 
 
+def gemm_nt_rowadd(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, addend: torch.Tensor, *, S: int, Spad: int, off: int,
+                   alpha: float = 1.0):
+    """out[r] = round(alpha * a[r] @ b^T + addend[(r // S) * Spad + r % S + off]); addend fp32 [B*Spad, N]."""
+    L = _lib.lib()
+    M, K = a.shape
+    N, K2 = b.shape
+    assert K == K2 and out.shape == (M, N) and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    assert addend.dtype == torch.float32 and addend.shape[1] == N and addend.shape[0] >= (M // S) * Spad
+    _lib.check(L.sf_gemm_nt_rowadd(_p(a), _rowmajor(a), _p(b), _rowmajor(b), _p(out), _dt(out), _rowmajor(out), M, N, K,
+                                   alpha, _p(addend), _rowmajor(addend), S, Spad, off, _stream()), "sf_gemm_nt_rowadd")
+    return out
+
+
 def ce_fused(logits: torch.Tensor, target_pad: torch.Tensor, *, S: int, Spad: int, off: int, pos_mask_pad, loss_mask_pad,
              tgt_ids_pad=None, pod_scale_pad=None, tsum_pad=None, d2t=None, grad_scale: float = 1.0, write_grad: bool = True,
              row_loss, row_correct, row_accept, row_pred=None):

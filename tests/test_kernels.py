@@ -42,6 +42,23 @@ def test_gemm_nt(backend, M, N, K, out_dtype):
     torch.testing.assert_close(out.float().cpu(), ref, rtol=tol, atol=tol * math.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K,S,T", [(64, 48, 64, 16, 3), (512, 264, 128, 64, 2)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_nt_rowadd(backend, M, N, K, S, T, out_dtype):
+    """fp32 row-mapped addend joins the accumulator before the single rounding (embedding half of the TTT QKV)"""
+    a = _rand((M, K), torch.bfloat16, 1)
+    b = _rand((N, K), torch.bfloat16, 2)
+    B, Spad = M // S, S + T
+    add = _rand((B * Spad, N), torch.float32, 3, scale=3.0)
+    for off in (0, T):
+        rows = (torch.arange(M) // S) * Spad + torch.arange(M) % S + off
+        ref = a.float() @ b.float().t() + add[rows]
+        out = torch.full((M, N), 7.0, dtype=out_dtype, device=backend)
+        ops.gemm_nt_rowadd(_dev(backend, a), _dev(backend, b), out, _dev(backend, add), S=S, Spad=Spad, off=off)
+        tol = 1e-3 if out_dtype == torch.float32 else 2e-2
+        torch.testing.assert_close(out.float().cpu(), ref, rtol=tol, atol=tol * math.sqrt(K))
+
+
 def test_gemm_nt_epilogues(backend):
     M, N, K = 136, 72, 128
     a, b = _rand((M, K), torch.bfloat16, 3), _rand((N, K), torch.bfloat16, 4)
