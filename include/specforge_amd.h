@@ -124,6 +124,15 @@ int sf_transpose(const void* in, int dtype, long in_b1, long in_b2, long in_ld, 
 /* out = a + b over n bf16 elements (n % 8 == 0; fp32 add, one rounding): the gradient sum autograd forms where the
  * un-normed hidden state feeds both lm_head and the next TTT step when norm_output=False (llama3_eagle.py:1772-1777). */
 int sf_add_bf16(long n, const void* a, const void* b, void* out, void* stream);
+/* dst[b*Spad + s + off][:] += src[b*S + s][:] (bf16 -> fp32): running sum over the TTT steps of the q/k/v gradient
+ * re-aligned to token positions, so that the embedding half of the QKV dgrad / wgrad (whose input is the same
+ * token shifted by the step index, specforge/algorithms/eagle3/model.py:428-432) is contracted once, not T times. */
+int sf_shift_accum(const void* src, long ldsrc, float* dst, long lddst, int B, int S, int Spad, int off, int C,
+                   void* stream);
+/* hi = bf16(x), lo = bf16(x - hi): two-term bf16 expansion of an fp32 matrix, so the summed gradient above enters the
+ * bf16 MFMA GEMM with 16 mantissa bits (the reference adds T bf16 products in fp32; rounding the sum once to 8 bits
+ * would be coarser than that). */
+int sf_split_bf16(const float* in, long ldin, void* hi, void* lo, long ldout, long rows, int C, void* stream);
 /* y = (accumulate ? y : 0) + alpha*x, fp32: carries norm-weight gradients across micro-steps. */
 int sf_axpy_f32(long n, float alpha, const float* x, float* y, int accumulate, void* stream);
 int sf_cast_from_f32(const float* in, long ldin, void* out, int dtype, long ldout, long rows, int C, float scale,

@@ -170,6 +170,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                 const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
                 acc[mt][nt] = sf_mfma16(f[0][nt], f[0][8 + mt], acc[mt][nt]);
             }
+            w4_fence();   // MFMAs first, then this group's loads (the compiler otherwise hoists the loads and waits on them)
             if (g < 8 && !((ABL & 1) && t > 0)) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
             w4_fence();
         }
@@ -184,6 +185,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                 const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
                 acc[mt][nt] = sf_mfma16(f[1][nt], f[1][8 + mt], acc[mt][nt]);
             }
+            w4_fence();
             // reads front-loaded (groups 0..11) so that the next half-step's first MFMA never waits on them
             if constexpr (decltype(READ_NEXT)::value && !(ABL & 1)) {
                 if (g < 4) { read_frag(0, 2 * g, nxt, 0); read_frag(0, 2 * g + 1, nxt, 0); }

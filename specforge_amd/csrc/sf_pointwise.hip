@@ -437,6 +437,62 @@ extern "C" int sf_cast_from_f32(const float* in, long ldin, void* out, int dtype
     return sf_check_launch("sf_cast_from_f32");
 }
 
+namespace {
+// dst[b*Spad + s + off][c] += src[b*S + s][c]   (bf16 -> fp32 running sum; 8 columns per thread)
+SF_GLOBAL void shift_accum_kernel(const sf_bf16* src, long ldsrc, float* dst, long lddst, long rows, int S, int Spad,
+                                  int off, int C8) {
+    const long total = rows * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C8;
+        const int c = (int)(i - r * C8) * 8;
+        const long b = r / S;
+        const long dr = b * Spad + (r - b * S) + off;
+        float x[8], y[8];
+        SfVec8<sf_bf16>::ld(src + r * ldsrc + c, x);
+        SfVec8<float>::ld(dst + dr * lddst + c, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] += x[j];
+        SfVec8<float>::st(dst + dr * lddst + c, y);
+    }
+}
+// hi = bf16(x), lo = bf16(x - hi): a two-term bf16 expansion (16 mantissa bits) of an fp32 matrix
+SF_GLOBAL void split_bf16_kernel(const float* in, long ldin, sf_bf16* hi, sf_bf16* lo, long ldout, long rows, int C8) {
+    const long total = rows * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C8;
+        const int c = (int)(i - r * C8) * 8;
+        float x[8], h[8], l[8];
+        SfVec8<float>::ld(in + r * ldin + c, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            h[j] = sf_round_bf(x[j]);
+            l[j] = x[j] - h[j];
+        }
+        SfVec8<sf_bf16>::st(hi + r * ldout + c, h);
+        SfVec8<sf_bf16>::st(lo + r * ldout + c, l);
+    }
+}
+}  // namespace
+
+extern "C" int sf_shift_accum(const void* src, long ldsrc, float* dst, long lddst, int B, int S, int Spad, int off, int C,
+                              void* stream) {
+    SF_CHECK_ARG(B >= 0 && S > 0 && Spad >= S && off >= 0 && off + S <= Spad, "sf_shift_accum: bad shape");
+    SF_CHECK_ARG(C >= 0 && C % 8 == 0 && ldsrc % 8 == 0 && lddst % 8 == 0, "sf_shift_accum: C and strides must be multiples of 8");
+    const long rows = (long)B * S;
+    if (rows == 0 || C == 0) return 0;
+    SF_LAUNCH(shift_accum_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, stream, (const sf_bf16*)src, ldsrc, dst, lddst,
+              rows, S, Spad, off, C / 8);
+    return sf_check_launch("sf_shift_accum");
+}
+
+extern "C" int sf_split_bf16(const float* in, long ldin, void* hi, void* lo, long ldout, long rows, int C, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && C >= 0 && C % 8 == 0 && ldin % 8 == 0 && ldout % 8 == 0, "sf_split_bf16: bad shape");
+    if (rows == 0 || C == 0) return 0;
+    SF_LAUNCH(split_bf16_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, stream, in, ldin, (sf_bf16*)hi, (sf_bf16*)lo,
+              ldout, rows, C / 8);
+    return sf_check_launch("sf_split_bf16");
+}
+
 extern "C" long sf_grad_norm_workspace_floats(void) { return 1024; }
 
 // norm_out[0] = prescale * sqrt(sum float(g)^2)   (prescale = 1/world for SUM-reduced grads)

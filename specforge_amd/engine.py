@@ -103,11 +103,20 @@ class Eagle3Engine:
         b["lse"] = [self._e(B, nh, S, dtype=f32) for _ in range(T)]
         b["gu"] = [self._e(N, 2 * I) for _ in range(T)]
         b["dln"] = [self._e(N, H) for _ in range(T)]
-        for nm in ("rstd_e", "rstd_h", "rstd_p", "rstd_n"):
+        for nm in ("rstd_h", "rstd_p", "rstd_n"):
             b[nm] = [self._e(N, dtype=f32) for _ in range(T)]
+        # embedding half of the QKV projection, hoisted out of the TTT loop: step k's token at position s is step 0's
+        # token at s + k (eagle3/model.py:428-432), so input_layernorm(embed(.)) and its product with Wqkv[:, :H] are
+        # computed once over the padded [B, S+T] positions and re-used by every step (sf_gemm_nt_rowadd)
+        b["Np_real"] = B * Spad
+        Np = (B * Spad + 31) // 32 * 32       # 2*Np is the K of a wgrad GEMM (64-aligned K -> 256-tile kernels); extra rows stay zero
+        b["Np"] = Np
+        b["en"] = torch.zeros(Np, H, dtype=torch.bfloat16, device=self.dev)
+        b["rstd_e1"] = self._e(Np, dtype=f32)
+        b["epart"] = self._e(Np, self.QW, dtype=f32)
         b["rstd_fc"] = [self._e(N, dtype=f32) for _ in range(3)]
         # transient per-step work buffers
-        b["xcat"] = self._e(N, 2 * H)
+        b["hn"] = self._e(N, H)
         b["pn"] = self._e(N, H)
         b["act"] = self._e(N, I)
         b["ln"] = self._e(N, H)
@@ -119,7 +128,7 @@ class Eagle3Engine:
         b["lk_logsum"] = torch.zeros(T, dtype=f32, device=self.dev)   # LK: sum_r m_r log(accept_r) per TTT step
         # transposed stashes for the deferred, K-concatenated wgrad GEMMs: [features, T*N]
         TN = T * N
-        for nm, feat in (("xcatT", 2 * H), ("oT", nh * hd), ("pnT", H), ("actT", I), ("lnT", H), ("dlogT", Vd),
+        for nm, feat in (("hnT", H), ("oT", nh * hd), ("pnT", H), ("actT", I), ("lnT", H), ("dlogT", Vd),
                          ("dhT", H), ("dguT", 2 * I), ("dh1T", H), ("dqkvT", self.QW)):
             b[nm] = self._e(feat, TN)
         b["hsT"] = self._e(Ht3, N)
@@ -131,13 +140,21 @@ class Eagle3Engine:
         b["dpn"] = self._e(N, H)
         b["do"] = self._e(N, nh * hd)
         b["dqkv"] = self._e(N, self.QW)
-        b["dxcat"] = self._e(N, 2 * H)
+        b["dxh"] = self._e(N, H)
+        # backward of the hoisted embedding half: fp32 sum over the steps of dqkv re-aligned to token positions, its
+        # two-term bf16 expansion (transposed, K-concatenated) for the wgrad, and the matching operand [en^T | en^T]
+        b["dsum"] = self._e(Np, self.QW, dtype=f32)
+        b["ds_hi"], b["ds_lo"] = self._e(Np, self.QW), self._e(Np, self.QW)
+        b["dsT"] = self._e(self.QW, 2 * Np)
+        b["enT2"] = self._e(H, 2 * Np)
+        b["dE"] = self._e(Np, H)
         b["dhs"] = self._e(N, Ht3) if c.fc_norm else None
         b["delta"] = self._e(B, nh, S, dtype=f32)
         b["dq_init"] = self._e(N, nh * hd, dtype=f32)
         b["dk"] = [self._e(N, nkv * hd, dtype=f32) for _ in range(T)]
         b["dv"] = [self._e(N, nkv * hd, dtype=f32) for _ in range(T)]
         b["nws"] = self._e(ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)
+        b["nws_e"] = self._e(ops.rmsnorm_bwd_workspace(Np, H), dtype=f32)
         self._bufs[key] = b
         return b
 
@@ -242,14 +259,21 @@ class Eagle3Engine:
         if lk is not None:
             for k in range(T):
                 b["msum"][k] = b["pm"][:, k:k + S].sum()
+        # input_layernorm(embed(ids)) . Wqkv[:, :H]^T for every padded position, once (fp32, joins each step's
+        # accumulator before the rounding)
+        Np = b["Np"]
+        ops.rmsnorm_fwd(self.model.embed_tokens.weight.data, f.view("midlayer.input_layernorm.weight"), eps, b["en"],
+                        b["rstd_e1"], ids_pad=b["ids"], S=Spad, Spad=Spad, off=0, rows=b["Np_real"])
+        ops.gemm_nt(b["en"], self.w_qkv[:, :H], b["epart"])
+        if train:
+            ops.transpose2d(b["en"], b["enT2"][:, :Np])
+            ops.transpose2d(b["en"], b["enT2"][:, Np:])
         for k in range(T):
             cols = slice(k * N, (k + 1) * N)
-            xcat, qkv = b["xcat"], b["qkv"][k]
-            # input_layernorm(embed(ids<<k)) | hidden_norm(h_k)   (llama3_eagle.py:1625-1630)
-            ops.rmsnorm_fwd(self.model.embed_tokens.weight.data, f.view("midlayer.input_layernorm.weight"), eps, xcat[:, :H],
-                            b["rstd_e"][k], ids_pad=b["ids"], S=S, Spad=Spad, off=k, rows=N)
-            ops.rmsnorm_fwd(b["h"][k], f.view("midlayer.hidden_norm.weight"), eps, xcat[:, H:], b["rstd_h"][k])
-            ops.gemm_nt(xcat, self.w_qkv, qkv)
+            hn, qkv = b["hn"], b["qkv"][k]
+            # q/k/v of cat(input_layernorm(embed(ids<<k)), hidden_norm(h_k))   (llama3_eagle.py:1625-1630)
+            ops.rmsnorm_fwd(b["h"][k], f.view("midlayer.hidden_norm.weight"), eps, hn, b["rstd_h"][k])
+            ops.gemm_nt_rowadd(hn, self.w_qkv[:, H:], qkv, b["epart"], S=S, Spad=Spad, off=k)
             ops.rope_(qkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k)
             ops.attn_fwd(qkv[:, :nh * hd], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], [b["qkv"][i][:, kcol] for i in range(1, k + 1)],
                          [b["qkv"][i][:, vcol] for i in range(1, k + 1)], b["kvlen"], b["o"][k], b["lse"][k],
@@ -285,7 +309,7 @@ class Eagle3Engine:
                 ops.gemm_nt(b["logits"], self.wlmT, b["dln"][k])        # lm_head dgrad, taken now
                 ops.transpose2d(b["logits"], b["dlogT"][:, cols])
                 ops.transpose2d(ln, b["lnT"][:, cols])
-                ops.transpose2d(xcat, b["xcatT"][:, cols])
+                ops.transpose2d(hn, b["hnT"][:, cols])
                 ops.transpose2d(b["o"][k], b["oT"][:, cols])
                 ops.transpose2d(b["pn"], b["pnT"][:, cols])
                 ops.transpose2d(b["act"], b["actT"][:, cols])
@@ -336,6 +360,7 @@ class Eagle3Engine:
         ws = b["nws"]
         for t in b["dk"] + b["dv"]:
             t.zero_()
+        b["dsum"].zero_()
         nm = self._norm_micro
         first = {n: True for n in nm}
 
@@ -385,18 +410,27 @@ class Eagle3Engine:
             ops.cast_from_f32(b["dv"][k], dqkv[:, vcol])
             ops.rope_(dqkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k, backward=True)
             ops.transpose2d(dqkv, b["dqkvT"][:, cols])
-            ops.gemm_nt(dqkv, self.wqkvT, b["dxcat"])
+            ops.gemm_nt(dqkv, self.wqkvT[H:], b["dxh"])                 # hidden half of the QKV dgrad
+            ops.shift_accum(dqkv, b["dsum"], B=B, S=S, Spad=Spad, off=k)   # embedding half: summed over the steps first
             dh_prev = b["dh_b"]
             acc, a = nacc("midlayer.hidden_norm.weight")
-            ops.rmsnorm_bwd(b["dxcat"][:, H:], b["h"][k], f.view("midlayer.hidden_norm.weight"), b["rstd_h"][k],
+            ops.rmsnorm_bwd(b["dxh"], b["h"][k], f.view("midlayer.hidden_norm.weight"), b["rstd_h"][k],
                             dx=dh_prev, add=b["dh1"], dw_acc=acc, dw_accumulate=a, workspace=ws)
-            acc, a = nacc("midlayer.input_layernorm.weight")
-            ops.rmsnorm_bwd(b["dxcat"][:, :H], self.model.embed_tokens.weight.data, f.view("midlayer.input_layernorm.weight"),
-                            b["rstd_e"][k], dx=None, dw_acc=acc, dw_accumulate=a, workspace=ws, ids_pad=b["ids"], S=S,
-                            Spad=Spad, off=k)
             dh_next = dh_prev  # dh_b was consumed (as `add`) before it is rewritten in the next iteration
         dh0 = dh_next
         ops.transpose2d(dh0, b["dh0T"])
+        # embedding half of the QKV backward, once for all steps.  The summed gradient enters the bf16 GEMMs as a
+        # two-term expansion hi + lo for the weight gradient; input_layernorm.weight only needs the leading term (the
+        # reference rounds every step's d(input) to bf16 before the norm backward, which is coarser than that).
+        Np = b["Np"]
+        ops.split_bf16(b["dsum"], b["ds_hi"], b["ds_lo"])
+        ops.transpose2d(b["ds_hi"], b["dsT"][:, :Np])
+        ops.transpose2d(b["ds_lo"], b["dsT"][:, Np:])
+        ops.gemm_nt(b["ds_hi"], self.wqkvT[:H], b["dE"])
+        acc, a = nacc("midlayer.input_layernorm.weight")
+        ops.rmsnorm_bwd(b["dE"][:b["Np_real"]], self.model.embed_tokens.weight.data, f.view("midlayer.input_layernorm.weight"),
+                        b["rstd_e1"], dx=None, dw_acc=acc, dw_accumulate=a, workspace=b["nws_e"], ids_pad=b["ids"], S=Spad,
+                        Spad=Spad, off=0)
         if c.fc_norm:
             ops.gemm_nt(dh0, self.wfcT, b["dhs"])
             hs = self._last_hs
@@ -412,13 +446,17 @@ class Eagle3Engine:
             ("midlayer.mlp.gate_proj.weight", "midlayer.mlp.up_proj.weight", b["dguT"], b["pnT"], self.g_gu),
             ("midlayer.mlp.down_proj.weight", "midlayer.mlp.down_proj.weight", b["dhT"], b["actT"],
              f.gview("midlayer.mlp.down_proj.weight")),
-            ("midlayer.self_attn.q_proj.weight", "midlayer.self_attn.v_proj.weight", b["dqkvT"], b["xcatT"], self.g_qkv),
+            ("midlayer.self_attn.q_proj.weight", "midlayer.self_attn.v_proj.weight", b["dqkvT"], b["hnT"], self.g_qkv),
             ("midlayer.self_attn.o_proj.weight", "midlayer.self_attn.o_proj.weight", b["dh1T"], b["oT"],
              f.gview("midlayer.self_attn.o_proj.weight")),
             ("fc.weight", "fc.weight", b["dh0T"], b["hsT"], f.gview("fc.weight")),
         ]
         for first_name, last_name, dyT, xT, gout in jobs:
-            ops.gemm_nt(dyT, xT, gout, alpha=g, beta=beta)
+            if gout is self.g_qkv:   # [QW, 2H] = [ embedding half | hidden half ]
+                ops.gemm_nt(b["dsT"], b["enT2"], gout[:, :H], alpha=g, beta=beta)
+                ops.gemm_nt(dyT, xT, gout[:, H:], alpha=g, beta=beta)
+            else:
+                ops.gemm_nt(dyT, xT, gout, alpha=g, beta=beta)
             if self.on_bucket_ready is not None:
                 self.on_bucket_ready(f.slices[first_name][0], f.slices[last_name][1])
         # norm weights: fp32 running total over the window, then one cast into the flat gradient

@@ -204,6 +204,25 @@ def add_bf16(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor):
     return out
 
 
+def shift_accum(src: torch.Tensor, dst: torch.Tensor, *, B: int, S: int, Spad: int, off: int):
+    """dst[b*Spad + s + off] += src[b*S + s]  (src bf16 [B*S, C], dst fp32 [B*Spad, C])"""
+    L = _lib.lib()
+    assert src.dtype == torch.bfloat16 and dst.dtype == torch.float32 and src.shape == (B * S, dst.shape[1])
+    assert dst.shape[0] >= B * Spad
+    _lib.check(L.sf_shift_accum(_p(src), _rowmajor(src), _p(dst), _rowmajor(dst), B, S, Spad, off, src.shape[1], _stream()),
+               "sf_shift_accum")
+    return dst
+
+
+def split_bf16(x: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor):
+    """hi = bf16(x), lo = bf16(x - hi)"""
+    L = _lib.lib()
+    assert x.dtype == torch.float32 and hi.dtype == lo.dtype == torch.bfloat16 and hi.shape == lo.shape == x.shape
+    assert _rowmajor(hi) == _rowmajor(lo)
+    _lib.check(L.sf_split_bf16(_p(x), _rowmajor(x), _p(hi), _p(lo), _rowmajor(hi), x.shape[0], x.shape[1], _stream()),
+               "sf_split_bf16")
+
+
 def axpy_f32(alpha: float, x: torch.Tensor, y: torch.Tensor, accumulate: bool = True):
     L = _lib.lib()
     assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.numel() == y.numel()

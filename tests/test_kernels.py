@@ -184,6 +184,27 @@ def test_ce_lk_grad(backend, lk, dtype, tol):
     assert float(xk.float().cpu()[sl(pos_pad) == 0].abs().max()) == 0.0   # masked rows: exactly zero
 
 
+def test_shift_accum_and_split(backend):
+    g = torch.Generator().manual_seed(5)
+    B, S, T, C = 3, 8, 3, 24
+    Spad = S + T
+    dst = torch.randn(B * Spad, C, generator=g)
+    ref = dst.clone()
+    dd = dst.to(backend)
+    for off in (0, 2, T):
+        src = torch.randn(B * S, C, generator=g).to(torch.bfloat16)
+        ops.shift_accum(src.to(backend), dd, B=B, S=S, Spad=Spad, off=off)
+        ref.view(B, Spad, C)[:, off:off + S] += src.float().view(B, S, C)
+    assert torch.equal(dd.cpu(), ref)   # fp32 adds of exactly representable terms in the same order
+    hi = torch.empty(B * Spad, C, dtype=torch.bfloat16, device=backend)
+    lo = torch.empty_like(hi)
+    ops.split_bf16(dd, hi, lo)
+    h = ref.to(torch.bfloat16)
+    assert torch.equal(hi.cpu(), h) and torch.equal(lo.cpu(), (ref - h.float()).to(torch.bfloat16))
+    err = (hi.cpu().float() + lo.cpu().float() - ref).abs().max() / ref.abs().max()
+    assert float(err) < 2 ** -15
+
+
 def test_add_bf16(backend):
     g = torch.Generator().manual_seed(3)
     a = torch.randn(40, 24, generator=g).to(torch.bfloat16)
