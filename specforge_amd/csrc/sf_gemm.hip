@@ -145,7 +145,9 @@ static int sf_gemm_dispatch(const void* A, long lda, const void* B, long ldb, in
     // SF_GEMM_W4=0 pins the ping-pong kernel, =1 forces the 4-wave kernel for every 256-tile shape (A/B knob).
     static const int w4_mode = [] { const char* en = getenv("SF_GEMM_W4"); return en ? atoi(en) : -1; }();
     const bool big = (long)((M + 255) / 256) * ((N + 255) / 256) >= 256 && K >= 512;
-    if (K % 64 == 0 && K >= 64 && M >= 192 && N >= 192 && sf_gemm_use_256() && (w4_mode == 1 || (w4_mode < 0 && big)))
+    const bool w4_ok = !(e.Cadd && e.alpha != 1.0f);   // its addend path starts the accumulators from Cadd
+    if (K % 64 == 0 && K >= 64 && M >= 192 && N >= 192 && sf_gemm_use_256() && w4_ok &&
+        (w4_mode == 1 || (w4_mode < 0 && big)))
         return sf_gemm_nt_256w4_launch(A, lda, B, ldb, K, e, c_dtype, stream);
     if (K % 64 == 0 && K >= 64 && M >= 192 && N >= 192 && sf_gemm_use_256())
         return sf_gemm_nt_256_launch(A, lda, B, ldb, K, e, c_dtype, stream);

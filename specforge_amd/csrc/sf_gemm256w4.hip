@@ -139,6 +139,26 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
+    if (ADD) {
+        // row-mapped fp32 addend: START the accumulators from it (alpha == 1 is enforced by the launcher), so the
+        // K loop and the epilogue are exactly the plain kernel's -- the loads overlap the staging of K-tiles 0 and 1
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+            if (m < p.M) {
+                const int bb = m / p.e.add_S;
+                const float* a = p.e.Cadd + ((long)bb * p.e.add_Spad + (m - bb * p.e.add_S) + p.e.add_off) * p.e.ldadd;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = n0 + wc * 128 + j * 16 + 4 * (lane >> 4);
+                    if (n + 3 < p.N) acc[i][j] = *reinterpret_cast<const sf_v4f*>(a + n);
+                    else
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < p.N) acc[i][j][r] = a[n + r];
+                }
+            }
+        }
+    }
     sf_v8s f[2][16];  // [set][0..7 = B n-tiles, 8..15 = A m-tiles]
 
     auto read_frag = [&](int set, int g, const char* buf, int ks) {
@@ -209,7 +229,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            w4_store4<OUT_F32, ADD>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
+            w4_store4<OUT_F32, 0>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
 }
 
 
@@ -499,6 +519,7 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
         return sf_check_launch("sf_gemm_nt(256w4 buf)");
     }
     if (p.e.Cadd) {
+        SF_CHECK_ARG(p.e.alpha == 1.0f, "sf_gemm_nt_rowadd: the 4-wave kernel needs alpha == 1");
         if (c_dtype == SF_F32) {
             SF_W4_SMEM((gemm_nt_256w4_kernel<1, 0, 0, 1>));
             SF_LAUNCH((gemm_nt_256w4_kernel<1, 0, 0, 1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
