@@ -184,7 +184,7 @@ def main():
         # collected from inside the timed run, so this field is null when the summary is absent.
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_write_summary.json")))["gemm256"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_write_summary.json")))["gemm256w4"]
             traffic = (2.0 * pm["FETCH_SIZE_sum"] + pm["WRITE_SIZE_sum"]) * 1024.0 / pm["launches"]
         except Exception:
             pass
@@ -196,7 +196,7 @@ def main():
             "config": {"workload": ("SMALL-debug" if args.small else "Llama-3-8B EAGLE3 offline draft")
                        + f", bf16, per-GPU batch {B} x seq {S}, ttt {args.ttt}, optimizer step included",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256_kernel (bf16 MFMA GEMM, 256x256x64 ping-pong)", "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_256w4_kernel (bf16 MFMA GEMM, 256x256x64, 4 waves x 128x128, software-pipelined)", "achieved": ach,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "launches_per_step": nlaunch / max(1, args.steps),
                          "gemm_ms_per_step": gemm_ms / max(1, args.steps)},
