@@ -76,7 +76,7 @@ SF_DEVICE void stage_rows64(char* lds, const sf_bf16* base, long ld, int row0, i
         const int pc = lane % CPR;
         const int lc = pc ^ swz<HD>(rr);
         const sf_bf16* src = (row0 + rr < nrows_valid) ? base + (long)(row0 + rr) * ld + lc * 8 : sf_zero16a;
-        sf_glds16(src, lds + (wave * NI + t) * 1024);  // uniform base; lane i lands at +16*i
+        sf_glds16_opaque(src, lds + (wave * NI + t) * 1024);  // uniform base; lane i lands at +16*i
     }
 }
 // Per-lane LDS byte offsets of the MFMA fragments, computed once per kernel so the tile loops issue

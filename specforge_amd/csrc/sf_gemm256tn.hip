@@ -1,0 +1,230 @@
+// "TN" form of the 4-wave 256x256x64 bf16 MFMA GEMM:   C[M,N] = alpha * A^T . B (+ beta * C)
+// with A stored [K, M] and B stored [K, N] (row-major, the contraction index outermost).
+//
+// This is the weight-gradient form of a linear layer: dW[out, in] = dY^T . X with dY [tokens, out] and
+// X [tokens, in] exactly as the forward / backward sweep produced them (the reference gets it from autograd's
+// `grad_output.t() @ input`, e.g. for llama3_eagle.py:555-566,1513-1515,1674-1693).  Feeding those natural layouts
+// straight to the GEMM removes every operand transpose (and the transposed stash copies) that the NT-only
+// kernels needed: 70 transposes / 48 GB of traffic per training step at cfg 2.
+//
+// Same pipeline as sf_gemm256w4.hip (4 waves x 128x128, one wave per SIMD, fragments double-buffered in
+// registers, LDS-DMA threaded between the MFMAs, one barrier per K-tile).  What differs is the LDS image and the
+// fragment reads:
+//   * a K-tile of an operand is staged as two half-tiles of 128 columns: [64 k][256 B], i.e. rows of the
+//     SOURCE matrix land as rows of LDS (an LDS-DMA instruction moves 4 k-rows x 256 B);
+//   * an MFMA fragment (16 columns x 32 k, 8 consecutive k per lane) is therefore a TRANSPOSED read: two
+//     ds_read_b64_tr_b16 per fragment (each returns 4 k-values of the lane's column from a 4 x 16 block);
+//   * bank conflicts of those reads are broken by permuting the 16-byte chunks of k-row k with
+//     c -> c ^ (2*((k & 3) | ((k >> 3) & 1) << 2)), applied to the global source address (the LDS image must stay
+//     lane-linear for LDS-DMA) and again to the read address.
+// Shapes: K % 64 == 0 (the caller pads its token stash with zero rows), M, N >= 8 and multiples of 8; edge tiles
+// re-read the last valid 8 columns (they only feed accumulators that are never stored).
+#include "sf_api_internal.h"
+#include "sf_util.h"
+#include "sf_gemm_epilogue.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int kHalfBytes = 128 * TK * 2;     // 16 KiB: [64 k][256 B]
+constexpr int kBufBytes = 4 * kHalfBytes;    // A0 A1 B0 B1
+
+struct GemmTnArgs {
+    const sf_bf16* A; long lda;   // [K, M]
+    const sf_bf16* B; long ldb;   // [K, N]
+    SfGemmEpi e;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    int gm;
+};
+
+#ifdef SF_EMU
+SF_DEVICE void tn_barrier() { sfemu::block_barrier(); }
+SF_DEVICE void tn_wait_all() {}
+SF_DEVICE void tn_fence() {}
+#else
+SF_DEVICE void tn_barrier() { __builtin_amdgcn_s_barrier(); }
+SF_DEVICE void tn_wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+SF_DEVICE void tn_fence() { __builtin_amdgcn_sched_barrier(0); }
+#endif
+
+SF_DEVICE void tn_tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int GM, int& tm, int& tn) {
+    const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    const int per_group = GM * tiles_n;
+    const int g = seq / per_group;
+    const int first_m = g * GM;
+    const int gsize = (tiles_m - first_m < GM) ? (tiles_m - first_m) : GM;
+    const int in_g = seq - g * per_group;
+    tm = first_m + in_g % gsize;
+    tn = in_g / gsize;
+}
+
+template <int OUT_F32>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4_kernel(GemmTnArgs p) {
+    SF_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
+    const int wr = wave >> 1, wc = wave & 1;
+    int tm, tn;
+    tn_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int nkt = p.K / TK;
+
+    // ---- DMA sources: half hh (0,1 = A columns m0+0.., m0+128..; 2,3 = B) is 16 pieces of 4 k-rows x 256 B; this wave
+    // stages pieces 4*wave .. 4*wave+3 of every half.  Lane: k-row skr = lane>>4 of the piece, physical chunk lane&15.
+    const int skr = lane >> 4;
+    const sf_bf16* src[16];
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int krow = (4 * wave + j) * 4 + skr;
+            const int hk = (krow & 3) | (((krow >> 3) & 1) << 2);
+            const int lc = (lane & 15) ^ (hk << 1);            // logical 16-byte chunk fetched into physical chunk lane&15
+            const bool isA = hh < 2;
+            const int dim = isA ? p.M : p.N;
+            int col = (isA ? m0 : n0) + (hh & 1) * 128 + lc * 8;
+            col = col + 8 <= dim ? col : dim - 8;
+            src[hh * 4 + j] = (isA ? p.A + (long)krow * p.lda : p.B + (long)krow * p.ldb) + col;
+        }
+    const long incA = (long)TK * p.lda, incB = (long)TK * p.ldb;
+    auto dma = [&](int g, int kt) {  // g = hh*4 + j: piece 4*wave+j of half hh of the next un-issued K-tile
+        char* dst = smem + (kt & 1) * kBufBytes + (g >> 2) * kHalfBytes + (4 * wave + (g & 3)) * 1024;
+        sf_glds16_opaque(src[g], dst);
+        src[g] += (g < 8) ? incA : incB;
+    };
+
+    // ---- fragment reads (transposed): lane constants of ds_read_b64_tr_b16 into the [64 k][256 B] image
+    const int fi = lane & 15, fg = lane >> 4;
+    const int fh = (fi >> 2) | ((fg & 1) << 2);
+    const int frag_lane = (8 * fg + (fi >> 2)) * 256 + ((fi >> 1) & 1) * 16 + (fi & 1) * 8;
+    const int a_half = wr * kHalfBytes, b_half = (2 + wc) * kHalfBytes;
+
+    sf_v4f acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
+    sf_v8s f[2][16];  // [set][0..7 = B n-tiles, 8..15 = A m-tiles]
+
+    auto read_frag = [&](int set, int g, const char* buf, int ks) {
+        const char* a = buf + (g < 8 ? b_half : a_half) + ks * (32 * 256) + frag_lane + ((((g & 7)) ^ fh) << 5);
+        const sf_v4s lo = sf_ds_read_tr16(a);
+        const sf_v4s up = sf_ds_read_tr16(a + 4 * 256);
+        f[set][g] = sf_v8s{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+    };
+
+    // ---- prologue
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dma(g, 0);
+    if (nkt > 1) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dma(g, 1);
+    }
+    tn_wait_all();
+    tn_barrier();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) read_frag(0, g, smem, 0);
+
+    auto tile = [&](auto READ_NEXT, auto DO_DMA, int t) {
+        const char* cur = smem + (t & 1) * kBufBytes;
+        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
+        // ---- half-step 2t: compute set 0; fragments of k-half 1 -> set 1 (front-loaded)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
+                sf_mfma16_acc(f[0][nt], f[0][8 + mt], acc[mt][nt]);
+            }
+            tn_fence();
+            if (g < 8) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
+            tn_fence();
+        }
+        tn_wait_all();   // my pieces of tile t+1 have landed; my reads of buffer t&1 have returned
+        tn_barrier();    // -> tile t+1 visible to everyone, buffer t&1 free for tile t+2
+        // ---- half-step 2t+1: compute set 1; fragments of (t+1, k-half 0) -> set 0; stage tile t+2
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
+                sf_mfma16_acc(f[1][nt], f[1][8 + mt], acc[mt][nt]);
+            }
+            tn_fence();
+            if constexpr (decltype(READ_NEXT)::value) {
+                if (g < 4) { read_frag(0, 2 * g, nxt, 0); read_frag(0, 2 * g + 1, nxt, 0); }
+                else if (g < 12) read_frag(0, g + 4, nxt, 0);
+            }
+            if constexpr (decltype(DO_DMA)::value) dma(g, t + 2);
+            tn_fence();
+        }
+    };
+
+    int t = 0;
+    for (; t + 2 < nkt; ++t) tile(std::true_type{}, std::true_type{}, t);
+    if (t + 1 < nkt) { tile(std::true_type{}, std::false_type{}, t); ++t; }
+    tile(std::false_type{}, std::false_type{}, t);
+
+    // ---- epilogue: lane owns C[m][n..n+3]
+    sf_mfma_drain();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            sf_gemm_store4<OUT_F32, 0>(p.e, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), v);
+        }
+}
+
+}  // namespace
+
+#ifdef SF_EMU
+#define SF_TN_SMEM(kernel)
+#else
+#define SF_TN_SMEM(kernel)                                                                                       \
+    do {                                                                                                         \
+        static bool done_ = false;                                                                               \
+        if (!done_) {                                                                                            \
+            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes); \
+            (void)hipGetLastError();                                                                             \
+            done_ = true;                                                                                        \
+        }                                                                                                        \
+    } while (0)
+#endif
+
+extern "C" int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
+                          int K, float alpha, float beta, void* stream) {
+    SF_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sf_gemm_tn: negative shape");
+    SF_CHECK_ARG(K % 64 == 0, "sf_gemm_tn: K must be a multiple of 64 (pad the contraction with zero rows)");
+    SF_CHECK_ARG(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sf_gemm_tn: M, N, lda, ldb must be multiples of 8");
+    SF_CHECK_ARG((M == 0 || M >= 8) && (N == 0 || N >= 8), "sf_gemm_tn: M, N >= 8");
+    SF_CHECK_ARG(ldc % 4 == 0, "sf_gemm_tn: ldc must be a multiple of 4");
+    SF_CHECK_ARG(c_dtype == SF_BF16 || c_dtype == SF_F32, "sf_gemm_tn: c_dtype");
+    if (M == 0 || N == 0) return 0;
+    if (K == 0) {
+        SF_CHECK_ARG(false, "sf_gemm_tn: K == 0 is not supported");
+    }
+    GemmTnArgs p;
+    p.A = (const sf_bf16*)A; p.lda = lda;
+    p.B = (const sf_bf16*)B; p.ldb = ldb;
+    p.e.C = C; p.e.ldc = ldc; p.e.R = nullptr; p.e.ldr = 0;
+    p.e.Cadd = nullptr; p.e.ldadd = 0; p.e.add_S = 1; p.e.add_Spad = 1; p.e.add_off = 0;
+    p.e.M = M; p.e.N = N; p.e.alpha = alpha; p.e.beta = beta;
+    p.M = M; p.N = N; p.K = K;
+    p.tiles_m = (M + TM - 1) / TM;
+    p.tiles_n = (N + TN - 1) / TN;
+    { const char* en = getenv("SF_GEMM_GM"); p.gm = en ? atoi(en) : 4; if (p.gm < 1) p.gm = 1; }
+    const long nblk = (long)p.tiles_m * p.tiles_n;
+    SF_CHECK_ARG(nblk < (1L << 31), "sf_gemm_tn: grid too large");
+    if (c_dtype == SF_F32) {
+        SF_TN_SMEM((gemm_tn_256w4_kernel<1>));
+        SF_LAUNCH((gemm_tn_256w4_kernel<1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+    } else {
+        SF_TN_SMEM((gemm_tn_256w4_kernel<0>));
+        SF_LAUNCH((gemm_tn_256w4_kernel<0>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+    }
+    return sf_check_launch("sf_gemm_tn");
+}

@@ -40,7 +40,10 @@ template <typename T> SF_DEVICE T sf_shfl_xor(T v, int m) { return sfemu::shfl_x
 template <typename T> SF_DEVICE T sf_shfl(T v, int l) { return sfemu::shfl(v, l); }
 SF_DEVICE sf_v4f sf_mfma16(sf_v8s a, sf_v8s b, sf_v4f c) { return sfemu::mfma_16x16x32_bf16(a, b, c); }
 SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) { return sfemu::mfma_32x32x16_bf16(a, b, c); }
+SF_DEVICE void sf_mfma16_acc(sf_v8s a, sf_v8s b, sf_v4f& c) { c = sfemu::mfma_16x16x32_bf16(a, b, c); }
+SF_DEVICE void sf_mfma_drain() {}
 SF_DEVICE void sf_glds16(const void* g, void* l) { sfemu::global_load_lds16(g, l); }
+SF_DEVICE void sf_glds16_opaque(const void* g, void* l) { sfemu::global_load_lds16(g, l); }
 struct SfBuf { const char* base; unsigned bytes; };
 SF_DEVICE SfBuf sf_make_buf(const void* base, unsigned bytes) { return SfBuf{(const char*)base, bytes}; }
 SF_DEVICE void sf_buf_glds16(SfBuf b, unsigned voff, unsigned soff, void* l) {
@@ -88,6 +91,14 @@ template <typename T> SF_DEVICE T sf_shfl(T v, int l) { return __shfl(v, l, 64);
 SF_DEVICE sf_v4f sf_mfma16(sf_v8s a, sf_v8s b, sf_v4f c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// In-place accumulate with the accumulator pinned to AGPRs (tied asm operand).  With 256 accumulator registers per
+// lane the compiler's own allocation of the builtin form is fragile: under pressure it renames MFMA destinations and
+// parks accumulator tiles in VGPRs (v_accvgpr_write + s_nop in front of every MFMA).  The asm form cannot be renamed.
+// The hazard recogniser does not see an MFMA inside asm: call sf_mfma_drain() before the accumulators are read.
+SF_DEVICE void sf_mfma16_acc(sf_v8s a, sf_v8s b, sf_v4f& c) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+SF_DEVICE void sf_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
 SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -120,6 +131,14 @@ SF_DEVICE SfBuf sf_make_buf(const void* base, unsigned bytes) {
 }
 SF_DEVICE void sf_buf_glds16(SfBuf b, unsigned voff, unsigned soff, void* l) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b.r, (__attribute__((address_space(3))) void*)l, 16, (int)voff, (int)soff, 0, 0);
+}
+// The same LDS-DMA as inline asm.  The compiler orders every LDS read it cannot disambiguate (ds_read_b64_tr_b16 has no
+// memory operand) behind outstanding LDS-DMA *builtins* with an automatic `s_waitcnt vmcnt(0)`, which serialises a
+// software-pipelined loop.  Hidden in asm, the DMA is invisible to that logic: the kernel's own counted vmcnt +
+// barrier are then the only ordering, exactly as the hardware requires.  `l` must be wave-uniform.
+SF_DEVICE void sf_glds16_opaque(const void* g, void* l) {
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds) : "memory", "m0");
 }
 SF_DEVICE void sf_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 SF_DEVICE void sf_setprio_hi() { __builtin_amdgcn_s_setprio(1); }

@@ -96,10 +96,23 @@ class Eagle3Engine:
         b["kvlen"] = torch.zeros(B, dtype=i32, device=self.dev)
         b["pos"] = torch.zeros(N, dtype=i64, device=self.dev)
         # per-step stash
-        b["h"] = [self._e(N, H) for _ in range(T + 1)]
+        # Natural-layout stashes [T*N (+ zero pad rows to a multiple of 64), features]: row block k is TTT step k.  They are
+        # the operands of the deferred weight-gradient GEMMs (sf_gemm_tn contracts over the token rows of dY and X as
+        # stored, K = T*N), and the per-step kernels write straight into their slot -- no copies, no transposes.
+        TNk = T * N
+        Kp = (TNk + 63) // 64 * 64
+        b["Kp"] = Kp
+        zs = lambda rows, feat: torch.zeros(rows, feat, dtype=torch.bfloat16, device=self.dev)
+        slots = lambda t: [t[k * N:(k + 1) * N] for k in range(T)]
+        h_all = zs(N + Kp, H)                           # h[0] | h[1..T] (the lm_head input when norm_output=False)
+        b["h_s"] = h_all[N:]
+        b["h"] = [h_all[k * N:(k + 1) * N] for k in range(T + 1)]
         b["h1"] = [self._e(N, H) for _ in range(T)]
         b["qkv"] = [self._e(N, self.QW) for _ in range(T)]
-        b["o"] = [self._e(N, nh * hd) for _ in range(T)]
+        for nm, feat in (("hn", H), ("o", nh * hd), ("pn", H), ("act", I), ("ln", H), ("logits", Vd), ("dh", H),
+                         ("dgu", 2 * I), ("dh1", H), ("dqkv", self.QW)):
+            b[nm + "_s"] = zs(Kp, feat)
+            b[nm] = slots(b[nm + "_s"])
         b["lse"] = [self._e(B, nh, S, dtype=f32) for _ in range(T)]
         b["gu"] = [self._e(N, 2 * I) for _ in range(T)]
         b["dln"] = [self._e(N, H) for _ in range(T)]
@@ -111,42 +124,31 @@ class Eagle3Engine:
         b["Np_real"] = B * Spad
         Np = (B * Spad + 31) // 32 * 32       # 2*Np is the K of a wgrad GEMM (64-aligned K -> 256-tile kernels); extra rows stay zero
         b["Np"] = Np
-        b["en"] = torch.zeros(Np, H, dtype=torch.bfloat16, device=self.dev)
+        b["en2"] = torch.zeros(2 * Np, H, dtype=torch.bfloat16, device=self.dev)   # [en ; en]: pairs with [hi ; lo]
+        b["en"] = b["en2"][:Np]
         b["rstd_e1"] = self._e(Np, dtype=f32)
         b["epart"] = self._e(Np, self.QW, dtype=f32)
         b["rstd_fc"] = [self._e(N, dtype=f32) for _ in range(3)]
         # transient per-step work buffers
-        b["hn"] = self._e(N, H)
-        b["pn"] = self._e(N, H)
-        b["act"] = self._e(N, I)
-        b["ln"] = self._e(N, H)
-        b["logits"] = self._e(N, Vd)
-        b["hsn"] = self._e(N, Ht3) if c.fc_norm else None
+        N64 = (N + 63) // 64 * 64
+        b["hs_s"] = zs(N64, Ht3)              # fc input (fc_norm output, or a copy of the hidden states when N % 64 != 0)
+        b["hsn"] = b["hs_s"][:N]
+        b["dh0_s"] = zs(N64, H)
         b["rows"] = self._e(3, N, dtype=f32)
         b["metrics"] = torch.zeros(T, 3, dtype=f32, device=self.dev)
         b["msum"] = torch.zeros(T, dtype=f32, device=self.dev)        # LK: sum of the position mask per TTT step
         b["lk_logsum"] = torch.zeros(T, dtype=f32, device=self.dev)   # LK: sum_r m_r log(accept_r) per TTT step
-        # transposed stashes for the deferred, K-concatenated wgrad GEMMs: [features, T*N]
-        TN = T * N
-        for nm, feat in (("hnT", H), ("oT", nh * hd), ("pnT", H), ("actT", I), ("lnT", H), ("dlogT", Vd),
-                         ("dhT", H), ("dguT", 2 * I), ("dh1T", H), ("dqkvT", self.QW)):
-            b[nm] = self._e(feat, TN)
-        b["hsT"] = self._e(Ht3, N)
-        b["dh0T"] = self._e(H, N)
         # backward work buffers
-        b["dh_a"], b["dh_b"], b["dh1"] = self._e(N, H), self._e(N, H), self._e(N, H)
+        b["dh_b"] = [self._e(N, H), self._e(N, H)]   # residual-stream gradient handed from step k to k-1 (ping-pong)
         b["dact"] = self._e(N, I)
-        b["dgu"] = self._e(N, 2 * I)
         b["dpn"] = self._e(N, H)
         b["do"] = self._e(N, nh * hd)
-        b["dqkv"] = self._e(N, self.QW)
         b["dxh"] = self._e(N, H)
         # backward of the hoisted embedding half: fp32 sum over the steps of dqkv re-aligned to token positions, its
         # two-term bf16 expansion (transposed, K-concatenated) for the wgrad, and the matching operand [en^T | en^T]
         b["dsum"] = self._e(Np, self.QW, dtype=f32)
-        b["ds_hi"], b["ds_lo"] = self._e(Np, self.QW), self._e(Np, self.QW)
-        b["dsT"] = self._e(self.QW, 2 * Np)
-        b["enT2"] = self._e(H, 2 * Np)
+        b["ds2"] = zs(2 * Np, self.QW)                     # [hi ; lo] stacked along the contraction
+        b["ds_hi"], b["ds_lo"] = b["ds2"][:Np], b["ds2"][Np:]
         b["dE"] = self._e(Np, H)
         b["dhs"] = self._e(N, Ht3) if c.fc_norm else None
         b["delta"] = self._e(B, nh, S, dtype=f32)
@@ -248,11 +250,13 @@ class Eagle3Engine:
                 ops.rmsnorm_fwd(hs[:, i * Ht:(i + 1) * Ht], f.view(f"fc_norm.{i}.weight"), eps,
                                 b["hsn"][:, i * Ht:(i + 1) * Ht], b["rstd_fc"][i])
             fc_in = b["hsn"]
+            self._fc_x = b["hs_s"]
+        elif N % 64 == 0:
+            fc_in = self._fc_x = hs                    # already a valid sf_gemm_tn operand (K = N)
         else:
-            fc_in = hs
+            b["hsn"].copy_(hs)                          # odd test shapes only: zero-padded copy for the weight gradient
+            fc_in, self._fc_x = b["hsn"], b["hs_s"]
         ops.gemm_nt(fc_in, f.view("fc.weight"), b["h"][0])
-        if train:
-            ops.transpose2d(fc_in, b["hsT"])
 
         kcol, vcol = slice(nh * hd, (nh + nkv) * hd), slice((nh + nkv) * hd, self.QW)
         lk = self.lk_loss_type
@@ -266,11 +270,9 @@ class Eagle3Engine:
                         b["rstd_e1"], ids_pad=b["ids"], S=Spad, Spad=Spad, off=0, rows=b["Np_real"])
         ops.gemm_nt(b["en"], self.w_qkv[:, :H], b["epart"])
         if train:
-            ops.transpose2d(b["en"], b["enT2"][:, :Np])
-            ops.transpose2d(b["en"], b["enT2"][:, Np:])
+            b["en2"][Np:].copy_(b["en"])
         for k in range(T):
-            cols = slice(k * N, (k + 1) * N)
-            hn, qkv = b["hn"], b["qkv"][k]
+            hn, qkv, pn, act, logits = b["hn"][k], b["qkv"][k], b["pn"][k], b["act"][k], b["logits"][k]
             # q/k/v of cat(input_layernorm(embed(ids<<k)), hidden_norm(h_k))   (llama3_eagle.py:1625-1630)
             ops.rmsnorm_fwd(b["h"][k], f.view("midlayer.hidden_norm.weight"), eps, hn, b["rstd_h"][k])
             ops.gemm_nt_rowadd(hn, self.w_qkv[:, H:], qkv, b["epart"], S=S, Spad=Spad, off=k)
@@ -279,18 +281,18 @@ class Eagle3Engine:
                          [b["qkv"][i][:, vcol] for i in range(1, k + 1)], b["kvlen"], b["o"][k], b["lse"][k],
                          B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
             ops.gemm_nt(b["o"][k], f.view("midlayer.self_attn.o_proj.weight"), b["h1"][k], residual=b["h"][k])
-            ops.rmsnorm_fwd(b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"), eps, b["pn"], b["rstd_p"][k])
-            ops.gemm_nt(b["pn"], self.w_gu, b["gu"][k])
-            ops.swiglu_fwd(b["gu"][k], b["act"])
-            ops.gemm_nt(b["act"], f.view("midlayer.mlp.down_proj.weight"), b["h"][k + 1], residual=b["h1"][k])
+            ops.rmsnorm_fwd(b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"), eps, pn, b["rstd_p"][k])
+            ops.gemm_nt(pn, self.w_gu, b["gu"][k])
+            ops.swiglu_fwd(b["gu"][k], act)
+            ops.gemm_nt(act, f.view("midlayer.mlp.down_proj.weight"), b["h"][k + 1], residual=b["h1"][k])
             if c.norm_output:   # compute_logits (llama3_eagle.py:1772-1777)
-                ln = b["ln"]
+                ln = b["ln"][k]
                 ops.rmsnorm_fwd(b["h"][k + 1], f.view("norm.weight"), eps, ln, b["rstd_n"][k])
             else:
                 ln = b["h"][k + 1]
-            ops.gemm_nt(ln, f.view("lm_head.weight"), b["logits"])
+            ops.gemm_nt(ln, f.view("lm_head.weight"), logits)
             # loss + d(logits) in place + accuracy + acceptance; ploss_k = mean over ALL B*S rows
-            ops.ce_fused(b["logits"], b["tp"], S=S, Spad=Spad, off=k, pos_mask_pad=b["pm"], loss_mask_pad=b["lm"],
+            ops.ce_fused(logits, b["tp"], S=S, Spad=Spad, off=k, pos_mask_pad=b["pm"], loss_mask_pad=b["lm"],
                          tgt_ids_pad=b["tids"], pod_scale_pad=b["pod"], tsum_pad=b["tsum"], d2t=self._d2t,
                          grad_scale=(self.decay ** k) / N, write_grad=train and lk is None, row_loss=b["rows"][0],
                          row_correct=b["rows"][1], row_accept=b["rows"][2])
@@ -301,18 +303,12 @@ class Eagle3Engine:
                 ra = b["rows"][2]
                 b["lk_logsum"][k] = torch.where(ra > 0, torch.log(ra), torch.zeros_like(ra)).sum()
                 if train:
-                    ops.ce_lk_grad(b["logits"], b["tp"], S=S, Spad=Spad, off=k, pos_mask_pad=b["pm"],
+                    ops.ce_lk_grad(logits, b["tp"], S=S, Spad=Spad, off=k, pos_mask_pad=b["pm"],
                                    pod_scale_pad=b["pod"], tsum_pad=b["tsum"], lk_loss_type=lk, kl_scale=self.kl_scale,
                                    kl_decay=self.kl_decay, step_scale=self.decay ** k, kl_row_scale=1.0 / N,
                                    accept_sum=b["metrics"][k][2:3], mask_sum=b["msum"][k:k + 1])
             if train:
-                ops.gemm_nt(b["logits"], self.wlmT, b["dln"][k])        # lm_head dgrad, taken now
-                ops.transpose2d(b["logits"], b["dlogT"][:, cols])
-                ops.transpose2d(ln, b["lnT"][:, cols])
-                ops.transpose2d(hn, b["hnT"][:, cols])
-                ops.transpose2d(b["o"][k], b["oT"][:, cols])
-                ops.transpose2d(b["pn"], b["pnT"][:, cols])
-                ops.transpose2d(b["act"], b["actT"][:, cols])
+                ops.gemm_nt(logits, self.wlmT, b["dln"][k])        # lm_head dgrad, taken now
 
         self._fwd_state = (B, S) if train else None
         # ---- metrics (tiny integer-mask sums; eagle3/model.py:161-190, core/lk_loss.py:43-80)
@@ -371,30 +367,27 @@ class Eagle3Engine:
 
         dh_next = None
         for k in range(T - 1, -1, -1):
-            cols = slice(k * N, (k + 1) * N)
-            # final norm + (already taken) lm_head dgrad; residual-stream gradient of step k+1 joins here
-            dh = b["dh_a"]
+            # final norm + (already taken) lm_head dgrad; residual-stream gradient of step k+1 joins here.
+            # dh / dgu / dh1 / dqkv are written straight into their slot of the weight-gradient stash.
+            dh, dgu, dh1, dqkv = b["dh"][k], b["dgu"][k], b["dh1"][k], b["dqkv"][k]
             if c.norm_output:
                 acc, a = nacc("norm.weight")
                 ops.rmsnorm_bwd(b["dln"][k], b["h"][k + 1], f.view("norm.weight"), b["rstd_n"][k], dx=dh, add=dh_next,
                                 dw_acc=acc, dw_accumulate=a, workspace=ws)
             elif dh_next is None:   # lm_head reads the un-normed hidden state; `norm` gets no gradient
-                dh = b["dln"][k]
+                dh.copy_(b["dln"][k])
             else:
                 ops.add_bf16(b["dln"][k], dh_next, dh)
-            ops.transpose2d(dh, b["dhT"][:, cols])
             # MLP
             ops.gemm_nt(dh, self.wdT, b["dact"])
-            ops.swiglu_bwd(b["dact"], b["gu"][k], b["dgu"])
-            ops.transpose2d(b["dgu"], b["dguT"][:, cols])
-            ops.gemm_nt(b["dgu"], self.wguT, b["dpn"])
+            ops.swiglu_bwd(b["dact"], b["gu"][k], dgu)
+            ops.gemm_nt(dgu, self.wguT, b["dpn"])
             acc, a = nacc("midlayer.post_attention_layernorm.weight")
             ops.rmsnorm_bwd(b["dpn"], b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"), b["rstd_p"][k],
-                            dx=b["dh1"], add=dh, dw_acc=acc, dw_accumulate=a, workspace=ws)
-            ops.transpose2d(b["dh1"], b["dh1T"][:, cols])
+                            dx=dh1, add=dh, dw_acc=acc, dw_accumulate=a, workspace=ws)
             # attention
-            ops.gemm_nt(b["dh1"], self.woT, b["do"])
-            qkv, dqkv = b["qkv"][k], b["dqkv"]
+            ops.gemm_nt(dh1, self.woT, b["do"])
+            qkv = b["qkv"][k]
             q = qkv[:, :nh * hd]
             kd = [b["qkv"][i][:, kcol] for i in range(1, k + 1)]
             vd = [b["qkv"][i][:, vcol] for i in range(1, k + 1)]
@@ -409,23 +402,23 @@ class Eagle3Engine:
             ops.cast_from_f32(b["dk"][k], dqkv[:, kcol])
             ops.cast_from_f32(b["dv"][k], dqkv[:, vcol])
             ops.rope_(dqkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k, backward=True)
-            ops.transpose2d(dqkv, b["dqkvT"][:, cols])
             ops.gemm_nt(dqkv, self.wqkvT[H:], b["dxh"])                 # hidden half of the QKV dgrad
             ops.shift_accum(dqkv, b["dsum"], B=B, S=S, Spad=Spad, off=k)   # embedding half: summed over the steps first
-            dh_prev = b["dh_b"]
+            dh_prev = b["dh_b"][0]
             acc, a = nacc("midlayer.hidden_norm.weight")
             ops.rmsnorm_bwd(b["dxh"], b["h"][k], f.view("midlayer.hidden_norm.weight"), b["rstd_h"][k],
-                            dx=dh_prev, add=b["dh1"], dw_acc=acc, dw_accumulate=a, workspace=ws)
-            dh_next = dh_prev  # dh_b was consumed (as `add`) before it is rewritten in the next iteration
+                            dx=dh_prev, add=dh1, dw_acc=acc, dw_accumulate=a, workspace=ws)
+            dh_next = dh_prev  # consumed (as `add`) by step k-1 before it is rewritten at the end of that step
         dh0 = dh_next
-        ops.transpose2d(dh0, b["dh0T"])
+        if N % 64 == 0:
+            fc_dy = dh0
+        else:                       # odd test shapes only: zero-padded copy (K of the fc weight gradient)
+            b["dh0_s"][:N].copy_(dh0)
+            fc_dy = b["dh0_s"]
         # embedding half of the QKV backward, once for all steps.  The summed gradient enters the bf16 GEMMs as a
         # two-term expansion hi + lo for the weight gradient; input_layernorm.weight only needs the leading term (the
         # reference rounds every step's d(input) to bf16 before the norm backward, which is coarser than that).
-        Np = b["Np"]
         ops.split_bf16(b["dsum"], b["ds_hi"], b["ds_lo"])
-        ops.transpose2d(b["ds_hi"], b["dsT"][:, :Np])
-        ops.transpose2d(b["ds_lo"], b["dsT"][:, Np:])
         ops.gemm_nt(b["ds_hi"], self.wqkvT[:H], b["dE"])
         acc, a = nacc("midlayer.input_layernorm.weight")
         ops.rmsnorm_bwd(b["dE"][:b["Np_real"]], self.model.embed_tokens.weight.data, f.view("midlayer.input_layernorm.weight"),
@@ -439,24 +432,24 @@ class Eagle3Engine:
                 ops.rmsnorm_bwd(b["dhs"][:, i * Ht:(i + 1) * Ht], hs[:, i * Ht:(i + 1) * Ht], f.view(f"fc_norm.{i}.weight"),
                                 b["rstd_fc"][i], dx=None, dw_acc=acc, dw_accumulate=a, workspace=ws)
 
-        # ---- deferred weight gradients: one K = T*N GEMM per weight, bf16 straight into flat.grad
+        # ---- deferred weight gradients: dW = dY^T . X over all T*N token rows of the natural-layout stashes
+        # (sf_gemm_tn), bf16 straight into flat.grad in all-reduce bucket order
         beta = 0.0 if self.micro_in_window == 0 else 1.0
+        ln_s = b["ln_s"] if c.norm_output else b["h_s"]
         jobs = [
-            ("lm_head.weight", "lm_head.weight", b["dlogT"], b["lnT"], f.gview("lm_head.weight")),
-            ("midlayer.mlp.gate_proj.weight", "midlayer.mlp.up_proj.weight", b["dguT"], b["pnT"], self.g_gu),
-            ("midlayer.mlp.down_proj.weight", "midlayer.mlp.down_proj.weight", b["dhT"], b["actT"],
-             f.gview("midlayer.mlp.down_proj.weight")),
-            ("midlayer.self_attn.q_proj.weight", "midlayer.self_attn.v_proj.weight", b["dqkvT"], b["hnT"], self.g_qkv),
-            ("midlayer.self_attn.o_proj.weight", "midlayer.self_attn.o_proj.weight", b["dh1T"], b["oT"],
-             f.gview("midlayer.self_attn.o_proj.weight")),
-            ("fc.weight", "fc.weight", b["dh0T"], b["hsT"], f.gview("fc.weight")),
+            ("lm_head.weight", "lm_head.weight", [(b["logits_s"], ln_s, f.gview("lm_head.weight"))]),
+            ("midlayer.mlp.gate_proj.weight", "midlayer.mlp.up_proj.weight", [(b["dgu_s"], b["pn_s"], self.g_gu)]),
+            ("midlayer.mlp.down_proj.weight", "midlayer.mlp.down_proj.weight",
+             [(b["dh_s"], b["act_s"], f.gview("midlayer.mlp.down_proj.weight"))]),
+            ("midlayer.self_attn.q_proj.weight", "midlayer.self_attn.v_proj.weight",   # [QW, 2H] = [embedding | hidden] half
+             [(b["ds2"], b["en2"], self.g_qkv[:, :H]), (b["dqkv_s"], b["hn_s"], self.g_qkv[:, H:])]),
+            ("midlayer.self_attn.o_proj.weight", "midlayer.self_attn.o_proj.weight",
+             [(b["dh1_s"], b["o_s"], f.gview("midlayer.self_attn.o_proj.weight"))]),
+            ("fc.weight", "fc.weight", [(fc_dy, self._fc_x, f.gview("fc.weight"))]),
         ]
-        for first_name, last_name, dyT, xT, gout in jobs:
-            if gout is self.g_qkv:   # [QW, 2H] = [ embedding half | hidden half ]
-                ops.gemm_nt(b["dsT"], b["enT2"], gout[:, :H], alpha=g, beta=beta)
-                ops.gemm_nt(dyT, xT, gout[:, H:], alpha=g, beta=beta)
-            else:
-                ops.gemm_nt(dyT, xT, gout, alpha=g, beta=beta)
+        for first_name, last_name, gemms in jobs:
+            for dy, x, gout in gemms:
+                ops.gemm_tn(dy, x, gout, alpha=g, beta=beta)
             if self.on_bucket_ready is not None:
                 self.on_bucket_ready(f.slices[first_name][0], f.slices[last_name][1])
         # norm weights: fp32 running total over the window, then one cast into the flat gradient

@@ -60,6 +60,17 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, alpha: float
     return out
 
 
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0):
+    """out[M,N] = alpha * a[K,M]^T @ b[K,N] (+ beta*out); a, b bf16 (row-major, K outermost); out bf16|fp32."""
+    L = _lib.lib()
+    K, M = a.shape
+    K2, N = b.shape
+    assert K == K2 and out.shape == (M, N) and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    _lib.check(L.sf_gemm_tn(_p(a), _rowmajor(a), _p(b), _rowmajor(b), _p(out), _dt(out), _rowmajor(out), M, N, K, alpha,
+                            beta, _stream()), "sf_gemm_tn")
+    return out
+
+
 def gemm_nt_rowadd(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, addend: torch.Tensor, *, S: int, Spad: int, off: int,
                    alpha: float = 1.0):
     """out[r] = round(alpha * a[r] @ b^T + addend[(r // S) * Spad + r % S + off]); addend fp32 [B*Spad, N]."""

@@ -59,6 +59,24 @@ def test_gemm_nt_rowadd(backend, M, N, K, S, T, out_dtype):
         torch.testing.assert_close(out.float().cpu(), ref, rtol=tol, atol=tol * math.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 48, 64), (200, 136, 128), (256, 256, 64), (520, 264, 192), (136, 1000, 320)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_tn(backend, M, N, K, out_dtype):
+    """weight-gradient form: both operands stored with the contraction index outermost"""
+    a = _rand((K, M), torch.bfloat16, 1)
+    b = _rand((K, N), torch.bfloat16, 2)
+    ref = a.float().t() @ b.float()
+    out = torch.full((M, N), 7.0, dtype=out_dtype, device=backend)
+    ops.gemm_tn(_dev(backend, a), _dev(backend, b), out)
+    tol = 1e-3 if out_dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=tol, atol=tol * math.sqrt(K))
+    # accumulate into a strided view (the fused q|k|v gradient block) with alpha/beta
+    wide = torch.ones(M, N + 16, dtype=out_dtype, device=backend)
+    ops.gemm_tn(_dev(backend, a), _dev(backend, b), wide[:, 8:8 + N], alpha=0.5, beta=2.0)
+    torch.testing.assert_close(wide[:, 8:8 + N].float().cpu(), 0.5 * ref + 2.0, rtol=tol, atol=tol * math.sqrt(K))
+    assert float(wide[:, :8].float().min()) == 1.0 and float(wide[:, 8 + N:].float().max()) == 1.0
+
+
 def test_gemm_nt_epilogues(backend):
     M, N, K = 136, 72, 128
     a, b = _rand((M, K), torch.bfloat16, 3), _rand((N, K), torch.bfloat16, 4)
