@@ -234,6 +234,126 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
 
 
 // ---------------------------------------------------------------------------------------------------
+// Register-staged variant (experiment knob SF_GEMM_W4R=1): the same 4-wave pipeline, but operand tiles go
+// HBM -> VGPR (global_load_dwordx4, issued a full K-tile before they are needed) -> LDS (ds_write_b128 into the
+// buffer the barrier has just freed).  The VGPR stage is a third pipeline slot that costs no LDS, which doubles the
+// load lead (the LDS-DMA form can only start a tile once its LDS buffer is free), and a global_load + ds_write pair
+// may cost fewer issue cycles than one LDS-DMA instruction (~60 cycles each, 16 per wave and K-tile).
+// Accumulators are pinned to AGPRs (sf_mfma16_acc) so that the extra 64 staging registers cannot disturb them.
+template <int OUT_F32>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4r_kernel(GemmW4Args p) {
+    SF_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
+    const int wr = wave >> 1, wc = wave & 1;
+    int tm, tn;
+    w4_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int nkt = p.K / TK;
+
+    const int srow = lane >> 3;
+    const int slc = (lane & 7) ^ (srow & 7);
+    const sf_bf16* src[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int ra = m0 + (8 * wave + j) * 8 + srow, rb = n0 + (8 * wave + j) * 8 + srow;
+        ra = ra < p.M ? ra : p.M - 1;
+        rb = rb < p.N ? rb : p.N - 1;
+        src[j] = p.A + (long)ra * p.lda + slc * 8;
+        src[8 + j] = p.B + (long)rb * p.ldb + slc * 8;
+    }
+    sf_v8s stage[16];
+    auto gload = [&](int g) {   // piece g of the next un-fetched K-tile -> staging registers
+        stage[g] = *reinterpret_cast<const sf_v8s*>(src[g]);
+        src[g] += TK;
+    };
+    auto lwrite = [&](int g, int kt) {   // staging registers -> piece g of buffer kt&1 (the LDS-DMA image, lane-linear)
+        char* dst = smem + (kt & 1) * kBufBytes + (g >> 3) * kOpBytes + (8 * wave + (g & 7)) * 1024 + lane * 16;
+        *reinterpret_cast<sf_v8s*>(dst) = stage[g];
+    };
+
+    const int frow = lane & 15;
+    int swz[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) swz[ks] = ((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
+    const int a_off = (wr * 128 + frow) * 128;
+    const int b_off = kOpBytes + (wc * 128 + frow) * 128;
+
+    sf_v4f acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
+    sf_v8s f[2][16];
+    auto read_frag = [&](int set, int g, const char* buf, int ks) {
+        if (g < 8) f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + b_off + g * 2048 + swz[ks]);
+        else f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + a_off + (g - 8) * 2048 + swz[ks]);
+    };
+
+    // ---- prologue: tiles 0 and 1 in LDS, tile 2 in flight towards the staging registers
+#pragma unroll
+    for (int g = 0; g < 16; ++g) gload(g);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) lwrite(g, 0);
+    if (nkt > 1) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) gload(g);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) lwrite(g, 1);
+    }
+    if (nkt > 2) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) gload(g);
+    }
+    sf_syncthreads();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) read_frag(0, g, smem, 0);
+
+    // WRITE_NEXT: tile t+2 exists (it sits in the staging registers); LOAD_NEXT: tile t+3 exists
+    auto tile = [&](auto WRITE_NEXT, auto LOAD_NEXT, int t) {
+        const char* cur = smem + (t & 1) * kBufBytes;
+        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
+                sf_mfma16_acc(f[0][nt], f[0][8 + mt], acc[mt][nt]);
+            }
+            w4_fence();
+            if (g < 8) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
+            w4_fence();
+        }
+        w4_wait_lgkm();     // my fragment reads of buffer t&1 and my ds_writes of tile t+1 are complete ...
+        w4_barrier();       // ... everyone's are: tile t+1 visible, buffer t&1 free (in-flight global loads keep flying)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
+                sf_mfma16_acc(f[1][nt], f[1][8 + mt], acc[mt][nt]);
+            }
+            w4_fence();
+            if (g < 4) { read_frag(0, 2 * g, nxt, 0); read_frag(0, 2 * g + 1, nxt, 0); }
+            else if (g < 12) read_frag(0, g + 4, nxt, 0);
+            if constexpr (decltype(WRITE_NEXT)::value) lwrite(g, t + 2);
+            if constexpr (decltype(LOAD_NEXT)::value) gload(g);
+            w4_fence();
+        }
+    };
+    int t = 0;
+    for (; t + 3 < nkt; ++t) tile(std::true_type{}, std::true_type{}, t);
+    for (; t + 2 < nkt; ++t) tile(std::true_type{}, std::false_type{}, t);
+    for (; t < nkt; ++t) tile(std::false_type{}, std::false_type{}, t);
+
+    sf_mfma_drain();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            w4_store4<OUT_F32, 0>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 8-wave form of the same loop (2 x 4 waves, 128 x 64 per wave, two waves per SIMD): identical
 // single-barrier-per-K-tile software pipeline, but every SIMD has a second wave whose MFMAs cover the
 // ~60 cycles a wave is stuck issuing each LDS-DMA instruction (measured: in the 4-wave form the DMA issue
@@ -490,6 +610,17 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
             SF_LAUNCH((gemm_nt_256w4m32_kernel<0>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
         }
         return sf_check_launch("sf_gemm_nt(256w4m32)");
+    }
+    static const bool w4r = [] { const char* e = getenv("SF_GEMM_W4R"); return e ? atoi(e) == 1 : false; }();
+    if (w4r && !p.e.Cadd) {
+        if (c_dtype == SF_F32) {
+            SF_W4_SMEM((gemm_nt_256w4r_kernel<1>));
+            SF_LAUNCH((gemm_nt_256w4r_kernel<1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+        } else {
+            SF_W4_SMEM((gemm_nt_256w4r_kernel<0>));
+            SF_LAUNCH((gemm_nt_256w4r_kernel<0>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+        }
+        return sf_check_launch("sf_gemm_nt(256w4r)");
     }
     static const bool w8 = [] { const char* e = getenv("SF_GEMM_W8"); return e ? atoi(e) == 1 : false; }();
     if (w8) {
