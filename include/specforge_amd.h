@@ -48,9 +48,11 @@ int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_
 /* Weight-gradient form: C[M,N] = alpha * A^T . B (+ beta * C) with A [K, M] and B [K, N] row-major (bf16), i.e.
  * dW = dY^T . X on the tensors exactly as the sweep produced them -- replaces autograd's `grad_output.t() @ input`
  * of every linear layer on the path (llama3_eagle.py:555-566,1513-1515,1674-1693) without materialising a
- * transposed operand.  K % 64 == 0 (pad the token dimension with zero rows), M, N multiples of 8. */
+ * transposed operand.  K % 64 == 0 (pad the token dimension with zero rows), M, N multiples of 8.
+ * workspace (optional, fp32, >= 2*M*N floats): lets the launcher split K in two when the tile count would leave the
+ * last round of CUs half empty; the partials are reduced in a fixed order (deterministic). */
 int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N, int K,
-               float alpha, float beta, void* stream);
+               float alpha, float beta, float* workspace, long workspace_floats, void* stream);
 
 /* Same GEMM with an fp32 row-mapped addend joined to the accumulator before the single rounding:
  *   C[r][n] = round( alpha * (A.B^T)[r][n] + Cadd[(r / S) * Spad + r % S + off][n] )

@@ -38,6 +38,8 @@ struct GemmTnArgs {
     int M, N, K;
     int tiles_m, tiles_n;
     int gm;
+    int ksplit;       // > 1: blockIdx.y contracts K-range [y*K/ksplit, (y+1)*K/ksplit) into fp32 partial y of `ws`
+    float* ws;        // [ksplit][M][N] fp32 partials (split-K only)
 };
 
 #ifdef SF_EMU
@@ -70,7 +72,14 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4_kernel(GemmTnArgs p) {
     int tm, tn;
     tn_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
     const int m0 = tm * TM, n0 = tn * TN;
-    const int nkt = p.K / TK;
+    const int nkt = p.K / TK / p.ksplit;
+    const long k0 = (long)blockIdx.y * nkt * TK;      // first contraction row of this split
+    if (p.ksplit > 1) {                               // partial sums go to the fp32 workspace, plain store
+        p.e.C = p.ws + (long)blockIdx.y * p.M * p.N;
+        p.e.ldc = p.N;
+        p.e.alpha = 1.f;
+        p.e.beta = 0.f;
+    }
 
     // ---- DMA sources: half hh (0,1 = A columns m0+0.., m0+128..; 2,3 = B) is 16 pieces of 4 k-rows x 256 B; this wave
     // stages pieces 4*wave .. 4*wave+3 of every half.  Lane: k-row skr = lane>>4 of the piece, physical chunk lane&15.
@@ -87,7 +96,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4_kernel(GemmTnArgs p) {
             const int dim = isA ? p.M : p.N;
             int col = (isA ? m0 : n0) + (hh & 1) * 128 + lc * 8;
             col = col + 8 <= dim ? col : dim - 8;
-            src[hh * 4 + j] = (isA ? p.A + (long)krow * p.lda : p.B + (long)krow * p.ldb) + col;
+            src[hh * 4 + j] = (isA ? p.A + (k0 + krow) * p.lda : p.B + (k0 + krow) * p.ldb) + col;
         }
     const long incA = (long)TK * p.lda, incB = (long)TK * p.ldb;
     auto dma = [&](int g, int kt) {  // g = hh*4 + j: piece 4*wave+j of half hh of the next un-issued K-tile
@@ -179,6 +188,31 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4_kernel(GemmTnArgs p) {
         }
 }
 
+// C = alpha * sum_y ws[y] (+ beta * C): deterministic fixed-order reduction of the split-K partials
+template <int OUT_F32>
+SF_GLOBAL void tn_splitk_reduce_kernel(const float* ws, int ksplit, void* C, long ldc, int M, int N, float alpha, float beta) {
+    const long n4 = N / 4, total = (long)M * n4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / n4;
+        const int n = (int)(i - m * n4) * 4;
+        sf_v4f a = *reinterpret_cast<const sf_v4f*>(ws + m * N + n);
+        for (int y = 1; y < ksplit; ++y) {
+            const sf_v4f b = *reinterpret_cast<const sf_v4f*>(ws + (long)y * M * N + m * N + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] += b[r];
+        }
+        if (OUT_F32) {
+            float* c = (float*)C + m * ldc + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = alpha * a[r] + (beta != 0.f ? beta * c[r] : 0.f);
+        } else {
+            sf_bf16* c = (sf_bf16*)C + m * ldc + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = sf_f2bf(alpha * a[r] + (beta != 0.f ? beta * sf_bf2f(c[r]) : 0.f));
+        }
+    }
+}
+
 }  // namespace
 
 #ifdef SF_EMU
@@ -196,7 +230,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4_kernel(GemmTnArgs p) {
 #endif
 
 extern "C" int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
-                          int K, float alpha, float beta, void* stream) {
+                          int K, float alpha, float beta, float* workspace, long workspace_floats, void* stream) {
     SF_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sf_gemm_tn: negative shape");
     SF_CHECK_ARG(K % 64 == 0, "sf_gemm_tn: K must be a multiple of 64 (pad the contraction with zero rows)");
     SF_CHECK_ARG(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sf_gemm_tn: M, N, lda, ldb must be multiples of 8");
@@ -219,6 +253,28 @@ extern "C" int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void
     { const char* en = getenv("SF_GEMM_GM"); p.gm = en ? atoi(en) : 4; if (p.gm < 1) p.gm = 1; }
     const long nblk = (long)p.tiles_m * p.tiles_n;
     SF_CHECK_ARG(nblk < (1L << 31), "sf_gemm_tn: grid too large");
+    // Split-K by 2 when the tile count leaves the last round of the 256 CUs at most half full (e.g. 384 or 896 tiles:
+    // 1.5 / 3.5 rounds -> 3 / 7 full rounds of half-length blocks) and the caller provided room for the fp32 partials.
+    p.ksplit = 1;
+    p.ws = nullptr;
+    static const int split_mode = [] { const char* en = getenv("SF_GEMM_SPLITK"); return en ? atoi(en) : -1; }();
+    {
+        const long rem = nblk % 256;
+        const bool helps = rem > 0 && rem <= 128 && nblk < 2048 && ((2 * nblk) % 256 == 0 || (2 * nblk) % 256 > 192);
+        const bool fits = workspace && workspace_floats >= 2L * M * N && (K / TK) % 2 == 0 && K >= 4096 && N % 4 == 0;
+        if (fits && split_mode != 0 && (helps || split_mode == 2)) { p.ksplit = 2; p.ws = workspace; }
+    }
+    if (p.ksplit > 1) {
+        SF_TN_SMEM((gemm_tn_256w4_kernel<1>));
+        SF_LAUNCH((gemm_tn_256w4_kernel<1>), dim3((unsigned)nblk, (unsigned)p.ksplit), dim3(256), 2 * kBufBytes, stream, p);
+        const long units = (long)M * (N / 4);
+        const int grid = (int)((units + 255) / 256 < 2048 ? (units + 255) / 256 : 2048);
+        if (c_dtype == SF_F32)
+            SF_LAUNCH((tn_splitk_reduce_kernel<1>), dim3(grid), dim3(256), 0, stream, (const float*)p.ws, p.ksplit, C, ldc, M, N, alpha, beta);
+        else
+            SF_LAUNCH((tn_splitk_reduce_kernel<0>), dim3(grid), dim3(256), 0, stream, (const float*)p.ws, p.ksplit, C, ldc, M, N, alpha, beta);
+        return sf_check_launch("sf_gemm_tn(split-K)");
+    }
     if (c_dtype == SF_F32) {
         SF_TN_SMEM((gemm_tn_256w4_kernel<1>));
         SF_LAUNCH((gemm_tn_256w4_kernel<1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);

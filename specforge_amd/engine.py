@@ -157,6 +157,8 @@ class Eagle3Engine:
         b["dv"] = [self._e(N, nkv * hd, dtype=f32) for _ in range(T)]
         b["nws"] = self._e(ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)
         b["nws_e"] = self._e(ops.rmsnorm_bwd_workspace(Np, H), dtype=f32)
+        # fp32 partials for the 2-way split-K of weight-gradient GEMMs whose tile count fills the CUs badly (down, q|k|v)
+        b["tn_ws"] = self._e(2 * max(H * I, self.QW * H), dtype=f32)
         self._bufs[key] = b
         return b
 
@@ -449,7 +451,7 @@ class Eagle3Engine:
         ]
         for first_name, last_name, gemms in jobs:
             for dy, x, gout in gemms:
-                ops.gemm_tn(dy, x, gout, alpha=g, beta=beta)
+                ops.gemm_tn(dy, x, gout, alpha=g, beta=beta, workspace=b["tn_ws"])
             if self.on_bucket_ready is not None:
                 self.on_bucket_ready(f.slices[first_name][0], f.slices[last_name][1])
         # norm weights: fp32 running total over the window, then one cast into the flat gradient
