@@ -799,6 +799,14 @@ extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long l
     AttnBwdArgs p;
     fill_bwd_args(p, q, ldq, dout, lddo, k0, ldk, v0, ldv, kv_len, lse, delta, nullptr, nullptr, 0, dk,
                   dv, lddk, B, S, nh, nkv, scale);
+    static const int dkv_waves = [] { const char* e = getenv("SF_ATTN_DKV_WAVES"); return e ? atoi(e) : kAttnWaves; }();
+    if (dkv_waves == 4) {
+        constexpr int NW = 4;
+        dim3 grid((S + NW * 16 - 1) / (NW * 16), nkv, B);
+        SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, NW>), 2 * (128 * HD * 2 + 512));
+                       SF_LAUNCH((attn_bwd_dkv_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (128 * HD * 2 + 512), stream, p));
+        return sf_check_launch("sf_attn_bwd_dkv");
+    }
     constexpr int NW = kAttnWaves;
     dim3 grid((S + NW * 16 - 1) / (NW * 16), nkv, B);  // NW/2 key sub-blocks of 32 keys per workgroup
     SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, NW>), 2 * (128 * HD * 2 + 512));

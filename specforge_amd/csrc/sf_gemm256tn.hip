@@ -64,7 +64,7 @@ SF_DEVICE void tn_tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int G
     tn = in_g / gsize;
 }
 
-template <int OUT_F32>
+template <int OUT_F32, int SPREAD = 0>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4_kernel(GemmTnArgs p) {
     SF_DYN_SMEM(smem);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
@@ -149,7 +149,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4_kernel(GemmTnArgs p) {
                 sf_mfma16_acc(f[0][nt], f[0][8 + mt], acc[mt][nt]);
             }
             tn_fence();
-            if (g < 8) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
+            if (SPREAD) read_frag(1, g, cur, 1);
+            else if (g < 8) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
             tn_fence();
         }
         tn_wait_all();   // my pieces of tile t+1 have landed; my reads of buffer t&1 have returned
@@ -164,7 +165,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4_kernel(GemmTnArgs p) {
             }
             tn_fence();
             if constexpr (decltype(READ_NEXT)::value) {
-                if (g < 4) { read_frag(0, 2 * g, nxt, 0); read_frag(0, 2 * g + 1, nxt, 0); }
+                if (SPREAD) read_frag(0, g, nxt, 0);
+                else if (g < 4) { read_frag(0, 2 * g, nxt, 0); read_frag(0, 2 * g + 1, nxt, 0); }
                 else if (g < 12) read_frag(0, g + 4, nxt, 0);
             }
             if constexpr (decltype(DO_DMA)::value) dma(g, t + 2);
@@ -274,6 +276,12 @@ extern "C" int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void
         else
             SF_LAUNCH((tn_splitk_reduce_kernel<0>), dim3(grid), dim3(256), 0, stream, (const float*)p.ws, p.ksplit, C, ldc, M, N, alpha, beta);
         return sf_check_launch("sf_gemm_tn(split-K)");
+    }
+    static const bool spread = [] { const char* en = getenv("SF_GEMM_TN_SPREAD"); return en ? atoi(en) == 1 : false; }();
+    if (spread && c_dtype != SF_F32) {
+        SF_TN_SMEM((gemm_tn_256w4_kernel<0, 1>));
+        SF_LAUNCH((gemm_tn_256w4_kernel<0, 1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+        return sf_check_launch("sf_gemm_tn(spread)");
     }
     if (c_dtype == SF_F32) {
         SF_TN_SMEM((gemm_tn_256w4_kernel<1>));
