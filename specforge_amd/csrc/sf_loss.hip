@@ -270,15 +270,27 @@ teacher_reduce_kernel(const T* z, long ldz, int Vt, int Vd, const long long* d2t
     const T* x = z + (long)r * ldz;
     const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
     const int V8 = Vt >> 3;
-    float m = SF_NEG_BIG, d = 0.f, md = SF_NEG_BIG;  // md: max over the draft sub-vocabulary (t2d mask)
+    // (m, d): online max / sum-exp over the full vocabulary; (md, sdd): the same over the draft sub-vocabulary (t2d
+    // mask), so that the gathered pass below can write normalised probabilities in ONE pass
+    float m = SF_NEG_BIG, d = 0.f, md = SF_NEG_BIG, sdd = 0.f;
     ArgMax am{SF_NEG_BIG, 0x7fffffff};
     for (int c = tid; c < V8; c += nt) {
         float v[8];
         SfVec8<T>::ld(x + c * 8, v);
         const unsigned long long mk = *reinterpret_cast<const unsigned long long*>(t2d + c * 8);
+        if (mk) {
+            float cmd = SF_NEG_BIG;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if ((mk >> (8 * i)) & 0xffull) md = fmaxf(md, v[i]);
+            for (int i = 0; i < 8; ++i)
+                if ((mk >> (8 * i)) & 0xffull) cmd = fmaxf(cmd, v[i]);
+            const float mdn = fmaxf(md, cmd);
+            float accd = (md == SF_NEG_BIG) ? 0.f : sdd * sf_exp(md - mdn);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if ((mk >> (8 * i)) & 0xffull) accd += sf_exp(v[i] - mdn);
+            md = mdn;
+            sdd = accd;
+        }
         float cm = v[0];
 #pragma unroll
         for (int i = 1; i < 8; ++i) cm = fmaxf(cm, v[i]);
@@ -295,40 +307,43 @@ teacher_reduce_kernel(const T* z, long ldz, int Vt, int Vd, const long long* d2t
     for (int j = V8 * 8 + tid; j < Vt; j += nt) {
         float v = SfElem<T>::ld(x + j);
         if (v > am.v) { am.v = v; am.i = j; }
-        if (t2d[j]) md = fmaxf(md, v);
+        if (t2d[j]) md_merge(md, sdd, v, 1.f);
         md_merge(m, d, v, 1.f);
     }
     for (int k = 32; k >= 1; k >>= 1) {
         float m2 = sf_shfl_xor(m, k), d2 = sf_shfl_xor(d, k);
         md_merge(m, d, m2, d2);
+        float m3 = sf_shfl_xor(md, k), d3 = sf_shfl_xor(sdd, k);
+        md_merge(md, sdd, m3, d3);
     }
     am = am_wave(am);
     const int w = tid >> 6, nw = nt >> 6;
-    if (sf_lane() == 0) { red[w] = m; red[8 + w] = d; red[16 + w] = am.v; redi[w] = am.i; }
+    if (sf_lane() == 0) { red[w] = m; red[8 + w] = d; red[16 + w] = am.v; redi[w] = am.i; red[24 + w] = md; }
     sf_syncthreads();
     m = red[0]; d = red[8];
     am.v = red[16]; am.i = redi[0];
+    float mdb = red[24];
     for (int i = 1; i < nw; ++i) {
         md_merge(m, d, red[i], red[8 + i]);
         am = am_pick(am, ArgMax{red[16 + i], redi[i]});
+        mdb = fmaxf(mdb, red[24 + i]);
     }
     const float lse_full = m + sf_log(d);
     sf_syncthreads();
-    // draft sub-vocabulary: max (taken in the streaming pass above), exp-sum over ONE gathered pass,
-    // then normalise (torch.softmax order)
-    md = sf_block_max(md, red);
-    float* tp = target_p_pad + pr * (long)Vd;
+    // block-wide draft sum-exp relative to the block max (second small exchange through LDS)
+    sdd = (md == SF_NEG_BIG) ? 0.f : sdd * sf_exp(md - mdb);   // this wave's partial, rescaled (lane-uniform after the butterfly)
+    if (sf_lane() == 0) red[w] = sdd;
+    sf_syncthreads();
     float sd = 0.f;
-    for (int j = tid; j < Vd; j += nt) {
-        float e = sf_exp(SfElem<T>::ld(x + j + d2t[j]) - md);
-        tp[j] = e;
-        sd += e;
-    }
-    sd = sf_block_sum(sd, red);
+    for (int i = 0; i < nw; ++i) sd += red[i];
+    sf_syncthreads();
+    md = mdb;
     const float inv = 1.0f / sd;
+    // draft sub-vocabulary: one gathered pass writes the normalised probabilities (torch.softmax: exp(x - max) / sum)
+    float* tp = target_p_pad + pr * (long)Vd;
     float ts = 0.f;
     for (int j = tid; j < Vd; j += nt) {
-        float p = tp[j] * inv;
+        const float p = sf_exp(SfElem<T>::ld(x + j + d2t[j]) - md) * inv;
         tp[j] = p;
         ts += p;
     }
