@@ -12,12 +12,15 @@ Design notes (MI355X-first, 288 GB HBM):
 * No autograd graph: every activation the backward needs lives in a persistent stash that is
   allocated once per (B, S) shape; step k's K/V are views into step k's fused QKV buffer.
 * The soft-target CE writes d(logits) in place while computing the loss, so the lm_head
-  input gradient is taken in the forward sweep and only [N, H] survives per step.
-* Weight gradients are NOT computed per TTT step.  X^T and dY^T of every linear are stashed
-  for all T steps side by side ([*, T*N]); after the sweep ONE GEMM per weight contracts over
-  K = T*N tokens with fp32 accumulation and writes the bf16 gradient straight into the flat
-  gradient buffer, largest first -- each finished bucket is handed to the DP backend, whose
-  RCCL all-reduce overlaps the next wgrad GEMM.
+  input gradient is taken in the forward sweep.
+* Weight gradients are NOT computed per TTT step.  Every kernel writes its output into slot k of
+  a natural-layout stash [T*N, features]; after the sweep ONE sf_gemm_tn per weight contracts
+  dW = dY^T . X over K = T*N token rows with fp32 accumulation and writes the bf16 gradient
+  straight into the flat gradient buffer, largest first -- each finished bucket is handed to
+  the DP backend, whose RCCL all-reduce overlaps the next GEMM.  No operand is ever transposed.
+* The embedding half of the QKV projection (same token, shifted by the step index) is computed
+  once over the padded positions and joins each step's accumulator (sf_gemm_nt_rowadd); its
+  backward is contracted once from the fp32 sum of the re-aligned step gradients.
 * The upstream gradient g = dLoss/d(sum_k decay^k ploss_k) enters only as the alpha of those
   final GEMMs: everything before is linear in it.
 """
