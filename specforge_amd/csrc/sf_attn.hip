@@ -138,7 +138,12 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
     constexpr int KS = HD / 16, DB = HD / 32, QB = NW * 32, TILE = 128 * HD * 2;
     SF_DYN_SMEM(smem);  // 2 x { K [64][HD], V [64][HD] }
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
-    const int qb0 = (int)blockIdx.x * QB, h = (int)blockIdx.y, b = (int)blockIdx.z;
+    // 1-D grid, heaviest work first: the causal key range grows with the query block, so the LAST query blocks are
+    // dispatched first (longest-processing-time order keeps the tail of the launch short)
+    const int nqb = (p.S + QB - 1) / QB, per_qb = p.nh * p.B;
+    const int bid = (int)blockIdx.x;
+    const int qbi = nqb - 1 - bid / per_qb, hb = bid % per_qb;
+    const int qb0 = qbi * QB, h = hb % p.nh, b = hb / p.nh;
     const int g = h / (p.nh / p.nkv);
     const int S = p.S;
     const int kvlen = p.kv_len ? p.kv_len[b] : S;
@@ -428,7 +433,12 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     constexpr int KS = HD / 16, DB = HD / 32, QB = NW * 32, TILE = 128 * HD * 2;
     SF_DYN_SMEM(smem);  // 2 x { K [64][HD], V [64][HD] }; K serves both S^T = K.Q^T and (transpose-read) dQ^T += K^T.dS^T
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
-    const int qb0 = (int)blockIdx.x * QB, h = (int)blockIdx.y, b = (int)blockIdx.z;
+    // 1-D grid, heaviest work first: the causal key range grows with the query block, so the LAST query blocks are
+    // dispatched first (longest-processing-time order keeps the tail of the launch short)
+    const int nqb = (p.S + QB - 1) / QB, per_qb = p.nh * p.B;
+    const int bid = (int)blockIdx.x;
+    const int qbi = nqb - 1 - bid / per_qb, hb = bid % per_qb;
+    const int qb0 = qbi * QB, h = hb % p.nh, b = hb / p.nh;
     const int g = h / (p.nh / p.nkv);
     const int S = p.S;
     const int kvlen = p.kv_len ? p.kv_len[b] : S;
@@ -540,7 +550,11 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dkv_kernel(AttnBwdArgs p) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
     const int role = wave / NSUB;  // 0: dV, 1: dK   (wave-uniform)
     const int sub = wave - role * NSUB;
-    const int kb0 = (int)blockIdx.x * KB, g = (int)blockIdx.y, b = (int)blockIdx.z;
+    // 1-D grid, heaviest first: key block 0 sees every query tile, the last one only the final tiles
+    const int per_kb = p.nkv * p.B;
+    const int bid = (int)blockIdx.x;
+    const int kbi = bid / per_kb, gb = bid % per_kb;
+    const int kb0 = kbi * KB, g = gb % p.nkv, b = gb / p.nkv;
     const int S = p.S, nrep = p.nh / p.nkv;
     const int kvlen = p.kv_len ? p.kv_len[b] : S;
     const int kw0 = kb0 + sub * 32;
@@ -706,13 +720,13 @@ extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, co
     { const char* e = getenv("SF_ATTN_DBG"); p.dbg = e ? atoi(e) : 0; }
     if (sf_attn_waves() == 4) {
         constexpr int NW = 4;
-        dim3 grid((S + NW * 32 - 1) / (NW * 32), nh, B);
+        dim3 grid((unsigned)(((S + NW * 32 - 1) / (NW * 32)) * nh * B));
         SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_fwd_kernel<HD, NW>), 2 * 128 * HD * 2);
                        SF_LAUNCH((attn_fwd_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
         return sf_check_launch("sf_attn_fwd");
     }
     constexpr int NW = kAttnWaves;
-    dim3 grid((S + NW * 32 - 1) / (NW * 32), nh, B);
+    dim3 grid((unsigned)(((S + NW * 32 - 1) / (NW * 32)) * nh * B));
     SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_fwd_kernel<HD, NW>), 2 * 128 * HD * 2);
                    SF_LAUNCH((attn_fwd_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
     return sf_check_launch("sf_attn_fwd");
@@ -777,13 +791,13 @@ extern "C" int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long ld
                   nullptr, nullptr, 0, B, S, nh, nkv, scale);
     if (sf_attn_waves() == 4) {
         constexpr int NW = 4;
-        dim3 grid((S + NW * 32 - 1) / (NW * 32), nh, B);
+        dim3 grid((unsigned)(((S + NW * 32 - 1) / (NW * 32)) * nh * B));
         SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dq_kernel<HD, NW>), 2 * 128 * HD * 2);
                        SF_LAUNCH((attn_bwd_dq_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
         return sf_check_launch("sf_attn_bwd_dq");
     }
     constexpr int NW = kAttnWaves;
-    dim3 grid((S + NW * 32 - 1) / (NW * 32), nh, B);
+    dim3 grid((unsigned)(((S + NW * 32 - 1) / (NW * 32)) * nh * B));
     SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dq_kernel<HD, NW>), 2 * 128 * HD * 2);
                    SF_LAUNCH((attn_bwd_dq_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
     return sf_check_launch("sf_attn_bwd_dq");
@@ -802,13 +816,13 @@ extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long l
     static const int dkv_waves = [] { const char* e = getenv("SF_ATTN_DKV_WAVES"); return e ? atoi(e) : kAttnWaves; }();
     if (dkv_waves == 4) {
         constexpr int NW = 4;
-        dim3 grid((S + NW * 16 - 1) / (NW * 16), nkv, B);
+        dim3 grid((unsigned)(((S + NW * 16 - 1) / (NW * 16)) * nkv * B));
         SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, NW>), 2 * (128 * HD * 2 + 512));
                        SF_LAUNCH((attn_bwd_dkv_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (128 * HD * 2 + 512), stream, p));
         return sf_check_launch("sf_attn_bwd_dkv");
     }
     constexpr int NW = kAttnWaves;
-    dim3 grid((S + NW * 16 - 1) / (NW * 16), nkv, B);  // NW/2 key sub-blocks of 32 keys per workgroup
+    dim3 grid((unsigned)(((S + NW * 16 - 1) / (NW * 16)) * nkv * B));  // NW/2 key sub-blocks of 32 keys per workgroup
     SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, NW>), 2 * (128 * HD * 2 + 512));
                    SF_LAUNCH((attn_bwd_dkv_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (128 * HD * 2 + 512), stream, p));
     return sf_check_launch("sf_attn_bwd_dkv");
