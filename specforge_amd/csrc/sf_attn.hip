@@ -251,12 +251,42 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
 
     // diagonal branch terms: one extra key per later TTT step at the query's own position
     for (int i = 0; i < p.ndiag; ++i) {
-        const sf_bf16* kr = p.kd[i] + qrow * p.ldk + g * HD;
-        const sf_bf16* vr = p.vd[i] + qrow * p.ldk + g * HD;
+        sf_v8s kk[KS];
+        sf_v4s vv4[DB * 4];
+        if (NW == 4) {
+            // the block's 128 K_i / V_i rows go through LDS (coalesced LDS-DMA into the two free tile buffers) and every
+            // lane picks its own query's row from there; per-lane global reads of 32 different rows cost ~2x the
+            // whole main loop at 6 branches
+            sf_syncthreads();
+            const sf_bf16* kdb = p.kd[i] + (long)b * S * p.ldk + g * HD;
+            const sf_bf16* vdb = p.vd[i] + (long)b * S * p.ldk + g * HD;
+            stage_rows64<HD, NW>(smem, kdb, p.ldk, qb0, S, wave, lane);
+            stage_rows64<HD, NW>(smem + 64 * HD * 2, kdb, p.ldk, qb0 + 64, S, wave, lane);
+            stage_rows64<HD, NW>(smem + 128 * HD * 2, vdb, p.ldk, qb0, S, wave, lane);
+            stage_rows64<HD, NW>(smem + 192 * HD * 2, vdb, p.ldk, qb0 + 64, S, wave, lane);
+            sf_wait_vm0();
+            sf_syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kk[ks] = frag_rows<HD>(smem, wave * 32, ks, fo);
+            const char* vrow = smem + 128 * HD * 2 + (wave * 32 + c) * (HD * 2) + 8 * hi;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    vv4[d * 4 + j] = *reinterpret_cast<const sf_v4s*>(vrow + (((4 * d + j) ^ swz<HD>(c)) << 4));
+        } else {
+            const sf_bf16* kr = p.kd[i] + qrow * p.ldk + g * HD;
+            const sf_bf16* vr = p.vd[i] + qrow * p.ldk + g * HD;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kk[ks] = *reinterpret_cast<const sf_v8s*>(kr + 16 * ks + 8 * hi);
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vv4[d * 4 + j] = *reinterpret_cast<const sf_v4s*>(vr + d * 32 + 8 * j + 4 * hi);
+        }
         float dp = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            dp += dot8(qf[ks], *reinterpret_cast<const sf_v8s*>(kr + 16 * ks + 8 * hi));
+        for (int ks = 0; ks < KS; ++ks) dp += dot8(qf[ks], kk[ks]);
         dp += sf_shfl_xor(dp, 32);
         const float s2 = dp * sc;
         const float mn = fmaxf(m, s2);
@@ -268,7 +298,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
         for (int d = 0; d < DB; ++d)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const sf_v4s vv = *reinterpret_cast<const sf_v4s*>(vr + d * 32 + 8 * j + 4 * hi);
+                const sf_v4s vv = vv4[d * 4 + j];
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     acc_o[d][4 * j + t] = acc_o[d][4 * j + t] * alpha + e * sf_bf2f((sf_bf16)vv[t]);
