@@ -196,6 +196,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
         }
         if constexpr (ABL & 8) w4_wait_lgkm(); else
         w4_wait_all();   // my pieces of tile t+1 have landed; my reads of buffer t&1 have returned
+        if constexpr (!(ABL & 16))
         w4_barrier();    // -> tile t+1 visible to everyone, buffer t&1 free for tile t+2
         // ---- half-step 2t+1: compute set 1; fragments of (t+1, k-half 0) -> set 0; stage tile t+2
 #pragma unroll
@@ -232,6 +233,131 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
             w4_store4<OUT_F32, 0>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Soft-barrier variant (SF_GEMM_SOFT=1).  Ablation: deleting the per-K-tile s_barrier from the 4-wave loop
+// lifts it from 1.69 to 1.95 PFLOP/s (zero-filled 8192^3) -- the four waves of a workgroup drift apart by LDS /
+// DMA timing and every K-tile pays the slowest one.  Here the barrier's two halves are separate program points on a
+// monotonic LDS counter: a wave ARRIVES at the end of half-step 2t (its DMA pieces of tile t+1 have landed, its reads
+// of buffer t&1 have returned) and only WAITS for the other three at group G of half-step 2t+1, right before its
+// first read of tile t+1 / first DMA into buffer t&1 -- G groups (G x 64 cycles) of skew are absorbed for free.
+// Accumulators pinned to AGPRs, LDS-DMA from inline asm (the loop contains a spin loop; the builtin forms'
+// register allocation would not survive it).
+constexpr int kSoftG = 8;
+
+template <int OUT_F32>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4s_kernel(GemmW4Args p) {
+    SF_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
+    const int wr = wave >> 1, wc = wave & 1;
+    int tm, tn;
+    w4_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int nkt = p.K / TK;
+    unsigned* cnt = reinterpret_cast<unsigned*>(smem + 2 * kBufBytes);
+
+    const int srow = lane >> 3;
+    const int slc = (lane & 7) ^ (srow & 7);
+    const sf_bf16* src[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int ra = m0 + (8 * wave + j) * 8 + srow, rb = n0 + (8 * wave + j) * 8 + srow;
+        ra = ra < p.M ? ra : p.M - 1;
+        rb = rb < p.N ? rb : p.N - 1;
+        src[j] = p.A + (long)ra * p.lda + slc * 8;
+        src[8 + j] = p.B + (long)rb * p.ldb + slc * 8;
+    }
+    auto dma = [&](int g, int kt) {
+        char* dst = smem + (kt & 1) * kBufBytes + (g >> 3) * kOpBytes + (8 * wave + (g & 7)) * 1024;
+        sf_glds16_opaque(src[g], dst);
+        src[g] += TK;
+    };
+    const int frow = lane & 15;
+    int swz[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) swz[ks] = ((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
+    const int a_off = (wr * 128 + frow) * 128;
+    const int b_off = kOpBytes + (wc * 128 + frow) * 128;
+
+    sf_v4f acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
+    sf_v8s f[2][16];
+    auto read_frag = [&](int set, int g, const char* buf, int ks) {
+        if (g < 8) f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + b_off + g * 2048 + swz[ks]);
+        else f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + a_off + (g - 8) * 2048 + swz[ks]);
+    };
+
+    if (tid == 0) *cnt = 0u;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dma(g, 0);
+    if (nkt > 1) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dma(g, 1);
+    }
+    w4_wait_all();
+    sf_syncthreads();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) read_frag(0, g, smem, 0);
+
+    auto tile = [&](auto READ_NEXT, auto DO_DMA, int t) {
+        const char* cur = smem + (t & 1) * kBufBytes;
+        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
+                sf_mfma16_acc(f[0][nt], f[0][8 + mt], acc[mt][nt]);
+            }
+            w4_fence();
+            if (g < 8) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
+            w4_fence();
+        }
+        w4_wait_all();        // my DMA pieces of tile t+1 have landed, my reads of buffer t&1 have returned
+        sf_flag_arrive(cnt);  // ... and I say so; nobody waits here
+        const unsigned target = 4u * (unsigned)(t + 1);
+        unsigned seen = 0;
+        int fi = 0, di = 0;   // next fragment / DMA piece to issue (compile-time after unrolling)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
+                sf_mfma16_acc(f[1][nt], f[1][8 + mt], acc[mt][nt]);
+            }
+            w4_fence();
+            if (decltype(READ_NEXT)::value || decltype(DO_DMA)::value) {
+                if (g == kSoftG - 2) seen = sf_flag_peek(cnt);                       // early look, latency hidden
+                if (g == kSoftG && seen < target) sf_flag_wait(cnt, target);          // slow path only under real skew
+            }
+            if (g >= kSoftG) {
+                const int n = (16 - kSoftG) >= 12 ? (g < kSoftG + 4 ? 2 : 1) : 2;   // 16 issues over groups G .. 15
+#pragma unroll
+                for (int k = 0; k < n; ++k) {
+                    if constexpr (decltype(READ_NEXT)::value) { if (fi < 16) read_frag(0, fi, nxt, 0); }
+                    ++fi;
+                    if constexpr (decltype(DO_DMA)::value) { if (di < 16) dma(di, t + 2); }
+                    ++di;
+                }
+            }
+            w4_fence();
+        }
+    };
+    int t = 0;
+    for (; t + 2 < nkt; ++t) tile(std::true_type{}, std::true_type{}, t);
+    if (t + 1 < nkt) { tile(std::true_type{}, std::false_type{}, t); ++t; }
+    tile(std::false_type{}, std::false_type{}, t);
+
+    sf_mfma_drain();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            w4_store4<OUT_F32, 0>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Register-staged variant (experiment knob SF_GEMM_W4R=1): the same 4-wave pipeline, but operand tiles go
@@ -611,6 +737,22 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
         }
         return sf_check_launch("sf_gemm_nt(256w4m32)");
     }
+    static const bool soft = [] { const char* e = getenv("SF_GEMM_SOFT"); return e ? atoi(e) == 1 : false; }();
+    if (soft && !p.e.Cadd) {
+        const int smem_bytes = 2 * kBufBytes + 64;
+#ifndef SF_EMU
+        static bool attr_soft = false;
+        if (!attr_soft) {
+            hipFuncSetAttribute((const void*)gemm_nt_256w4s_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+            hipFuncSetAttribute((const void*)gemm_nt_256w4s_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+            (void)hipGetLastError();
+            attr_soft = true;
+        }
+#endif
+        if (c_dtype == SF_F32) SF_LAUNCH((gemm_nt_256w4s_kernel<1>), dim3((unsigned)nblk), dim3(256), smem_bytes, stream, p);
+        else SF_LAUNCH((gemm_nt_256w4s_kernel<0>), dim3((unsigned)nblk), dim3(256), smem_bytes, stream, p);
+        return sf_check_launch("sf_gemm_nt(256w4 soft)");
+    }
     static const bool w4r = [] { const char* e = getenv("SF_GEMM_W4R"); return e ? atoi(e) == 1 : false; }();
     if (w4r && !p.e.Cadd) {
         if (c_dtype == SF_F32) {
@@ -636,7 +778,7 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     static const int abl = [] { const char* e = getenv("SF_GEMM_ABL"); return e ? atoi(e) : 0; }();
 #define SF_ABL_CASE(V) \
     if (abl == V) { SF_W4_SMEM((gemm_nt_256w4_kernel<0, V>)); SF_LAUNCH((gemm_nt_256w4_kernel<0, V>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p); return sf_check_launch("abl"); }
-    SF_ABL_CASE(1) SF_ABL_CASE(2) SF_ABL_CASE(3) SF_ABL_CASE(4) SF_ABL_CASE(8) SF_ABL_CASE(9) SF_ABL_CASE(12)
+    SF_ABL_CASE(1) SF_ABL_CASE(2) SF_ABL_CASE(3) SF_ABL_CASE(4) SF_ABL_CASE(8) SF_ABL_CASE(9) SF_ABL_CASE(12) SF_ABL_CASE(16) SF_ABL_CASE(24)
 #undef SF_ABL_CASE
     static const bool bufdma = [] { const char* e = getenv("SF_GEMM_BUF"); return e ? atoi(e) == 1 : false; }();
     if (bufdma) {

@@ -44,6 +44,15 @@ SF_DEVICE void sf_mfma16_acc(sf_v8s a, sf_v8s b, sf_v4f& c) { c = sfemu::mfma_16
 SF_DEVICE void sf_mfma_drain() {}
 SF_DEVICE void sf_glds16(const void* g, void* l) { sfemu::global_load_lds16(g, l); }
 SF_DEVICE void sf_glds16_opaque(const void* g, void* l) { sfemu::global_load_lds16(g, l); }
+SF_DEVICE void sf_flag_arrive(unsigned* c) { if (sfemu::lane_id() == 0) sfemu::atomic_add(c, 1u); }
+SF_DEVICE unsigned sf_flag_peek(const unsigned* c) { return *(volatile const unsigned*)c; }
+SF_DEVICE void sf_flag_wait(const unsigned* c, unsigned target) {
+    long spins = 0;
+    while (*(volatile const unsigned*)c < target) {
+        sfemu::yield();
+        if (++spins > 50000000L) { fprintf(stderr, "[sfemu] sf_flag_wait: no progress\n"); abort(); }
+    }
+}
 struct SfBuf { const char* base; unsigned bytes; };
 SF_DEVICE SfBuf sf_make_buf(const void* base, unsigned bytes) { return SfBuf{(const char*)base, bytes}; }
 SF_DEVICE void sf_buf_glds16(SfBuf b, unsigned voff, unsigned soff, void* l) {
@@ -139,6 +148,17 @@ SF_DEVICE void sf_buf_glds16(SfBuf b, unsigned voff, unsigned soff, void* l) {
 SF_DEVICE void sf_glds16_opaque(const void* g, void* l) {
     const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds) : "memory", "m0");
+}
+// Workgroup-level arrive / wait on a monotonic LDS counter: a barrier whose "arrive" and "wait" halves are separate
+// program points (gfx950 has no split s_barrier).  arrive = release (everything this wave did to LDS is complete),
+// wait = acquire.  One lane per wave arrives.
+SF_DEVICE void sf_flag_arrive(unsigned* c) {
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+SF_DEVICE unsigned sf_flag_peek(const unsigned* c) { return __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+SF_DEVICE void sf_flag_wait(const unsigned* c, unsigned target) {
+    while (__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 SF_DEVICE void sf_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 SF_DEVICE void sf_setprio_hi() { __builtin_amdgcn_s_setprio(1); }

@@ -240,6 +240,8 @@ inline void block_barrier() {
     tls_ctx()->cur->state = AT_BLOCK_BARRIER;
     switch_to_sched();
 }
+// cooperative spin-wait step: stay RUNNABLE, let every other fiber of the block run one slice
+inline void yield() { switch_to_sched(); }
 inline void wave_sync() {
     tls_ctx()->cur->state = AT_WAVE_SYNC;
     switch_to_sched();
