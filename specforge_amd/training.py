@@ -234,6 +234,42 @@ class HipDPTrainingBackend:
             torch.set_rng_state(state["rng"]["cpu"])
 
 
+@dataclass
+class StepResult:
+    """what ``TrainerCore.train_step`` hands back (specforge/training/controller.py:232-262)"""
+
+    loss: torch.Tensor                    # un-divided micro-step loss (detached)
+    metrics: Dict[str, Any]
+    grad_norm: Optional[torch.Tensor]     # set on optimizer boundaries
+    stepped: bool
+
+
+class TrainerCore:
+    """The micro-step protocol of the reference trainer (specforge/training/controller.py:328-363) for the EAGLE3
+    strategy: loss / accumulation_steps -> ``backend.backward(is_boundary)`` (the gradient all-reduce is skipped on
+    non-boundary micro-steps, backend.py:310-320) -> ``backend.step()`` on the boundary."""
+
+    def __init__(self, strategy, backend: "HipDPTrainingBackend", *, accumulation_steps: int = 1):
+        if accumulation_steps < 1:
+            raise ValueError("accumulation_steps must be >= 1")
+        self.strategy, self.backend, self.accumulation_steps = strategy, backend, int(accumulation_steps)
+        self._micro = 0
+        self.global_step = 0
+
+    def train_step(self, batch, ctx=None) -> StepResult:
+        out = self.strategy.forward_loss(batch, ctx)
+        if out.loss_terms is not None:
+            raise NotImplementedError("loss_terms strategies (DFlash) are outside the EAGLE3 path")
+        loss = out.loss / self.accumulation_steps
+        self._micro += 1
+        stepped = self._micro % self.accumulation_steps == 0
+        self.backend.backward(loss, is_boundary=stepped)
+        grad_norm = self.backend.step() if stepped else None
+        if stepped:
+            self.global_step += 1
+        return StepResult(loss=out.loss.detach(), metrics=out.metrics, grad_norm=grad_norm, stepped=stepped)
+
+
 def distributed_sampler_indices(size: int, *, dp_rank: int, dp_size: int, seed: int, epoch: int, shuffle: bool = True):
     """``_distributed_sampler_indices`` (specforge/launch.py:219-239): == torch DistributedSampler."""
     if size <= 0:
