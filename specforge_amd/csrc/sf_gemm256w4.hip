@@ -245,8 +245,10 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
 // register allocation would not survive it).
 constexpr int kSoftG = 8;
 
-template <int OUT_F32>
+// SOFT = 0: the same asm-MFMA / opaque-DMA loop with the plain s_barrier and loads from group 0 (A/B reference point)
+template <int OUT_F32, int SOFT = 1>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4s_kernel(GemmW4Args p) {
+    constexpr int G0 = SOFT ? kSoftG : 0;
     SF_DYN_SMEM(smem);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
     const int wr = wave >> 1, wc = wave & 1;
@@ -317,7 +319,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4s_kernel(GemmW4Args p) {
             w4_fence();
         }
         w4_wait_all();        // my DMA pieces of tile t+1 have landed, my reads of buffer t&1 have returned
-        sf_flag_arrive(cnt);  // ... and I say so; nobody waits here
+        if (SOFT) sf_flag_arrive(cnt);  // ... and I say so; nobody waits here
+        else w4_barrier();
         const unsigned target = 4u * (unsigned)(t + 1);
         unsigned seen = 0;
         int fi = 0, di = 0;   // next fragment / DMA piece to issue (compile-time after unrolling)
@@ -329,12 +332,12 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4s_kernel(GemmW4Args p) {
                 sf_mfma16_acc(f[1][nt], f[1][8 + mt], acc[mt][nt]);
             }
             w4_fence();
-            if (decltype(READ_NEXT)::value || decltype(DO_DMA)::value) {
-                if (g == kSoftG - 2) seen = sf_flag_peek(cnt);                       // early look, latency hidden
-                if (g == kSoftG && seen < target) sf_flag_wait(cnt, target);          // slow path only under real skew
+            if (SOFT && (decltype(READ_NEXT)::value || decltype(DO_DMA)::value)) {
+                if (g == G0 - 2) seen = sf_flag_peek(cnt);                       // early look, latency hidden
+                if (g == G0 && seen < target) sf_flag_wait(cnt, target);          // slow path only under real skew
             }
-            if (g >= kSoftG) {
-                const int n = (16 - kSoftG) >= 12 ? (g < kSoftG + 4 ? 2 : 1) : 2;   // 16 issues over groups G .. 15
+            if (g >= G0) {
+                const int n = (16 - G0) >= 16 ? 1 : ((16 - G0) >= 12 ? (g < G0 + 4 ? 2 : 1) : 2);   // 16 issues over groups G0 .. 15
 #pragma unroll
                 for (int k = 0; k < n; ++k) {
                     if constexpr (decltype(READ_NEXT)::value) { if (fi < 16) read_frag(0, fi, nxt, 0); }
@@ -749,6 +752,21 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
             attr_soft = true;
         }
 #endif
+        static const bool hard = [] { const char* e = getenv("SF_GEMM_SOFT_HARD"); return e ? atoi(e) == 1 : false; }();
+        if (hard) {
+            static bool attr_h = false;
+#ifndef SF_EMU
+            if (!attr_h) {
+                hipFuncSetAttribute((const void*)gemm_nt_256w4s_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+                (void)hipGetLastError();
+                attr_h = true;
+            }
+#endif
+            (void)attr_h;
+            SF_CHECK_ARG(c_dtype != SF_F32, "SF_GEMM_SOFT_HARD: bf16 output only (A/B knob)");
+            SF_LAUNCH((gemm_nt_256w4s_kernel<0, 0>), dim3((unsigned)nblk), dim3(256), smem_bytes, stream, p);
+            return sf_check_launch("sf_gemm_nt(256w4 asm)");
+        }
         if (c_dtype == SF_F32) SF_LAUNCH((gemm_nt_256w4s_kernel<1>), dim3((unsigned)nblk), dim3(256), smem_bytes, stream, p);
         else SF_LAUNCH((gemm_nt_256w4s_kernel<0>), dim3((unsigned)nblk), dim3(256), smem_bytes, stream, p);
         return sf_check_launch("sf_gemm_nt(256w4 soft)");
