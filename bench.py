@@ -201,6 +201,7 @@ def main():
                          "launches_per_step": nlaunch / max(1, args.steps),
                          "gemm_ms_per_step": gemm_ms / max(1, args.steps)},
             "final_loss": loss,
+            "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
