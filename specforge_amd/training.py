@@ -166,6 +166,8 @@ class HipDPTrainingBackend:
         self.module: Optional[OnlineEagle3Model] = None
         self.optimizer: Optional[BF16Optimizer] = None
         self._handles: List[Any] = []
+        self._single_collective = os.environ.get("SF_DP_SINGLE") == "1"
+        self._pending_single = False
         self._sync_this_backward = True
         self.no_sync_backwards = 0  # telemetry: micro-steps that skipped the collective
 
@@ -192,6 +194,9 @@ class HipDPTrainingBackend:
     def _bucket_ready(self, lo: int, hi: int) -> None:
         if not self._sync_this_backward:
             return
+        if self._single_collective:      # SF_DP_SINGLE=1: one all-reduce of the whole flat gradient after the sweep
+            self._pending_single = True
+            return
         # async SUM over RCCL: enqueued behind the wgrad GEMM that produced the bucket, runs on the
         # communicator's stream while the compute stream continues with the next GEMM
         self._handles.append(dist.all_reduce(self.module.engine.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
@@ -208,6 +213,9 @@ class HipDPTrainingBackend:
 
     def synchronize_gradients(self) -> None:
         """wait for the bucket all-reduces launched by the last boundary backward"""
+        if self._pending_single:
+            dist.all_reduce(self.module.engine.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+            self._pending_single = False
         for h in self._handles:
             h.wait()
         self._handles.clear()
