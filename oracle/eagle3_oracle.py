@@ -1,7 +1,8 @@
 """CPU ORACLE for the EAGLE3 offline draft-training hot path.  TEST INFRASTRUCTURE ONLY.
 
-This file is a from-scratch CPU restatement (plain torch-CPU tensor algebra, autograd
-for gradients) of the reference algorithm.  It is imported ONLY by ``tests/``,
+This file is a from-scratch restatement (plain torch tensor algebra, autograd for
+gradients; CPU by default -- it follows the device of its inputs, so the full-size parity
+tests run the same code in fp32 on the GPU box as the checker) of the reference algorithm.  It is imported ONLY by ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg -- never by the
 product package ``specforge_amd`` (which fails loudly without its HIP library).
 
@@ -389,6 +390,7 @@ def eagle3_forward(
     out = Eagle3Out()
     B, S, _ = hidden_state.shape
     dt = hidden_state.dtype
+    dev = hidden_state.device   # the same restatement is the full-size checker on cuda (fp32) in tests/test_full_size.py
     # TargetHead.preprocess: shift target + input_ids left by one (target_head.py:103-108)
     target_hidden = padding_left_shift(target_hidden)
     input_ids = padding_left_shift(input_ids)
@@ -405,8 +407,9 @@ def eagle3_forward(
     hidden = project_hidden_states(p, cfg, hidden_state)
     if position_ids is None:
         position_ids = torch.arange(0, S, dtype=torch.long).unsqueeze(0)
-    add_mask = additive_attention_mask(attention_mask.bool() if attention_mask is not None else torch.ones(B, S, dtype=torch.bool), S, dt)
-    cos, sin = rope_tables(cfg, cfg.max_position_embeddings + 20, dt)
+    position_ids = position_ids.to(dev)
+    add_mask = additive_attention_mask(attention_mask.bool().cpu() if attention_mask is not None else torch.ones(B, S, dtype=torch.bool), S, dt).to(dev)
+    cos, sin = (t.to(dev) for t in rope_tables(cfg, cfg.max_position_embeddings + 20, dt))
     cache = [[], []]
     g_ids, g_pm, g_lm = input_ids, pos_mask, lm
     for idx in range(ttt_length):

@@ -466,6 +466,15 @@ class Eagle3Engine:
             self.on_bucket_ready(lo, f.numel)
         self.micro_in_window += 1
 
+    def bucket_bounds(self):
+        """(lo, hi) element ranges of flat.grad in the order the backward sweep hands them to ``on_bucket_ready``"""
+        f = self.flat
+        pairs = [("lm_head.weight", "lm_head.weight"), ("midlayer.mlp.gate_proj.weight", "midlayer.mlp.up_proj.weight"),
+                 ("midlayer.mlp.down_proj.weight", "midlayer.mlp.down_proj.weight"),
+                 ("midlayer.self_attn.q_proj.weight", "midlayer.self_attn.v_proj.weight"),
+                 ("midlayer.self_attn.o_proj.weight", "midlayer.self_attn.o_proj.weight"), ("fc.weight", "fc.weight")]
+        return [(f.slices[a][0], f.slices[b][1]) for a, b in pairs] + [(f.slices[self._norm_names[0]][0], f.numel)]
+
     def end_window(self):
         """called by the optimizer after it consumed flat.grad"""
         self.micro_in_window = 0

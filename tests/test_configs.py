@@ -81,3 +81,26 @@ def test_config_micro_step_matches_oracle(name):
         worst[k] = float((named[k].grad.float().cpu() - gref).abs().max()) / scale
     bad = {k: round(v, 4) for k, v in worst.items() if v > 6e-2}
     assert not bad, worst
+
+
+# ------------------------------------------------------------------ the other configs at their REAL dimensions
+REAL = {
+    # configs/qwen3-8b-eagle3.json
+    "cfg3_qwen3_8b": dict(H=4096, Ht=4096, I=12288, nh=32, nkv=8, hd=128, Vt=151936, Vd=32000, B=2, S=512, ttt=7, eps=1e-6,
+                          max_pos=40960, rope_theta=1000000.0, lengths=[512, 301]),
+    # configs/qwen3-30B-A3B-eagle3.1.json (fc_norm, nh*hd = 2H)
+    "cfg4_qwen3_30b_a3b_eagle31": dict(H=2048, Ht=2048, I=12288, nh=32, nkv=4, hd=128, Vt=151936, Vd=32000, B=2, S=512, ttt=7,
+                                       eps=1e-6, max_pos=2048, rope_theta=1000000.0, fc_norm=True, lengths=[512, 77]),
+    # configs/deepseek-v3-671b-eagle3.json (3*Ht = 21504 fusion input, I 40960, 129k vocabulary)
+    "cfg5_deepseek_v3": dict(H=7168, Ht=7168, I=40960, nh=56, nkv=8, hd=128, Vt=129280, Vd=32000, B=1, S=512, ttt=7, eps=1e-5,
+                             max_pos=163840, lengths=[509]),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(REAL))
+def test_real_dims_match_oracle(name):
+    """cfg 3 / 4 / 5 at the reference's own model dimensions (S = 512) vs the pinned oracle in fp32 on the GPU"""
+    from tests._parity import compare
+
+    compare(name, REAL[name])

@@ -1,0 +1,208 @@
+"""The kernels the headline step actually dispatches, at the headline shapes (Llama-3-8B draft, 8 x 2048 tokens,
+ttt 7), each against a plain fp32 reference computed with torch on the same GPU:
+
+* ``gemm_nt_256w4_kernel`` (taken when ceil(M/256)*ceil(N/256) >= 256 and K >= 512): lm_head (16384, 32000, 4096),
+  down-proj (16384, 4096, 14336), the row-addend form of the QKV projection (16384, 6144, 4096);
+* ``gemm_tn_256w4_kernel`` at K = T*N = 114 688 for the lm_head and down-proj weight gradients, incl. the AUTOMATIC
+  deterministic 2-way split-K (down: 16 x 56 = 896 tiles = 3.5 rounds of 256 CUs);
+* bitwise run-to-run determinism of those kernels over 26 launches (they carry hand-managed hazards);
+* TTT attention at S in {1024, 2048} with right padding and 6 diagonal branches (the reference's own backend-parity
+  test goes to 2048: tests/test_utils/test_flex_attention.py:44-242) -- the heaviest-first 1-D dispatch and the
+  multi-block causal bookkeeping only exist at these lengths;
+* the fused CE at (8*2048, 32000) bf16 with a DENSE position mask (every row reads its soft target).
+GPU only (the SIMT interpreter would take hours at these sizes).
+"""
+import math
+
+import pytest
+import torch
+
+from specforge_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _randn(shape, seed, dtype=torch.bfloat16, scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(shape, device=DEV, generator=g) * scale).to(dtype)
+
+
+def _check(out, ref, K, out_dtype, what):
+    tol = 1e-3 if out_dtype == torch.float32 else 2e-2
+    err = (out.float() - ref).abs()
+    rel_max = float(err.max() / ref.abs().max())
+    print(f"\n[{what}] max|err|/max|ref| = {rel_max:.3e}")
+    torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol * math.sqrt(K))
+    assert rel_max < (2e-4 if out_dtype == torch.float32 else 8e-3), rel_max
+
+
+@pytest.mark.parametrize("M,N,K", [(16384, 32000, 4096), (16384, 4096, 14336), (16384, 28672, 4096)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_nt_headline_shapes(M, N, K, out_dtype):
+    a, b = _randn((M, K), 1), _randn((N, K), 2)
+    ref = a.float() @ b.float().t()
+    out = torch.full((M, N), 7.0, dtype=out_dtype, device=DEV)
+    ops.gemm_nt(a, b, out)
+    _check(out, ref, K, out_dtype, f"nt {M}x{N}x{K}")
+    if out_dtype == torch.bfloat16 and N == 4096:
+        res = _randn((M, N), 3)
+        ops.gemm_nt(a, b, out, residual=res)      # the down-proj / o-proj epilogue: + residual after the rounding
+        torch.testing.assert_close(out.float(), (ref.to(torch.bfloat16) + res).float(), rtol=2e-2, atol=2e-2 * math.sqrt(K))
+
+
+def test_gemm_nt_rowadd_headline_shape():
+    M, N, K, S, T = 16384, 6144, 4096, 2048, 7
+    B, Spad = M // S, S + T
+    a, b = _randn((M, K), 1), _randn((N, K), 2)
+    add = _randn((B * Spad, N), 3, dtype=torch.float32, scale=30.0)
+    base = a.float() @ b.float().t()
+    for off in (0, 3, T):
+        rows = (torch.arange(M, device=DEV) // S) * Spad + torch.arange(M, device=DEV) % S + off
+        out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        ops.gemm_nt_rowadd(a, b, out, add, S=S, Spad=Spad, off=off)
+        _check(out, base + add[rows], K, torch.bfloat16, f"rowadd off={off}")
+
+
+@pytest.mark.parametrize("M,N,name", [(32000, 4096, "lm_head"), (4096, 14336, "down"), (6144, 4096, "qkv-hidden-half")])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_tn_k114688(M, N, name, out_dtype):
+    """dW = dY^T . X over all T*N = 114 688 token rows, workspace given -> the kernel picks split-K by itself"""
+    K = 7 * 16384
+    a, b = _randn((K, M), 1), _randn((K, N), 2)
+    ref = torch.empty(M, N, device=DEV)
+    for m0 in range(0, M, 8192):                      # fp32 reference in row blocks (bounded temporaries)
+        ref[m0:m0 + 8192] = a[:, m0:m0 + 8192].float().t() @ b.float()
+    ws = torch.empty(2 * M * N, dtype=torch.float32, device=DEV)
+    out = torch.full((M, N), 7.0, dtype=out_dtype, device=DEV)
+    ops.gemm_tn(a, b, out, workspace=ws)
+    _check(out, ref, K, out_dtype, f"tn {name} {M}x{N}x{K}")
+    out2 = torch.full((M, N), 1.0, dtype=out_dtype, device=DEV)
+    ops.gemm_tn(a, b, out2, alpha=0.5, beta=2.0, workspace=ws)   # accumulation-window form (beta = 1 in the engine)
+    _check(out2, 0.5 * ref + 2.0, K, out_dtype, f"tn {name} alpha/beta")
+    out3 = torch.full((M, N), 7.0, dtype=out_dtype, device=DEV)
+    ops.gemm_tn(a, b, out3)                                      # no workspace -> unsplit
+    _check(out3, ref, K, out_dtype, f"tn {name} unsplit")
+
+
+@pytest.mark.parametrize("form,M,N,K", [("nt", 16384, 4096, 14336), ("nt", 16384, 32000, 4096), ("rowadd", 16384, 6144, 4096),
+                                        ("tn", 4096, 14336, 114688), ("tn", 32000, 4096, 114688)])
+def test_gemm_bitwise_determinism(form, M, N, K):
+    if form == "tn":
+        a, b = _randn((K, M), 1), _randn((K, N), 2)
+        ws = torch.empty(2 * M * N, dtype=torch.float32, device=DEV)
+        f = lambda o: ops.gemm_tn(a, b, o, workspace=ws)
+    elif form == "nt":
+        a, b = _randn((M, K), 1), _randn((N, K), 2)
+        f = lambda o: ops.gemm_nt(a, b, o)
+    else:
+        a, b = _randn((M, K), 1), _randn((N, K), 2)
+        add = _randn((8 * 2055, N), 3, dtype=torch.float32)
+        f = lambda o: ops.gemm_nt_rowadd(a, b, o, add, S=2048, Spad=2055, off=5)
+    first = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    f(first)
+    o = torch.empty_like(first)
+    for i in range(25):
+        o.fill_(0)
+        f(o)
+        assert torch.equal(o, first), f"run {i + 1} differs from run 0"
+
+
+@pytest.mark.parametrize("S,lengths", [(1024, [1024, 651]), (2048, [2048, 1675])])
+@pytest.mark.parametrize("nsteps", [1, 7])
+def test_ttt_attention_long(S, lengths, nsteps):
+    from tests.test_attention import _mk, _oracle
+
+    B, nh, nkv, hd = 2, 4, 2, 128
+    q, ks, vs, do = _mk(B, S, nh, nkv, hd, nsteps, seed=S + nsteps)
+    o_ref, dq_ref, dk_ref, dv_ref = _oracle(q, ks, vs, do, B, S, nh, nkv, hd, lengths)
+    d = lambda t: t.to(DEV)
+    scale = 1.0 / math.sqrt(hd)
+    N = B * S
+    qkv = [torch.zeros(N, (nh + 2 * nkv) * hd, dtype=torch.bfloat16) for _ in range(nsteps)]
+    for i in range(nsteps):
+        qkv[i][:, nh * hd:(nh + nkv) * hd] = ks[i].view(N, -1)
+        qkv[i][:, (nh + nkv) * hd:] = vs[i].view(N, -1)
+    qkv[-1][:, :nh * hd] = q.view(N, -1)
+    qkv = [d(t) for t in qkv]
+    qv = qkv[-1][:, :nh * hd]
+    kview = [t[:, nh * hd:(nh + nkv) * hd] for t in qkv]
+    vview = [t[:, (nh + nkv) * hd:] for t in qkv]
+    kv_len = d(torch.tensor(lengths, dtype=torch.int32))
+    o = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, nh, S, device=DEV)
+    ops.attn_fwd(qv, kview[0], vview[0], kview[1:], vview[1:], kv_len, o, lse, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+    torch.testing.assert_close(o.float().cpu(), o_ref, rtol=1e-2, atol=1e-2)   # the reference's bar: test_flex_attention.py:124-132
+    dout = d(do.view(N, -1))
+    delta = torch.empty(B, nh, S, device=DEV)
+    dq_init = torch.zeros(N, nh * hd, device=DEV) if nsteps > 1 else None
+    dk_acc = [torch.zeros(N, nkv * hd, device=DEV) for _ in range(nsteps)]
+    dv_acc = [torch.zeros(N, nkv * hd, device=DEV) for _ in range(nsteps)]
+    ops.attn_bwd_pre(qv, o, dout, kview[1:], vview[1:], dk_acc[1:], dv_acc[1:], lse, delta, dq_init, B=B, S=S, nh=nh,
+                     nkv=nkv, hd=hd, scale=scale)
+    dq = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=DEV)
+    ops.attn_bwd_dq(qv, dout, kview[0], vview[0], kv_len, lse, delta, dq_init, dq, B=B, S=S, nh=nh, nkv=nkv, hd=hd,
+                    scale=scale)
+    ops.attn_bwd_dkv(qv, dout, kview[0], vview[0], kv_len, lse, delta, dk_acc[0], dv_acc[0], B=B, S=S, nh=nh,
+                     nkv=nkv, hd=hd, scale=scale)
+
+    def close(got, ref, what):
+        tol = 2e-2 * float(ref.abs().max()) + 1e-6
+        err = float((got.float().cpu() - ref).abs().max())
+        print(f"[attn S={S} k={nsteps}] {what}: err/max = {err / float(ref.abs().max() + 1e-12):.3e}")
+        assert err <= tol, (what, err, tol)
+
+    close(dq, dq_ref, "dq")
+    for i in range(nsteps):
+        close(dk_acc[i], dk_ref[i], f"dk{i}")
+        close(dv_acc[i], dv_ref[i], f"dv{i}")
+    for bi, L in enumerate(lengths):
+        if L < S:
+            assert float(dk_acc[0].view(B, S, -1)[bi, L:].abs().max()) == 0.0
+            assert float(dv_acc[0].view(B, S, -1)[bi, L:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("density", [1.0, 0.25])
+def test_ce_fused_headline_shape(density):
+    """(8*2048, 32000) bf16 logits; density 1.0 = every row carries a position mask (reads its soft target)"""
+    B, S, V, T, off = 8, 2048, 32000, 7, 3
+    Spad, N = S + T, B * S
+    g = torch.Generator(device=DEV).manual_seed(5)
+    logits = (torch.randn(N, V, device=DEV, generator=g) * 2).to(torch.bfloat16)
+    target_pad = torch.softmax(torch.randn(B, Spad, V, device=DEV, generator=g) * 3, -1)
+    pos_pad = (torch.rand(B, Spad, device=DEV, generator=g) < density).int()
+    lm_pad = torch.ones(B, Spad, dtype=torch.int32, device=DEV)
+    pod_pad = torch.rand(B, Spad, device=DEV, generator=g)
+    tsum_pad = target_pad.sum(-1)
+    d2t = torch.randint(0, 50, (V,), device=DEV, generator=g).sort().values
+    ids_pad = torch.randint(0, V + 50, (B, Spad), device=DEV, generator=g)
+    sl = lambda t: t[:, off:off + S].reshape(N, *t.shape[2:])
+    gs = 0.512 / N
+    # fp32 reference in row chunks
+    rl, acc, cor, pred = (torch.empty(N, device=DEV) for _ in range(4))
+    grad = torch.empty(N, V, device=DEV)
+    tgt, pm, pod = sl(target_pad), sl(pos_pad).float(), sl(pod_pad)
+    for r0 in range(0, N, 2048):
+        r = slice(r0, r0 + 2048)
+        x = logits[r].float()
+        lp = torch.log_softmax(x, -1)
+        sm = lp.exp()
+        rl[r] = -(tgt[r] * lp).sum(-1) * pm[r]
+        grad[r] = (sm * tgt[r].sum(-1, keepdim=True) - tgt[r]) * pm[r, None] * gs
+        acc[r] = torch.minimum(tgt[r] * pod[r, None], sm).sum(-1) * pm[r]
+        p = x.argmax(-1)
+        pred[r] = p.float()
+        cor[r] = ((p + d2t[p]) == sl(ids_pad)[r]).float()
+    x = logits.clone()
+    row_loss, row_cor, row_acc = (torch.empty(N, device=DEV) for _ in range(3))
+    row_pred = torch.empty(N, dtype=torch.int32, device=DEV)
+    ops.ce_fused(x, target_pad, S=S, Spad=Spad, off=off, pos_mask_pad=pos_pad, loss_mask_pad=lm_pad, tgt_ids_pad=ids_pad,
+                 pod_scale_pad=pod_pad, tsum_pad=tsum_pad, d2t=d2t, grad_scale=gs, row_loss=row_loss, row_correct=row_cor,
+                 row_accept=row_acc, row_pred=row_pred)
+    assert torch.equal(row_pred.float(), pred)
+    assert torch.equal(row_cor, cor)
+    tol = 2e-2
+    torch.testing.assert_close(row_loss, rl, rtol=tol, atol=tol)
+    torch.testing.assert_close(row_acc, acc, rtol=tol, atol=tol)
+    torch.testing.assert_close(x.float(), grad, rtol=tol, atol=tol * float(grad.abs().max()))
+    assert float(x.float()[pm == 0].abs().max() if density < 1 else 0.0) == 0.0
