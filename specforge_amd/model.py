@@ -168,14 +168,23 @@ class _Layer(nn.Module):
         self.post_attention_layernorm = _W(c.hidden_size, **nkw)
 
 
-class LlamaForCausalLMEagle3(nn.Module):
-    """Parameter container with the reference's names and registration order
-    (llama3_eagle.py:1658-1700): embed_tokens, midlayer, fc, [fc_norm], norm, lm_head, t2d, d2t."""
+class Eagle3DraftMethods:
+    """The ``Eagle3DraftModel`` seam (specforge/modeling/draft/base.py:38-206) on the C-ABI: parameter construction
+    under the reference's names, the four abstract methods (``embed_input_ids`` / ``project_hidden_states`` /
+    ``backbone`` / ``compute_logits``; base.py:45-109, llama3_eagle.py:1702-1798), ``load_embedding(path)`` (base.py:135)
+    and ``load_vocab_mapping(path)`` (base.py:193).  A mixin so the same code serves the standalone container below
+    (``nn.Module``) and the ``@register_draft`` class that ``specforge_amd.reference_plugin`` derives from the
+    reference's own ``Eagle3DraftModel`` when that package is importable.
 
-    def __init__(self, config, attention_backend: str = "hip", dtype=torch.bfloat16, device=None):
-        super().__init__()
-        c = config if isinstance(config, DraftConfig) else DraftConfig.from_hf(config)
-        self.config = c
+    The four methods are forward-only (evaluation, export checks, the reference's assembly code): each is one or a few
+    C-ABI calls on the current stream with no autograd graph.  TRAINING never goes through them -- the whole TTT
+    micro-step runs in ``specforge_amd.engine.Eagle3Engine`` (one level up, the ``OnlineEagle3Model`` seam), which is
+    what keeps activations in persistent stashes and the weight gradients deferred."""
+
+    def _build_parameters(self, c: DraftConfig, attention_backend: str, dtype, device) -> None:
+        """registration order of the reference (llama3_eagle.py:1658-1700): embed_tokens, midlayer, fc, [fc_norm], norm,
+        lm_head, t2d, d2t"""
+        self.draft_config = c
         self.attention_backend = attention_backend
         self.vocab_size, self.draft_vocab_size = c.vocab_size, c.draft_vocab_size
         self.target_hidden_size = c.target_hidden_size
@@ -189,9 +198,10 @@ class LlamaForCausalLMEagle3(nn.Module):
         self.lm_head = _W(c.draft_vocab_size, c.hidden_size, **kw)
         self.register_buffer("t2d", torch.ones(c.vocab_size, dtype=torch.bool, device=device))
         self.register_buffer("d2t", torch.zeros(c.draft_vocab_size, dtype=torch.int64, device=device))
-        self.freeze_embedding()
+        self.vocab_mapping_loaded = False
+        self._rope = None
 
-    # -- the reference ABC's helpers (modeling/draft/base.py:128-206) -------------------------
+    # -- helpers of the reference ABC (modeling/draft/base.py:128-206) ------------------------
     def freeze_embedding(self) -> None:
         self.embed_tokens.weight.requires_grad = False
 
@@ -203,6 +213,167 @@ class LlamaForCausalLMEagle3(nn.Module):
         with torch.no_grad():
             self.t2d.copy_(t2d.to(torch.bool))
             self.d2t.copy_(d2t.to(torch.int64))
+        self.vocab_mapping_loaded = True
+
+    @torch.no_grad()
+    def load_embedding(self, model_path: str, embedding_key: str = "model.embed_tokens.weight") -> None:
+        """base.py:135-191: copy the target's embedding table from a local model directory (``*.index.json`` ->
+        shard, else ``model.safetensors`` / ``pytorch_model.bin``).  Hub ids are not resolved here (no network on the
+        training nodes): pass the local snapshot directory."""
+        import glob
+        import json
+        import os
+
+        if not os.path.isdir(model_path):
+            raise FileNotFoundError(f"load_embedding: {model_path!r} is not a local model directory")
+        index = glob.glob(os.path.join(model_path, "*.index.json"))
+        if len(index) > 1:
+            raise FileNotFoundError(f"Multiple index.json files found in {model_path}")
+        if index:
+            with open(index[0]) as f:
+                ckpt = os.path.join(model_path, json.load(f)["weight_map"][embedding_key])
+        elif os.path.exists(os.path.join(model_path, "model.safetensors")):
+            ckpt = os.path.join(model_path, "model.safetensors")
+        elif os.path.exists(os.path.join(model_path, "pytorch_model.bin")):
+            ckpt = os.path.join(model_path, "pytorch_model.bin")
+        else:
+            raise FileNotFoundError(f"No index.json, model.safetensors or pytorch_model.bin found in {model_path}")
+        if ckpt.endswith(".safetensors"):
+            from safetensors import safe_open
+
+            with safe_open(ckpt, framework="pt") as f:
+                w = f.get_tensor(embedding_key)
+        else:
+            w = torch.load(ckpt, map_location="cpu")[embedding_key]
+        self.load_embedding_weight(w)
+
+    def load_vocab_mapping(self, file_path: str) -> None:
+        """base.py:193-206: ``torch.save({"t2d": bool[Vt], "d2t": int64[Vd]})``"""
+        m = torch.load(file_path, map_location="cpu")
+        self.load_vocab_mapping_tensors(m["t2d"], m["d2t"])
+
+    # -- the four abstract methods, forward-only on the C-ABI ---------------------------------------
+    def _w(self, name: str) -> torch.Tensor:
+        return self.get_parameter(name).data
+
+    @torch.no_grad()
+    def embed_input_ids(self, input_ids: torch.Tensor) -> torch.Tensor:
+        """llama3_eagle.py:1759-1760: frozen embedding gather, [B,S] -> [B,S,H]"""
+        return self.embed_tokens.weight.data[input_ids]
+
+    @torch.no_grad()
+    def project_hidden_states(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        """llama3_eagle.py:1762-1770: [B,S,3Ht] -> (3x fc_norm) -> fc -> [B,S,H]"""
+        from . import ops
+
+        c = self.draft_config
+        B, S, W = hidden_states.shape
+        x = hidden_states.reshape(B * S, W).to(torch.bfloat16)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        if c.fc_norm:
+            Ht = c.target_hidden_size
+            xn = torch.empty_like(x)
+            for i in range(3):
+                ops.rmsnorm_fwd(x[:, i * Ht:(i + 1) * Ht], self.fc_norm[i].weight.data, c.rms_norm_eps,
+                                xn[:, i * Ht:(i + 1) * Ht], None)
+            x = xn
+        out = torch.empty(B * S, c.hidden_size, dtype=torch.bfloat16, device=x.device)
+        ops.gemm_nt(x, self.fc.weight.data, out)
+        return out.view(B, S, c.hidden_size)
+
+    @torch.no_grad()
+    def compute_logits(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        """llama3_eagle.py:1772-1777: lm_head(norm(h)) (norm skipped when ``norm_output`` is False)"""
+        from . import ops
+
+        c = self.draft_config
+        B, S, H = hidden_states.shape
+        x = hidden_states.reshape(B * S, H).contiguous()
+        if c.norm_output:
+            xn = torch.empty_like(x)
+            ops.rmsnorm_fwd(x, self.norm.weight.data, c.rms_norm_eps, xn, None)
+            x = xn
+        out = torch.empty(B * S, c.draft_vocab_size, dtype=torch.bfloat16, device=x.device)
+        ops.gemm_nt(x, self.lm_head.weight.data, out)
+        return out.view(B, S, c.draft_vocab_size)
+
+    @torch.no_grad()
+    def backbone(self, input_embeds, hidden_states, cache_hidden, attention_mask, position_ids, past_key_values=None,
+                 use_cache: bool = True) -> torch.Tensor:
+        """One TTT step of ``LlamaDecoderLayer`` (llama3_eagle.py:1598-1650; attention cache branch 717-778):
+        ``cache_hidden`` is the caller-owned ``[[k...],[v...]]`` list of one micro-step -- this step's K/V are appended
+        (as [B*S, nkv*hd] bf16 views) and every earlier step contributes its diagonal.  ``attention_mask`` is the
+        [B,S] padding mask or the 4-D additive mask of ``prepare_decoder_attention_mask`` (its last query row tells the
+        number of valid keys: the collator right-pads)."""
+        from . import ops
+
+        if past_key_values is not None:
+            raise NotImplementedError("past_key_values is unused by EAGLE3 training (eagle3/model.py:262)")
+        c = self.draft_config
+        B, S, H = hidden_states.shape
+        N = B * S
+        dev = hidden_states.device
+        nh, nkv, hd, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        if S % 8 != 0:
+            raise ValueError("sequence length must be a multiple of 8")
+        if attention_mask is None:
+            kv_len = torch.full((B,), S, dtype=torch.int32, device=dev)
+        elif attention_mask.dim() == 2:
+            kv_len = attention_mask.to(dev).sum(dim=1).to(torch.int32)
+        else:
+            kv_len = (attention_mask[:, 0, -1, :] == 0).sum(dim=-1).to(torch.int32).to(dev)
+        lck = len(cache_hidden[0])
+        if self._rope is None or self._rope[0].device != dev:
+            cos, sin = rope_tables(c, torch.bfloat16)
+            self._rope = (cos.to(dev), sin.to(dev))
+        cos, sin = self._rope
+        pos = (torch.arange(S, device=dev).repeat(B) if position_ids is None
+               else position_ids.to(dev).expand(B, S).reshape(-1)).to(torch.int64).contiguous()
+        ml = self.midlayer
+        bf = torch.bfloat16
+        e = lambda *shape, dtype=bf: torch.empty(*shape, dtype=dtype, device=dev)
+        h = hidden_states.reshape(N, H).to(bf).contiguous()
+        x = e(N, 2 * H)            # cat(input_layernorm(embeds), hidden_norm(hidden))  (1625-1630)
+        ops.rmsnorm_fwd(input_embeds.reshape(N, H).to(bf).contiguous(), ml.input_layernorm.weight.data, eps, x[:, :H], None)
+        ops.rmsnorm_fwd(h, ml.hidden_norm.weight.data, eps, x[:, H:], None)
+        QW = (nh + 2 * nkv) * hd
+        qkv = e(N, QW)
+        at = ml.self_attn
+        ops.gemm_nt(x, at.q_proj.weight.data, qkv[:, :nh * hd])
+        ops.gemm_nt(x, at.k_proj.weight.data, qkv[:, nh * hd:(nh + nkv) * hd])
+        ops.gemm_nt(x, at.v_proj.weight.data, qkv[:, (nh + nkv) * hd:])
+        ops.rope_(qkv, nh + nkv, hd, cos, sin, pos, lck)
+        cache_hidden[0].append(qkv[:, nh * hd:(nh + nkv) * hd])
+        cache_hidden[1].append(qkv[:, (nh + nkv) * hd:])
+        ks, vs = cache_hidden
+        o, lse = e(N, nh * hd), e(B, nh, S, dtype=torch.float32)
+        ops.attn_fwd(qkv[:, :nh * hd], ks[0], vs[0], ks[1:], vs[1:], kv_len, o, lse, B=B, S=S, nh=nh, nkv=nkv, hd=hd,
+                     scale=1.0 / math.sqrt(hd))
+        h1 = e(N, H)
+        ops.gemm_nt(o, at.o_proj.weight.data, h1, residual=h)
+        pn = e(N, H)
+        ops.rmsnorm_fwd(h1, ml.post_attention_layernorm.weight.data, eps, pn, None)
+        I = c.intermediate_size
+        gu = e(N, 2 * I)
+        ops.gemm_nt(pn, ml.mlp.gate_proj.weight.data, gu[:, :I])
+        ops.gemm_nt(pn, ml.mlp.up_proj.weight.data, gu[:, I:])
+        act = e(N, I)
+        ops.swiglu_fwd(gu, act)
+        out = e(N, H)
+        ops.gemm_nt(act, ml.mlp.down_proj.weight.data, out, residual=h1)
+        return out.view(B, S, H)
+
+
+class LlamaForCausalLMEagle3(Eagle3DraftMethods, nn.Module):
+    """Standalone parameter container with the reference's names and registration order."""
+
+    def __init__(self, config, attention_backend: str = "hip", dtype=torch.bfloat16, device=None):
+        super().__init__()
+        c = config if isinstance(config, DraftConfig) else DraftConfig.from_hf(config)
+        self.config = c
+        self._build_parameters(c, attention_backend, dtype, device)
+        self.freeze_embedding()
 
 
 # order of the flat buffer = order in which the backward sweep finishes the gradients, so the DP

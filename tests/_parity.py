@@ -2,13 +2,19 @@
 vs the pinned oracle (oracle/eagle3_oracle.py) run ON THE SAME GPU in fp32 as the checker -- the CPU
 cannot finish Llama-3-8B x seq 2048 in test time, the restatement is device-agnostic torch.
 
-What is compared (BASELINE.json north_star tolerances, bf16 path 2e-2):
-  * plosses / loss / acceptance rates: rtol = atol = 2e-2
-  * acc_denoms: bit-exact; teacher argmax ids >= 99.9 % (the HIP path rounds the teacher logits to bf16 exactly like
-    ``TargetHead.forward`` does, the fp32 checker does not, so exact near-ties may resolve differently)
+The checker runs the DRAFT in fp32 and the frozen teacher head in bf16 (as the reference trains: ``TargetHead`` is a
+bf16 module, so bf16-rounded teacher logits and the argmax near-ties they create belong to the reference's semantics;
+a first version with an fp32 teacher disagreed on 1-3 % of the argmax ids for the HIP path AND for the reference's own
+bf16 run alike, which then dominated every gradient comparison at 8-17 %).
+
+What is compared (BASELINE.json north_star tolerance for the bf16 path: 2e-2):
+  * plosses / loss / acceptance rates / accuracy
+  * acc_denoms: bit-exact; teacher argmax ids and position mask (two bf16 GEMMs with fp32 accumulation in different
+    orders can differ in the last ulp, so exact ties may flip: >= 99.95 %, measured 100 %)
   * every parameter gradient: max-abs error relative to the tensor's max-abs, and relative Frobenius error
-The same comparison is made for the oracle run in bf16 (= what the reference itself produces at that precision;
-torch/hipBLASLt kernels) so each number has a yardstick.  Results go to gpurun_out/parity_<name>.json.
+The same numbers are taken for the oracle run entirely in bf16 (= what the reference itself produces at that
+precision with torch/hipBLASLt kernels), the yardstick each HIP number is printed beside.
+Results go to gpurun_out/parity_<name>.json (committed under profiles/).
 """
 import json
 import os
@@ -49,11 +55,14 @@ def make_case(c, seed=1):
 
 
 def run_oracle(oc, params, embed, head_w, t2d, d2t, batch, ttt, dev, dtype):
+    """draft in ``dtype``; the TEACHER always in bf16: the frozen ``TargetHead`` is a bf16 module in the reference's
+    training runs (target_head.py:100-101 on bf16 features), so bf16-rounded teacher logits -- and the argmax ties they
+    create -- are part of the reference's semantics, not an approximation of the HIP path."""
     p = {k: v.to(dev).to(dtype).requires_grad_(True) for k, v in params.items()}
-    out = O.eagle3_forward(p, oc, embed_weight=embed.to(dev).to(dtype), target_head_weight=head_w.to(dev).to(dtype),
+    out = O.eagle3_forward(p, oc, embed_weight=embed.to(dev).to(dtype), target_head_weight=head_w.to(dev),
                            t2d=t2d.to(dev), d2t=d2t.to(dev), input_ids=batch["input_ids"].to(dev),
                            attention_mask=batch["attention_mask"], loss_mask=batch["loss_mask"].to(dev),
-                           hidden_state=batch["hidden_state"].to(dev).to(dtype), target_hidden=batch["target"].to(dev).to(dtype),
+                           hidden_state=batch["hidden_state"].to(dev).to(dtype), target_hidden=batch["target"].to(dev),
                            ttt_length=ttt)
     out.loss.backward()
     res = dict(plosses=torch.stack([x.detach().float() for x in out.plosses]).cpu(), loss=out.loss.detach().float().cpu(),
@@ -99,7 +108,7 @@ def grad_errors(got, ref):
     return rows
 
 
-def compare(name, c, *, loss_tol=2e-2, ids_min=0.999, grad_max_rel=5e-2, grad_fro_rel=3e-2, with_bf16_yardstick=True):
+def compare(name, c, *, loss_tol=5e-3, ids_min=0.9995, grad_max_rel=2e-2, grad_fro_rel=2e-2, with_bf16_yardstick=True):
     """runs both sides, writes the report, asserts the bars; returns the report dict."""
     dev = torch.device("cuda", 0)
     ttt = c["ttt"]
