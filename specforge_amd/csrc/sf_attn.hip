@@ -736,7 +736,7 @@ extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, co
                            const void* const* vd, int ndiag, const int* kv_len, void* o, long ldo, float* lse, int B,
                            int S, int nh, int nkv, int hd, float scale, void* stream) {
     SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_fwd: bad shape");
-    SF_CHECK_ARG(S % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0, "sf_attn_fwd: S and strides must be multiples of 8");
+    SF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0, "sf_attn_fwd: row strides must be multiples of 8 (16-byte segments)");
     SF_CHECK_ARG(ndiag >= 0 && ndiag <= kMaxDiag, "sf_attn_fwd: at most 8 diagonal branches");
     AttnFwdArgs p;
     memset(&p, 0, sizeof(p));
@@ -814,8 +814,8 @@ extern "C" int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long ld
                               const float* delta, const float* dq_init, void* dq, long lddq, int B, int S, int nh,
                               int nkv, int hd, float scale, void* stream) {
     SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_dq: bad shape");
-    SF_CHECK_ARG(S % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0,
-                 "sf_attn_bwd_dq: S and strides must be multiples of 8");
+    SF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0,
+                 "sf_attn_bwd_dq: row strides must be multiples of 8 (16-byte segments)");
     AttnBwdArgs p;
     fill_bwd_args(p, q, ldq, dout, lddo, k0, ldk, v0, ldv, kv_len, lse, delta, dq_init, dq, lddq,
                   nullptr, nullptr, 0, B, S, nh, nkv, scale);
@@ -838,8 +838,8 @@ extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long l
                                const float* delta, float* dk, float* dv, long lddk, int B, int S, int nh, int nkv,
                                int hd, float scale, void* stream) {
     SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_dkv: bad shape");
-    SF_CHECK_ARG(S % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddk % 4 == 0,
-                 "sf_attn_bwd_dkv: S and strides must be multiples of 8");
+    SF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddk % 4 == 0,
+                 "sf_attn_bwd_dkv: row strides must be multiples of 8 (16-byte segments)");
     AttnBwdArgs p;
     fill_bwd_args(p, q, ldq, dout, lddo, k0, ldk, v0, ldv, kv_len, lse, delta, nullptr, nullptr, 0, dk,
                   dv, lddk, B, S, nh, nkv, scale);

@@ -56,13 +56,41 @@ class OnlineEagle3Model(nn.Module):
                  lk_loss_type: Optional[str] = None, kl_scale: float = 1.0, kl_decay: float = 1.0,
                  ploss_decay: float = 0.8):
         super().__init__()
+        if lk_loss_type not in (None, "alpha", "lambda"):
+            raise ValueError(f"Unknown lk loss type: {lk_loss_type}")  # core/lk_loss.py:99
+        if not 1 <= int(length) <= 8:
+            raise ValueError("ttt_length must be in 1..8")
         self.draft_model = draft_model
         self.length = length
         self.attention_backend = attention_backend
         self.lk_loss_type, self.kl_scale, self.kl_decay = lk_loss_type, kl_scale, kl_decay
-        self.engine = Eagle3Engine(draft_model, ttt_length=length, ploss_decay=ploss_decay, lk_loss_type=lk_loss_type,
-                                   kl_scale=kl_scale, kl_decay=kl_decay)
-        self._anchor = nn.Parameter(torch.zeros((), device=self.engine.dev), requires_grad=True)
+        self.ploss_decay = ploss_decay
+        self._engine: Optional[Eagle3Engine] = None
+        dev = next(draft_model.parameters()).device
+        self._anchor = nn.Parameter(torch.zeros((), device=dev), requires_grad=True)
+
+    @property
+    def engine(self) -> Eagle3Engine:
+        """Built on first use: the reference's assembly moves the composite with ``.to(device, dtype)`` AFTER
+        constructing it (algorithms/model_providers.py:268-275); adopting the parameters into the flat buffer any
+        earlier would be undone by that move."""
+        if self._engine is None:
+            self._engine = Eagle3Engine(self.draft_model, ttt_length=self.length, ploss_decay=self.ploss_decay,
+                                        lk_loss_type=self.lk_loss_type, kl_scale=self.kl_scale, kl_decay=self.kl_decay)
+            object.__setattr__(self.draft_model, "_hip_engine", self._engine)   # found by BF16Optimizer(draft_model)
+        return self._engine
+
+    def _apply(self, fn, *a, **kw):
+        if self._engine is not None:
+            before = self._engine.flat.data.data_ptr()
+            super()._apply(fn, *a, **kw)
+            if any(p.data_ptr() != self._engine.flat.data[lo:hi].data_ptr()
+                   for n, p in self._engine.flat.params.items() for lo, hi in [self._engine.flat.slices[n]]):
+                raise RuntimeError("OnlineEagle3Model was moved/cast after its HIP engine adopted the parameters; move the "
+                                   "model to its device and dtype before the first forward / optimizer construction")
+            assert before == self._engine.flat.data.data_ptr()
+            return self
+        return super()._apply(fn, *a, **kw)
 
     def forward(self, input_ids, attention_mask, target=None, loss_mask=None, hidden_states=None, past_key_values=None,
                 position_ids=None, target_hidden_for_compact=None, target_head_weight=None,
@@ -122,7 +150,7 @@ class Eagle3TrainStrategy:
         self.eagle3_model = eagle3_model
         self.target_head = target_head
         self.ploss_decay = ploss_decay
-        if abs(eagle3_model.engine.decay - ploss_decay) > 1e-12:
+        if abs(eagle3_model.ploss_decay - ploss_decay) > 1e-12:
             raise ValueError("OnlineEagle3Model.ploss_decay and the strategy's ploss_decay must agree")
 
     def trainable_module(self) -> nn.Module:
@@ -136,16 +164,18 @@ class Eagle3TrainStrategy:
     def forward_loss(self, batch, ctx=None) -> StepOutput:
         self.validate_batch(batch)
         t = batch.tensors
-        target_repr = getattr(batch, "metadata", {}).get("target_repr", "hidden_state")
+        target_repr = getattr(batch, "metadata", {}).get("target_repr")
         kwargs = {}
         if target_repr == "hidden_state":
             if self.target_head is None:
-                raise ValueError("target_repr='hidden_state' needs the offline target_head")
+                raise ValueError("target_repr='hidden_state' requires a target_head to re-run the lm_head projection")
             input_ids, target_hidden, loss_mask = TargetHead.preprocess(t["input_ids"], t["target"], t["loss_mask"])
             kwargs = dict(target_hidden_for_compact=target_hidden, target_head_weight=self.target_head.fc.weight.data)
             target = None
-        else:  # logits delivered as-is (online capture)
-            input_ids, target, loss_mask = TargetHead.preprocess(t["input_ids"], t["target"], t["loss_mask"])
+        else:
+            # logits (or any other / missing target_repr): online capture has already shifted logits and input ids, so
+            # they are used exactly as delivered (_prepare_eagle_target, strategies/base.py:95-121)
+            input_ids, target, loss_mask = t["input_ids"], t["target"], t["loss_mask"]
         plosses, acceptance_rates, acces, acc_corrects, acc_denoms, metric_losses, metric_loss_denoms = self.eagle3_model(
             input_ids=input_ids, attention_mask=t["attention_mask"], loss_mask=loss_mask, target=target,
             hidden_states=t["hidden_state"], position_ids=t.get("position_ids"), **kwargs)

@@ -40,7 +40,7 @@ class Eagle3Engine:
                  teacher_rows: int = 4096, lk_loss_type: Optional[str] = None, kl_scale: float = 1.0,
                  kl_decay: float = 1.0):
         self.model = model
-        self.cfg: DraftConfig = model.config
+        self.cfg: DraftConfig = getattr(model, "draft_config", None) or model.config   # (the plugin class keeps the HF config in .config)
         c = self.cfg
         if lk_loss_type not in (None, "alpha", "lambda"):
             raise ValueError(f"Unknown lk loss type: {lk_loss_type}")  # core/lk_loss.py:99
@@ -56,7 +56,9 @@ class Eagle3Engine:
         self.teacher_rows = teacher_rows
         cos, sin = rope_tables(c, torch.bfloat16)
         self.cos, self.sin = cos.to(self.dev), sin.to(self.dev)
-        self._bufs: Dict = {}
+        self._arena: Dict[str, torch.Tensor] = {}   # name -> flat storage shared by every batch shape
+        self._views: Dict = {}                       # (B, S) -> dict of views into the arena
+        self._active = None                          # the shape whose constants are currently laid down
         self._wt_version = -1
         self.weights_version = 0          # bumped by the optimizer after every step
         self.micro_in_window = 0          # micro-steps accumulated into flat.grad since the last optimizer step
@@ -78,26 +80,87 @@ class Eagle3Engine:
     def _e(self, *shape, dtype=torch.bfloat16):
         return torch.empty(*shape, dtype=dtype, device=self.dev)
 
+    def _carve(self, name: str, *shape, dtype=torch.bfloat16, invalidate: bool = True) -> torch.Tensor:
+        """A contiguous view of ``shape`` at the start of the named arena entry, which is (re)allocated only when the
+        request exceeds its capacity.  Every batch shape runs inside the SAME storage: variable-length data (the
+        collator pads each batch to its own longest sample) never grows HBM beyond the largest shape seen, and
+        ``reserve(B, S_max)`` makes that a single allocation up front."""
+        n = 1
+        for x in shape:
+            n *= int(x)
+        cur = self._arena.get(name)
+        if cur is None or cur.numel() < n or cur.dtype != dtype:
+            self._arena.pop(name, None)
+            del cur
+            if invalidate:               # cached views of other shapes may alias the freed storage
+                self._views.clear()
+                self._active = None
+            self._arena[name] = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
+        return self._arena[name][:n].view(*shape)
+
+    def reserve(self, B: int, S: int) -> None:
+        """size every buffer for batches up to [B, S] now (one allocation per buffer; smaller batches are views)"""
+        self._buffers(B, S)
+
+    def arena_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._arena.values())
+
     def _buffers(self, B: int, S: int):
         key = (B, S)
-        if key in self._bufs:
-            return self._bufs[key]
+        b = self._views.get(key)
+        if b is None:
+            b = self._build_views(B, S)
+            if key not in self._views:           # a regrowth inside _build_views clears the cache: carve again
+                b = self._build_views(B, S)
+            self._views[key] = b
+        if self._active != key:
+            self._init_constants(b, B, S)
+            self._active = key
+        return b
+
+    def _init_constants(self, b, B: int, S: int) -> None:
+        """the parts of the (shared) storage whose value the kernels rely on without writing it: padded tails of the
+        teacher arrays (eagle3/model.py:445-484: 1/Vd, 0, 0), zero pad rows of the K-concatenated stashes"""
+        Vd, T = self.cfg.draft_vocab_size, self.T
+        b["tp"][:, S:].fill_(1.0 / Vd)
+        b["tsum"][:, S:].fill_(float(torch.full((Vd,), 1.0 / Vd).sum()))
+        for nm in ("pod", "tids", "pm", "lm", "ids"):
+            b[nm].zero_()
+        b["kvlen"].zero_()
+        TN = T * B * S
+        for nm in self._stash_names:
+            if b["Kp"] > TN:
+                b[nm + "_s"][TN:].zero_()
+        if b["Kp"] > TN:
+            b["h_s"][TN:].zero_()
+        b["en2"].zero_()
+        b["hs_s"].zero_()
+        b["dh0_s"].zero_()
+        b["ds2"].zero_()
+        b["metrics"].zero_()
+        b["msum"].zero_()
+        b["lk_logsum"].zero_()
+
+    _stash_names = ("hn", "o", "pn", "act", "ln", "logits", "dh", "dgu", "dh1", "dqkv")
+
+    def _build_views(self, B: int, S: int):
         c, T = self.cfg, self.T
         N, Spad = B * S, S + T
         H, I, hd, nh, nkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
         Vd, Ht3 = c.draft_vocab_size, 3 * c.target_hidden_size
-        f32, i32, i64 = torch.float32, torch.int32, torch.int64
+        f32, i32, i64, bf = torch.float32, torch.int32, torch.int64, torch.bfloat16
+        cv = self._carve
         b = dict(N=N, Spad=Spad)
         # teacher targets (padded tails are constants: 1/Vd, 0, 0 -- eagle3/model.py:445-484)
-        b["tp"] = torch.full((B, Spad, Vd), 1.0 / Vd, dtype=f32, device=self.dev)
-        b["pod"] = torch.zeros(B, Spad, dtype=f32, device=self.dev)
-        b["tsum"] = torch.full((B, Spad), float(torch.full((Vd,), 1.0 / Vd).sum()), dtype=f32, device=self.dev)
-        b["tids"] = torch.zeros(B, Spad, dtype=i64, device=self.dev)
-        b["pm"] = torch.zeros(B, Spad, dtype=i32, device=self.dev)
-        b["lm"] = torch.zeros(B, Spad, dtype=i32, device=self.dev)
-        b["ids"] = torch.zeros(B, Spad, dtype=i64, device=self.dev)
-        b["kvlen"] = torch.zeros(B, dtype=i32, device=self.dev)
-        b["pos"] = torch.zeros(N, dtype=i64, device=self.dev)
+        b["tp"] = cv("tp", B, Spad, Vd, dtype=f32)
+        b["pod"] = cv("pod", B, Spad, dtype=f32)
+        b["tsum"] = cv("tsum", B, Spad, dtype=f32)
+        b["tids"] = cv("tids", B, Spad, dtype=i64)
+        b["pm"] = cv("pm", B, Spad, dtype=i32)
+        b["lm"] = cv("lm", B, Spad, dtype=i32)
+        b["ids"] = cv("ids", B, Spad, dtype=i64)
+        b["kvlen"] = cv("kvlen", B, dtype=i32)
+        b["pos"] = cv("pos", N, dtype=i64)
         # per-step stash
         # Natural-layout stashes [T*N (+ zero pad rows to a multiple of 64), features]: row block k is TTT step k.  They are
         # the operands of the deferred weight-gradient GEMMs (sf_gemm_tn contracts over the token rows of dY and X as
@@ -105,64 +168,61 @@ class Eagle3Engine:
         TNk = T * N
         Kp = (TNk + 63) // 64 * 64
         b["Kp"] = Kp
-        zs = lambda rows, feat: torch.zeros(rows, feat, dtype=torch.bfloat16, device=self.dev)
         slots = lambda t: [t[k * N:(k + 1) * N] for k in range(T)]
-        h_all = zs(N + Kp, H)                           # h[0] | h[1..T] (the lm_head input when norm_output=False)
+        h_all = cv("h_all", N + Kp, H)                  # h[0] | h[1..T] (the lm_head input when norm_output=False)
         b["h_s"] = h_all[N:]
         b["h"] = [h_all[k * N:(k + 1) * N] for k in range(T + 1)]
-        b["h1"] = [self._e(N, H) for _ in range(T)]
-        b["qkv"] = [self._e(N, self.QW) for _ in range(T)]
-        for nm, feat in (("hn", H), ("o", nh * hd), ("pn", H), ("act", I), ("ln", H), ("logits", Vd), ("dh", H),
-                         ("dgu", 2 * I), ("dh1", H), ("dqkv", self.QW)):
-            b[nm + "_s"] = zs(Kp, feat)
+        b["h1"] = [cv(f"h1_{k}", N, H) for k in range(T)]
+        b["qkv"] = [cv(f"qkv_{k}", N, self.QW) for k in range(T)]
+        for nm, feat in zip(self._stash_names, (H, nh * hd, H, I, H, Vd, H, 2 * I, H, self.QW)):
+            b[nm + "_s"] = cv(nm + "_s", Kp, feat)
             b[nm] = slots(b[nm + "_s"])
-        b["lse"] = [self._e(B, nh, S, dtype=f32) for _ in range(T)]
-        b["gu"] = [self._e(N, 2 * I) for _ in range(T)]
-        b["dln"] = [self._e(N, H) for _ in range(T)]
+        b["lse"] = [cv(f"lse_{k}", B, nh, S, dtype=f32) for k in range(T)]
+        b["gu"] = [cv(f"gu_{k}", N, 2 * I) for k in range(T)]
+        b["dln"] = [cv(f"dln_{k}", N, H) for k in range(T)]
         for nm in ("rstd_h", "rstd_p", "rstd_n"):
-            b[nm] = [self._e(N, dtype=f32) for _ in range(T)]
+            b[nm] = [cv(f"{nm}_{k}", N, dtype=f32) for k in range(T)]
         # embedding half of the QKV projection, hoisted out of the TTT loop: step k's token at position s is step 0's
         # token at s + k (eagle3/model.py:428-432), so input_layernorm(embed(.)) and its product with Wqkv[:, :H] are
         # computed once over the padded [B, S+T] positions and re-used by every step (sf_gemm_nt_rowadd)
         b["Np_real"] = B * Spad
         Np = (B * Spad + 31) // 32 * 32       # 2*Np is the K of a wgrad GEMM (64-aligned K -> 256-tile kernels); extra rows stay zero
         b["Np"] = Np
-        b["en2"] = torch.zeros(2 * Np, H, dtype=torch.bfloat16, device=self.dev)   # [en ; en]: pairs with [hi ; lo]
+        b["en2"] = cv("en2", 2 * Np, H)                  # [en ; en]: pairs with [hi ; lo]
         b["en"] = b["en2"][:Np]
-        b["rstd_e1"] = self._e(Np, dtype=f32)
-        b["epart"] = self._e(Np, self.QW, dtype=f32)
-        b["rstd_fc"] = [self._e(N, dtype=f32) for _ in range(3)]
+        b["rstd_e1"] = cv("rstd_e1", Np, dtype=f32)
+        b["epart"] = cv("epart", Np, self.QW, dtype=f32)
+        b["rstd_fc"] = [cv(f"rstd_fc_{i}", N, dtype=f32) for i in range(3)]
         # transient per-step work buffers
         N64 = (N + 63) // 64 * 64
-        b["hs_s"] = zs(N64, Ht3)              # fc input (fc_norm output, or a copy of the hidden states when N % 64 != 0)
+        b["hs_s"] = cv("hs_s", N64, Ht3)      # fc input (fc_norm output, or a copy of the hidden states when N % 64 != 0)
         b["hsn"] = b["hs_s"][:N]
-        b["dh0_s"] = zs(N64, H)
-        b["rows"] = self._e(3, N, dtype=f32)
-        b["metrics"] = torch.zeros(T, 3, dtype=f32, device=self.dev)
-        b["msum"] = torch.zeros(T, dtype=f32, device=self.dev)        # LK: sum of the position mask per TTT step
-        b["lk_logsum"] = torch.zeros(T, dtype=f32, device=self.dev)   # LK: sum_r m_r log(accept_r) per TTT step
+        b["dh0_s"] = cv("dh0_s", N64, H)
+        b["rows"] = cv("rows", 3, N, dtype=f32)
+        b["metrics"] = cv("metrics", T, 3, dtype=f32)
+        b["msum"] = cv("msum", T, dtype=f32)             # LK: sum of the position mask per TTT step
+        b["lk_logsum"] = cv("lk_logsum", T, dtype=f32)   # LK: sum_r m_r log(accept_r) per TTT step
         # backward work buffers
-        b["dh_b"] = [self._e(N, H), self._e(N, H)]   # residual-stream gradient handed from step k to k-1 (ping-pong)
-        b["dact"] = self._e(N, I)
-        b["dpn"] = self._e(N, H)
-        b["do"] = self._e(N, nh * hd)
-        b["dxh"] = self._e(N, H)
+        b["dh_b"] = [cv("dh_b0", N, H), cv("dh_b1", N, H)]   # residual-stream gradient handed from step k to k-1 (ping-pong)
+        b["dact"] = cv("dact", N, I)
+        b["dpn"] = cv("dpn", N, H)
+        b["do"] = cv("do", N, nh * hd)
+        b["dxh"] = cv("dxh", N, H)
         # backward of the hoisted embedding half: fp32 sum over the steps of dqkv re-aligned to token positions, its
         # two-term bf16 expansion (transposed, K-concatenated) for the wgrad, and the matching operand [en^T | en^T]
-        b["dsum"] = self._e(Np, self.QW, dtype=f32)
-        b["ds2"] = zs(2 * Np, self.QW)                     # [hi ; lo] stacked along the contraction
+        b["dsum"] = cv("dsum", Np, self.QW, dtype=f32)
+        b["ds2"] = cv("ds2", 2 * Np, self.QW)              # [hi ; lo] stacked along the contraction
         b["ds_hi"], b["ds_lo"] = b["ds2"][:Np], b["ds2"][Np:]
-        b["dE"] = self._e(Np, H)
-        b["dhs"] = self._e(N, Ht3) if c.fc_norm else None
-        b["delta"] = self._e(B, nh, S, dtype=f32)
-        b["dq_init"] = self._e(N, nh * hd, dtype=f32)
-        b["dk"] = [self._e(N, nkv * hd, dtype=f32) for _ in range(T)]
-        b["dv"] = [self._e(N, nkv * hd, dtype=f32) for _ in range(T)]
-        b["nws"] = self._e(ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)
-        b["nws_e"] = self._e(ops.rmsnorm_bwd_workspace(Np, H), dtype=f32)
+        b["dE"] = cv("dE", Np, H)
+        b["dhs"] = cv("dhs", N, Ht3) if c.fc_norm else None
+        b["delta"] = cv("delta", B, nh, S, dtype=f32)
+        b["dq_init"] = cv("dq_init", N, nh * hd, dtype=f32)
+        b["dk"] = [cv(f"dk_{k}", N, nkv * hd, dtype=f32) for k in range(T)]
+        b["dv"] = [cv(f"dv_{k}", N, nkv * hd, dtype=f32) for k in range(T)]
+        b["nws"] = cv("nws", ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)
+        b["nws_e"] = cv("nws_e", ops.rmsnorm_bwd_workspace(Np, H), dtype=f32)
         # fp32 partials for the 2-way split-K of weight-gradient GEMMs whose tile count fills the CUs badly (down, q|k|v)
-        b["tn_ws"] = self._e(2 * max(H * I, self.QW * H), dtype=f32)
-        self._bufs[key] = b
+        b["tn_ws"] = cv("tn_ws", 2 * max(H * I, self.QW * H), dtype=f32)
         return b
 
     def _refresh_weight_transposes(self):
@@ -201,8 +261,6 @@ class Eagle3Engine:
         H, I, hd, nh, nkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
         Vd, Ht = c.draft_vocab_size, c.target_hidden_size
         eps, scale = c.rms_norm_eps, 1.0 / math.sqrt(hd)
-        if S % 8 != 0:
-            raise ValueError("sequence length must be a multiple of 8 (16-byte rows of the transposed attention images)")
         if S + T > self.cos.shape[0]:
             raise ValueError("sequence length exceeds the RoPE table (max_position_embeddings + 20)")
         loss_mask = loss_mask.reshape(B, S)
@@ -237,12 +295,10 @@ class Eagle3Engine:
             th = target_hidden.reshape(B, S, Ht)
             Vt = target_head_weight.shape[0]
             cb = max(1, self.teacher_rows // S)
-            zkey = ("z", min(cb, B) * S, Vt)
-            if zkey not in self._bufs:
-                self._bufs[zkey] = self._e(min(cb, B) * S, Vt)
+            zbuf = self._carve("teacher_z", min(cb, B) * S, Vt, invalidate=False)   # scratch: no cached view aliases it
             for b0 in range(0, B, cb):
                 nb = min(cb, B - b0)
-                z = self._bufs[zkey][: nb * S]
+                z = zbuf[: nb * S]
                 ops.gemm_nt(th[b0:b0 + nb].reshape(nb * S, Ht), target_head_weight, z)
                 ops.teacher_reduce(z, Vd=Vd, d2t=self._d2t, t2d_u8=self._t2d_u8, loss_mask_pad=b["lm"][b0:b0 + nb], S=S,
                                    Spad=Spad, target_p_pad=b["tp"][b0:b0 + nb], pod_scale_pad=b["pod"][b0:b0 + nb],
@@ -465,6 +521,7 @@ class Eagle3Engine:
         if self.on_bucket_ready is not None:
             self.on_bucket_ready(lo, f.numel)
         self.micro_in_window += 1
+        f.realias_grads()     # an external optimizer's zero_grad(set_to_none=True) must not detach .grad from flat.grad
 
     def bucket_bounds(self):
         """(lo, hi) element ranges of flat.grad in the order the backward sweep hands them to ``on_bucket_ready``"""

@@ -12,9 +12,11 @@ Semantics mirrored from the reference (bit-for-bit on the produced tensors, see 
   ``aux_hidden_state [1,S,3Ht]`` (scripts/prepare_hidden_states.py:446-480, tests/test_runtime/_fixtures.py:131-149)
 * sample normalisation (algorithms/eagle3/data.py:10-27): ``hidden_state <- aux_hidden_state[:max_len]``,
   ``target <- hidden_state[:max_len]``, ``loss_mask[-1] = 0``, ``attention_mask = 1``
-* collation (data/utils.py:106-196): right-pad with zeros to the longest sample of the batch; the padded
-  length is additionally rounded up to a multiple of 8 (16-byte rows for the attention kernels) -- extra
-  right padding is masked out exactly like the collator's own padding
+* collation (data/utils.py:106-196, sp_degree 1): right-pad with zeros to the longest sample of the batch and
+  no further -- ``ploss_k`` is a mean over ALL B*S rows including masked ones (core/loss.py:20,201) and
+  ``metric_loss_denoms`` is B*S (eagle3/model.py:186-190), so any extra padding would rescale every loss.
+  (``pad_multiple`` > 1 exists for experiments only and is NOT the reference's semantics.)
+  tests/golden/ingest_collate.pt pins the batches to the reference's own normaliser + ``DataCollatorWithPadding``.
 * sharding (launch.py:174-239): ``distributed_sampler_indices`` (== torch DistributedSampler), ``drop_last``
   batches (trainer.py:151)
 """
@@ -68,7 +70,7 @@ class _Slot:
 
 class HiddenStateIngest:
     def __init__(self, files: Sequence[str], *, batch_size: int, max_len: int, target_hidden_size: int, device,
-                 dp_rank: int = 0, dp_size: int = 1, seed: int = 0, shuffle: bool = True, pad_multiple: int = 8,
+                 dp_rank: int = 0, dp_size: int = 1, seed: int = 0, shuffle: bool = True, pad_multiple: int = 1,
                  slots: int = 2):
         self.files = list(files)
         self.B, self.max_len, self.Ht = batch_size, max_len, target_hidden_size
@@ -95,6 +97,12 @@ class HiddenStateIngest:
                 n = s[k].shape[1]
                 buf[b, :n].copy_(s[k][0])
         return L
+
+    def collate_indices(self, idxs: Sequence[int]) -> Dict[str, torch.Tensor]:
+        """host-side batch of the given samples (normalise + right-pad), as fresh CPU tensors -- what ``epoch`` stages"""
+        slot = _Slot(len(idxs), self._slots[0].h["input_ids"].shape[1], self.Ht, torch.device("cpu"), pin=False)
+        L = self._fill(slot, list(idxs))
+        return {k: v[:, :L].clone() for k, v in slot.h.items()}
 
     def epoch(self, epoch: int = 0) -> Iterator[TrainBatch]:
         """Yields device-resident batches.  A batch's tensors are views of a staging slot: they stay valid until

@@ -315,8 +315,6 @@ class Eagle3DraftMethods:
         N = B * S
         dev = hidden_states.device
         nh, nkv, hd, eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
-        if S % 8 != 0:
-            raise ValueError("sequence length must be a multiple of 8")
         if attention_mask is None:
             kv_len = torch.full((B,), S, dtype=torch.int32, device=dev)
         elif attention_mask.dim() == 2:
@@ -386,7 +384,8 @@ FLAT_ORDER = [
     "midlayer.self_attn.o_proj.weight",
     "fc.weight",
     "midlayer.hidden_norm.weight", "midlayer.input_layernorm.weight", "midlayer.post_attention_layernorm.weight",
-    "norm.weight", "fc_norm.0.weight", "fc_norm.1.weight", "fc_norm.2.weight",
+    "fc_norm.0.weight", "fc_norm.1.weight", "fc_norm.2.weight",
+    "norm.weight",   # last: with norm_output=False it receives no gradient and is left out of the optimizer range
 ]
 
 
@@ -427,6 +426,12 @@ class FlatParams:
 
     def view(self, name: str) -> torch.Tensor:
         return self.params[name].data
+
+    def realias_grads(self) -> None:
+        for n, p in self.params.items():
+            if p.grad is None or p.grad.data_ptr() != self.grad[self.slices[n][0]:].data_ptr():
+                lo, hi = self.slices[n]
+                p.grad = self.grad[lo:hi].view(p.shape)
 
     def gview(self, name: str) -> torch.Tensor:
         lo, hi = self.slices[name]

@@ -32,32 +32,54 @@ class _WarmupSchedule:
     """LR in effect after ``last_epoch`` scheduler steps of the reference's ``CosineAnnealingWarmupLR`` /
     ``ConstantWarmupLR`` (specforge/lr_scheduler.py:56-147): linear warmup ``(k+1)/W*lr``; the cosine branch
     chains torch's recursive CosineAnnealingLR started one step late, giving
-    ``base*(1+cos(pi*e/T))/(1+cos(pi/T))`` with e = k-W (pinned by tests/golden/optimizer_bf16.pt)."""
+    ``base*(1+cos(pi*e/T))/(1+cos(pi/T))`` with e = k-W (pinned by tests/golden/optimizer_bf16.pt).
+    ``state_dict()`` / ``load_state_dict()`` use the reference scheduler's own layout (outer ``last_epoch`` stops at
+    the end of the warmup, progress after that lives in ``after_scheduler_dict['last_epoch']``; lr_scheduler.py:13-52),
+    so optimizer checkpoints move between the two trainers."""
 
     def __init__(self, kind: str, base_lr: float, total_steps: int, warmup_steps: int, eta_min: float = 0.0):
         if kind not in ("cosine", "constant"):
             raise ValueError(f"unsupported lr_scheduler={kind!r}; expected one of ['constant', 'cosine']")
+        if total_steps <= 0:
+            raise ValueError(f"total_steps must be positive, got {total_steps}")
+        if not 0 <= warmup_steps < total_steps:
+            raise ValueError(f"warmup_steps must be in [0, total_steps), got {warmup_steps} for total_steps={total_steps}")
         self.kind, self.base_lr, self.total_steps, self.warmup_steps, self.eta_min = kind, base_lr, total_steps, warmup_steps, eta_min
         self.last_epoch = 0
 
-    def lr(self) -> float:
-        k, W = self.last_epoch, self.warmup_steps
+    def lr(self, k: Optional[int] = None) -> float:
+        k = self.last_epoch if k is None else k
+        W = self.warmup_steps
         if k < W:
             return (k + 1) / W * self.base_lr
         if self.kind == "constant":
             return self.base_lr
         e, T = k - W, self.total_steps - W
+        if T == 1:   # torch's recursion has its own branch for T_max = 1: 2*base at the first step, then eta_min
+            return self.eta_min + 2 * (self.base_lr - self.eta_min) if e == 0 else self.eta_min
         return self.eta_min + (self.base_lr - self.eta_min) * (1 + math.cos(math.pi * e / T)) / (1 + math.cos(math.pi / T))
 
     def step(self):
         self.last_epoch += 1
 
     def state_dict(self):
-        return dict(last_epoch=self.last_epoch, base_lr=self.base_lr, total_steps=self.total_steps,
-                    warmup_steps=self.warmup_steps, eta_min=self.eta_min, kind=self.kind)
+        k, W = self.last_epoch, self.warmup_steps
+        common = {"_is_initial": False, "_get_lr_called_within_step": False}
+        after = dict(base_lrs=[self.base_lr], last_epoch=max(0, k - W), _step_count=max(0, k - W) + 1,
+                     _last_lr=[self.lr(k) if k > W else self.base_lr], **common)
+        if self.kind == "cosine":
+            after = dict(T_max=self.total_steps - W, eta_min=self.eta_min, **after)
+        return dict(warmup_epochs=W, finished=k >= W, base_lrs=[self.base_lr], last_epoch=min(k, W), _step_count=min(k, W) + 1,
+                    _last_lr=[self.lr(k)], after_scheduler_type="CosineAnnealingLR" if self.kind == "cosine" else "_FlatLR",
+                    after_scheduler_dict=after, **common)
 
     def load_state_dict(self, sd):
-        self.last_epoch = int(sd["last_epoch"])
+        if "warmup_epochs" in sd and int(sd["warmup_epochs"]) != self.warmup_steps:
+            raise ValueError(f"checkpoint scheduler has warmup_epochs={sd['warmup_epochs']} but this run has {self.warmup_steps}")
+        k = int(sd["last_epoch"])
+        if sd.get("finished") and "after_scheduler_dict" in sd:
+            k = self.warmup_steps + int(sd["after_scheduler_dict"]["last_epoch"])
+        self.last_epoch = k
 
 
 class BF16Optimizer:
@@ -66,8 +88,16 @@ class BF16Optimizer:
         if offload_master:
             raise NotImplementedError("fp32 masters live in HBM on MI355X (288 GB); offload_master is not supported")
         self.model = model
-        self.engine = model.engine
+        # ``model`` is the OnlineEagle3Model, or (the reference's convention: Trainer passes optimizer_target=
+        # model.draft_model, training/trainer.py:425) its draft model, which carries a handle to the engine
+        self.engine = model.engine if hasattr(model, "engine") else getattr(model, "_hip_engine", None)
+        if self.engine is None:
+            raise TypeError("BF16Optimizer needs a specforge_amd OnlineEagle3Model (or its draft model after the "
+                            "composite was built): no HIP engine found")
         f = self.engine.flat
+        # parameters that never receive a gradient are skipped like the reference skips ``p.grad is None``
+        # (optimizer.py:139-142): with norm_output=False that is the final norm, laid out last in the flat buffer
+        self.n_active = f.slices["norm.weight"][0] if not self.engine.cfg.norm_output else f.numel
         self.max_grad_norm = float(max_grad_norm)
         self.weight_decay, self.betas, self.eps = float(weight_decay), betas, eps
         self.master = f.data.float().clone()
@@ -88,10 +118,11 @@ class BF16Optimizer:
         f = self.engine.flat
         self.step_count += 1
         lr = self.scheduler.lr()
-        ops.grad_norm(f.grad, self.norm, self._ws, self.grad_prescale)
-        ops.adamw_step(f.grad, self.master, self.exp_avg, self.exp_avg_sq, f.data, self.norm, max_norm=self.max_grad_norm,
-                       lr=lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, wd=self.weight_decay,
-                       step=self.step_count, grad_prescale=self.grad_prescale)
+        n = self.n_active
+        ops.grad_norm(f.grad[:n], self.norm, self._ws, self.grad_prescale)
+        ops.adamw_step(f.grad[:n], self.master[:n], self.exp_avg[:n], self.exp_avg_sq[:n], f.data[:n], self.norm,
+                       max_norm=self.max_grad_norm, lr=lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                       wd=self.weight_decay, step=self.step_count, grad_prescale=self.grad_prescale)
         self.scheduler.step()
         self.engine.end_window()
         self.last_grad_norm = self.norm[0].clone()
@@ -103,10 +134,12 @@ class BF16Optimizer:
         return [flat[f.slices[n][0]:f.slices[n][1]].view(f.params[n].shape) for n in f.module_order]
 
     def state_dict(self) -> Dict[str, Any]:
-        n = len(self.engine.flat.module_order)
+        f = self.engine.flat
+        n = len(f.module_order)
+        active = [f.slices[name][0] < self.n_active for name in f.module_order]   # grad-less params carry no Adam state
         state = {i: dict(step=torch.tensor(float(self.step_count)), exp_avg=m.detach().cpu().clone(),
                          exp_avg_sq=v.detach().cpu().clone())
-                 for i, (m, v) in enumerate(zip(self._per_param(self.exp_avg), self._per_param(self.exp_avg_sq)))}
+                 for i, (m, v) in enumerate(zip(self._per_param(self.exp_avg), self._per_param(self.exp_avg_sq))) if active[i]}
         group = dict(lr=self.scheduler.lr(), betas=tuple(self.betas), eps=self.eps, weight_decay=self.weight_decay,
                      amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
                      initial_lr=self.scheduler.base_lr, params=list(range(n)))
@@ -183,13 +216,19 @@ class HipDPTrainingBackend:
         if use_dp:  # replicas must start identical (DDP broadcasts rank 0's parameters)
             dist.broadcast(model.engine.flat.data, src=0, group=self.group)
         if self._optimizer_factory is not None:
-            self.optimizer = self._optimizer_factory(optimizer_target if optimizer_target is not None else model)
-            self.optimizer.grad_prescale = 1.0 / self.world
+            # the reference's Trainer passes optimizer_target=model.draft_model (training/trainer.py:425)
+            model.engine   # adopt the parameters into the flat buffers before any optimizer clones its masters
+            self.set_optimizer(self._optimizer_factory(optimizer_target if optimizer_target is not None else model))
         return model
 
-    def set_optimizer(self, optimizer: BF16Optimizer) -> None:
+    def set_optimizer(self, optimizer) -> None:
+        """``BF16Optimizer`` of this package (fused; folds DDP's 1/world into its kernels) or any optimizer with the
+        reference's ``step() -> grad_norm`` / ``state_dict`` surface working on the draft's parameters and ``.grad``
+        (e.g. the reference's own ``specforge.optimizer.BF16Optimizer``: slower, per-parameter, but equivalent)."""
         self.optimizer = optimizer
-        optimizer.grad_prescale = 1.0 / self.world
+        self._native_optimizer = isinstance(optimizer, BF16Optimizer)
+        if self._native_optimizer:
+            optimizer.grad_prescale = 1.0 / self.world
 
     def _bucket_ready(self, lo: int, hi: int) -> None:
         if not self._sync_this_backward:
@@ -216,30 +255,52 @@ class HipDPTrainingBackend:
         if self._pending_single:
             dist.all_reduce(self.module.engine.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
             self._pending_single = False
+            self._handles.clear()
+            return True
+        reduced = bool(self._handles)
         for h in self._handles:
             h.wait()
         self._handles.clear()
+        return reduced
 
     def step(self):
-        self.synchronize_gradients()
+        reduced = self.synchronize_gradients()
+        if not getattr(self, "_native_optimizer", True):
+            eng = self.module.engine
+            if self.world > 1 and reduced:
+                eng.flat.grad.mul_(1.0 / self.world)       # DDP averages; a foreign optimizer sees plain mean gradients
+            out = self.optimizer.step()
+            eng.end_window()
+            eng.flat.realias_grads()
+            return out
         return self.optimizer.step()
 
     def state_dict(self) -> dict:
         sd = {k: v.detach().clone() for k, v in self.module.state_dict().items() if not k.startswith("_anchor")}
-        return {"model": sd, "optimizer": self.optimizer.state_dict() if self.optimizer else None,
-                "rng": {"cpu": torch.get_rng_state()}}
+        dev = self.module.engine.dev
+        rng = {"torch": torch.get_rng_state(), "device_type": "cuda" if dev.type == "cuda" else "cpu",   # backend.py:390-412
+               "cuda": torch.cuda.get_rng_state(dev) if dev.type == "cuda" else None, "npu": None}
+        return {"model": sd, "optimizer": self.optimizer.state_dict() if self.optimizer else None, "rng": rng}
 
     def load_state_dict(self, state: dict) -> None:
-        own = self.module.state_dict()
-        with torch.no_grad():
-            for k, v in state["model"].items():
-                own[k].copy_(v)
+        """restores whichever of module weights / optimizer / RNG the state carries (backend.py:352-360)"""
+        if state.get("model") is not None:
+            own = self.module.state_dict()
+            with torch.no_grad():
+                for k, v in state["model"].items():
+                    own[k].copy_(v)
         if self.optimizer is not None and state.get("optimizer") is not None:
             self.optimizer.load_state_dict(state["optimizer"])
-            self.module.engine.flat.data.copy_(self.optimizer.master)
+            if getattr(self, "_native_optimizer", True):
+                n = self.optimizer.n_active
+                self.module.engine.flat.data[:n].copy_(self.optimizer.master[:n])
         self.module.engine.weights_version += 1
-        if state.get("rng") and "cpu" in state["rng"]:
-            torch.set_rng_state(state["rng"]["cpu"])
+        rng = state.get("rng") or {}
+        cpu_state = rng.get("torch", rng.get("cpu"))
+        if cpu_state is not None:
+            torch.set_rng_state(cpu_state)
+        if rng.get("cuda") is not None and self.module.engine.dev.type == "cuda":
+            torch.cuda.set_rng_state(rng["cuda"], self.module.engine.dev)
 
 
 @dataclass

@@ -125,16 +125,101 @@ def test_accumulation_window_and_eval_mode(backend, golden_dir):
 
 
 def test_logits_teacher_path_equals_hidden_state_path(backend, golden_dir):
-    """target_repr == logits (online capture delivers target logits, strategies/base.py:246-268) must give the same
-    step as the streaming hidden-state teacher when the logits are the head's own bf16 output"""
+    """target_repr == logits: online capture has ALREADY shifted logits and input ids, so the strategy uses them exactly
+    as delivered (_prepare_eagle_target, strategies/base.py:95-121).  Feeding the head's own bf16 logits of the shifted
+    hidden state together with the shifted ids must give the same step as the offline hidden-state path (which shifts
+    inside TargetHead.preprocess)."""
     blob = torch.load(os.path.join(golden_dir, "eagle3_tiny_bf16.pt"), weights_only=False)
     cfg, model, eagle, strat = _build(blob, backend)
     eagle.train()
     batch = _batch(blob, backend)
     out_h = strat.forward_loss(batch)
     ids_h = eagle.last_artifacts["target_token_ids"].clone()
+    from specforge_amd.eagle3 import padding_left_shift
+
     t = dict(batch.tensors)
-    t["target"] = torch.nn.functional.linear(t["target"].cpu().to(torch.bfloat16), blob["head_w"].to(torch.bfloat16)).to(backend)
+    t["input_ids"] = padding_left_shift(t["input_ids"])
+    t["target"] = torch.nn.functional.linear(padding_left_shift(t["target"].cpu().to(torch.bfloat16)),
+                                             blob["head_w"].to(torch.bfloat16)).to(backend)
     out_l = strat.forward_loss(TrainBatch(t, {"target_repr": "logits"}))
     assert torch.equal(eagle.last_artifacts["target_token_ids"], ids_h)
     torch.testing.assert_close(torch.stack(out_l.metrics["plosses"]), torch.stack(out_h.metrics["plosses"]), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("B,S,lengths", [(2, 13, [13, 7]), (1, 27, [27])])
+def test_sequence_length_not_a_multiple_of_8(backend, B, S, lengths):
+    """The reference collator right-pads to the longest sample of the batch, whatever that length is
+    (data/utils.py:122-142); ploss_k is a mean over ALL B*S rows (core/loss.py:20,201), so padding S any further
+    would rescale every loss.  One micro-step at odd S vs the pinned oracle in bf16."""
+    kw = dict(hidden_size=64, intermediate_size=96, num_attention_heads=2, num_key_value_heads=1, vocab_size=304,
+              draft_vocab_size=72, head_dim=64, target_hidden_size=48, max_position_embeddings=64, rms_norm_eps=1e-5)
+    oc = O.DraftConfig(**kw)
+    bf = torch.bfloat16
+    params = {k: v.to(bf) for k, v in O.init_params(oc, seed=5).items()}
+    g = torch.Generator().manual_seed(6)
+    for k, v in params.items():
+        if v.dim() == 1:
+            params[k] = (1 + 0.1 * torch.randn(v.shape, generator=g)).to(bf)
+        else:
+            params[k] = (v.float() * 4).to(bf)
+    embed = (torch.randn(304, 64, generator=g) * 0.5).to(bf)
+    head_w = (torch.randn(304, 48, generator=g) * 0.5).to(bf)
+    t2d, d2t = O.make_vocab_mapping(304, 72, seed=3)
+    batch = O.make_batch(oc, B, S, seed=4, dtype=bf, lengths=lengths)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.eagle3_forward(p, oc, embed_weight=embed, target_head_weight=head_w, t2d=t2d, d2t=d2t, input_ids=batch["input_ids"],
+                           attention_mask=batch["attention_mask"], loss_mask=batch["loss_mask"],
+                           hidden_state=batch["hidden_state"], target_hidden=batch["target"], ttt_length=3)
+    ref.loss.backward()
+    model = LlamaForCausalLMEagle3(DraftConfig(**kw), device=backend)
+    sd = dict(params)
+    sd["embed_tokens.weight"], sd["t2d"], sd["d2t"] = embed, t2d, d2t
+    model.load_state_dict(sd)
+    eagle = OnlineEagle3Model(model, length=3).train()
+    strat = Eagle3TrainStrategy(eagle, target_head=TargetHead(head_w.to(backend)))
+    out = strat.forward_loss(TrainBatch(dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
+                                             loss_mask=batch["loss_mask"], hidden_state=batch["hidden_state"].to(backend),
+                                             target=batch["target"].to(backend)), {"target_repr": "hidden_state"}))
+    out.loss.backward()
+    assert torch.equal(eagle.last_artifacts["target_token_ids"].cpu(), ref.target_token_ids)
+    assert torch.stack(out.metrics["metric_loss_denoms"]).cpu().tolist() == [float(B * S)] * 3    # B*S, not a padded count
+    torch.testing.assert_close(torch.stack(out.metrics["acc_denoms"]).cpu(), torch.stack(ref.acc_denoms).float())
+    torch.testing.assert_close(torch.stack(out.metrics["plosses"]).float().cpu(),
+                               torch.stack([x.detach().float() for x in ref.plosses]), rtol=2e-2, atol=2e-2)
+    named = dict(model.named_parameters())
+    worst = {k: float((named[k].grad.float().cpu() - v.grad.float()).abs().max() / v.grad.float().abs().max().clamp_min(1e-8))
+             for k, v in p.items()}
+    assert max(worst.values()) <= 5e-2, worst
+
+
+def test_variable_length_batches_share_one_arena(backend, golden_dir):
+    """the collator pads every batch to its own longest sample, so real data brings a new (B, S)
+    almost every step.  All shapes run inside the storage reserved for the largest one -- HBM does not grow -- and a
+    shape revisited after others gives bit-identical results (the constants it relies on are re-laid on every switch)."""
+    blob = torch.load(os.path.join(golden_dir, "eagle3_tiny_bf16.pt"), weights_only=False)
+    cfg, model, eagle, strat = _build(blob, backend)
+    eagle.train()
+    eng = eagle.engine
+    full = _batch(blob, backend)
+    B, S = full.tensors["input_ids"].shape
+    eng.reserve(B, S)
+
+    def cut(L, nb=B):
+        t = {k: v[:nb, :L].contiguous() for k, v in full.tensors.items()}
+        t["attention_mask"] = t["attention_mask"].clone()
+        return TrainBatch(t, {"target_repr": "hidden_state"})
+
+    def run(batch):
+        eng.micro_in_window = 0
+        out = strat.forward_loss(batch)
+        out.loss.backward()
+        return torch.stack(out.metrics["plosses"]).clone(), eng.flat.grad.clone()
+
+    p0, g0 = run(full)
+    reserved = eng.arena_bytes()       # reserve() + the teacher-logit scratch chunk (sized at the first forward: needs Vt)
+    for L in (S - 3, 9):
+        run(cut(L) if L == 9 else cut(L, nb=1))
+        assert eng.arena_bytes() == reserved, "a smaller batch shape grew the arena"
+    p1, g1 = run(full)
+    assert torch.equal(p0, p1) and torch.equal(g0, g1)
+    assert eng.arena_bytes() == reserved

@@ -29,7 +29,7 @@ def _reference_collate(files, idxs, max_len):
     """normalize_offline_sample + DataCollatorWithPadding semantics, written independently (loops, no slicing tricks)"""
     samples = [torch.load(files[i]) for i in idxs]
     Ls = [min(int(s["input_ids"].shape[0]), max_len) for s in samples]
-    L = (max(Ls) + 7) // 8 * 8
+    L = max(Ls)          # the longest sample of the batch, nothing more (data/utils.py:122-142 at sp_degree 1)
     B = len(samples)
     out = dict(input_ids=torch.zeros(B, L, dtype=torch.int64), attention_mask=torch.zeros(B, L, dtype=torch.int64),
                loss_mask=torch.zeros(B, L, dtype=torch.int64), hidden_state=torch.zeros(B, L, 3 * HT, dtype=torch.bfloat16),
@@ -80,3 +80,23 @@ def test_normalizer_matches_reference_function():
     assert out["hidden_state"].shape == (1, 10, 3 * HT) and out["target"].shape == (1, 10, HT)
     assert out["loss_mask"][0, -1] == 0 and int(out["loss_mask"].sum()) == 9 and int(raw["loss_mask"].sum()) == 12
     assert torch.equal(out["attention_mask"], torch.ones(1, 10, dtype=torch.long))
+
+
+def test_ingest_matches_reference_collator_golden(tmp_path, golden_dir):
+    """tests/golden/ingest_collate.pt was produced by the reference's OWN ``normalize_offline_sample`` +
+    ``DataCollatorWithPadding`` (oracle/gen_fixtures_r2.py): ragged lengths, batches whose longest sample is not a
+    multiple of 8, truncation at max_len -- tensor for tensor, shapes included."""
+    blob = torch.load(os.path.join(golden_dir, "ingest_collate.pt"), weights_only=False)
+    files = []
+    for i, raw in enumerate(blob["raws"]):
+        p = os.path.join(str(tmp_path), f"{i:04d}.ckpt")
+        torch.save(raw, p)
+        files.append(p)
+    ing = HiddenStateIngest(files, batch_size=4, max_len=blob["max_len"], target_hidden_size=blob["hidden"], device="cpu")
+    for g, want in zip(blob["groups"], blob["batches"]):
+        got = ing.collate_indices(g)
+        assert set(got) == set(want)
+        for k, v in want.items():
+            assert got[k].shape == v.shape and got[k].dtype == v.dtype, (k, got[k].shape, v.shape)
+            assert torch.equal(got[k], v), k
+    assert any(b["input_ids"].shape[1] % 8 for b in blob["batches"])   # the fixture does exercise unaligned lengths

@@ -1,0 +1,206 @@
+"""The HIP path driven by the REFERENCE's own code (build container only: needs /root/reference; skipped elsewhere).
+
+* b1: ``AutoDraftModel.from_config`` constructs the registered HIP draft class; it IS an ``Eagle3DraftModel``; state
+  dicts are key-for-key (order included) interchangeable with the reference's ``LlamaForCausalLMEagle3``; its four
+  abstract methods agree with the reference class's own methods on the same weights.
+* a18 / N1 / N5: the reference ``Trainer`` (``build_offline_runtime`` -> ``Trainer.fit()``: its data plane, collator,
+  ``TrainerCore``, ``_reduce_eagle3_metrics``, checkpoint manager) runs the HIP strategy + backend + fused optimizer
+  over feature files and logs, step for step, the values the PURE reference run logged on the same files
+  (tests/golden/loss_curve_tiny.pt), mirroring tests/test_runtime/test_equiv_offline_eagle3.py:55-102.
+* N1 / N2: ``specforge train``'s own path -- ``load_config`` -> ``resolve_run(cfg, registry=...)`` -> ``cli._train``
+  (cli.py:113, application/composition.py:42-57) -- with the SAME run YAML and draft-config JSON as a reference run,
+  then ``export_to_sglang`` (export/to_sglang.py:57-88) on the checkpoint it wrote and a strict reload into the
+  reference's ``LlamaForCausalLMEagle3``.
+The kernels run under the SIMT interpreter here (no GPU in the build container); the C-ABI calls are the product's.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import ref_harness as RH
+
+pytestmark = pytest.mark.skipif(not RH.available(), reason="needs the reference checkout (/root/reference): build container only")
+
+
+@pytest.fixture(scope="module")
+def ref(emu_lib_path):
+    RH.setup()
+    RH.init_single_rank(29583)
+    from specforge_amd import _lib
+    from specforge_amd import reference_plugin as RP
+
+    _lib._inject_library_for_tests(emu_lib_path)
+    yield RP
+    RP.uninstall()
+    _lib._inject_library_for_tests(None)
+
+
+def _write_run_dir(work, blob, arch):
+    from safetensors.torch import save_file
+
+    dc = dict(blob["draft_config"], architectures=[arch])
+    dj = os.path.join(work, "draft.json")
+    json.dump(dc, open(dj, "w"))
+    feat = os.path.join(work, "features")
+    os.makedirs(feat)
+    for i, raw in enumerate(blob["raws"]):
+        torch.save(raw, os.path.join(feat, f"{i:04d}.ckpt"))
+    td = os.path.join(work, "target")
+    os.makedirs(td)
+    H, V = dc["hidden_size"], dc["vocab_size"]
+    json.dump({"architectures": ["LlamaForCausalLM"], "model_type": "llama", "hidden_size": H, "vocab_size": V,
+               "num_hidden_layers": 1, "num_attention_heads": 4, "intermediate_size": 128}, open(os.path.join(td, "config.json"), "w"))
+    w = {"lm_head.weight": blob["head_w"].float().contiguous(),
+         "model.embed_tokens.weight": blob["init_state"]["embed_tokens.weight"].float().contiguous()}
+    save_file(w, os.path.join(td, "model.safetensors"))
+    json.dump({"metadata": {}, "weight_map": {k: "model.safetensors" for k in w}},
+              open(os.path.join(td, "model.safetensors.index.json"), "w"))
+    vp = os.path.join(work, "vm.pt")
+    torch.save({"t2d": blob["t2d"], "d2t": blob["d2t"]}, vp)
+    return dj, feat, td, vp
+
+
+def test_draft_seam_is_the_reference_abc(ref, golden_dir, tmp_path):
+    from specforge.modeling.auto import AutoDraftModel, AutoDraftModelConfig
+    from specforge.modeling.draft.base import Eagle3DraftModel
+    from specforge.modeling.draft.llama3_eagle import LlamaForCausalLMEagle3 as RefDraft
+
+    blob = torch.load(os.path.join(golden_dir, "loss_curve_tiny.pt"), weights_only=False)
+    ref.draft_class()
+    dj, feat, td, vp = _write_run_dir(str(tmp_path), blob, ref.DRAFT_ARCHITECTURE)
+    hip = AutoDraftModel.from_config(AutoDraftModelConfig.from_file(dj), attention_backend="sdpa", torch_dtype=torch.bfloat16)
+    assert isinstance(hip, Eagle3DraftModel) and type(hip).__name__ == ref.DRAFT_ARCHITECTURE
+    rdj = os.path.join(str(tmp_path), "draft_ref.json")
+    json.dump(blob["draft_config"], open(rdj, "w"))
+    rm = AutoDraftModel.from_config(AutoDraftModelConfig.from_file(rdj), attention_backend="sdpa", torch_dtype=torch.bfloat16)
+    assert isinstance(rm, RefDraft)
+    assert list(hip.state_dict()) == list(rm.state_dict())               # names AND order
+    rm.load_state_dict(blob["init_state"], strict=True)
+    hip.load_state_dict(rm.state_dict(), strict=True)                     # reference -> HIP
+    rm.load_state_dict(hip.state_dict(), strict=True)                     # HIP -> reference
+    hip.load_vocab_mapping(vp)
+    hip.load_embedding(td, embedding_key="model.embed_tokens.weight")     # base.py:135 / :193
+    assert hip.vocab_mapping_loaded and torch.equal(hip.t2d, blob["t2d"]) and torch.equal(hip.d2t, blob["d2t"])
+    assert torch.equal(hip.embed_tokens.weight, blob["init_state"]["embed_tokens.weight"])
+    hip.freeze_embedding()
+    assert not hip.embed_tokens.weight.requires_grad
+    # the four abstract methods vs the reference class's own (llama3_eagle.py:1702-1798), two TTT steps
+    b = blob["batches"][0]
+    B, S = b["input_ids"].shape
+    close = lambda a, c: torch.testing.assert_close(a.float(), c.float(), rtol=2e-2, atol=2e-2)
+    with torch.no_grad():
+        assert torch.equal(hip.embed_input_ids(b["input_ids"]), rm.embed_input_ids(b["input_ids"]))
+        h_h, h_r = hip.project_hidden_states(b["hidden_state"]), rm.project_hidden_states(b["hidden_state"])
+        close(h_h, h_r)
+        mask4 = rm.prepare_decoder_attention_mask(attention_mask=b["attention_mask"], hidden_states=h_r, batch_size=B,
+                                                  seq_length=S, past_key_values_length=0)
+        pos = torch.arange(S).unsqueeze(0)
+        ch, cr = [[], []], [[], []]
+        ids = b["input_ids"]
+        for step in range(2):
+            e = rm.embed_input_ids(ids)
+            h_h = hip.backbone(input_embeds=e, hidden_states=h_h, cache_hidden=ch, attention_mask=mask4, position_ids=pos)
+            h_r = rm.backbone(input_embeds=e, hidden_states=h_r, cache_hidden=cr, attention_mask=mask4, position_ids=pos,
+                              use_cache=True)
+            valid = b["attention_mask"].bool()
+            close(h_h[valid], h_r[valid])
+            close(hip.compute_logits(h_h)[valid], rm.compute_logits(h_r)[valid])
+            ids = torch.cat((ids[:, 1:], torch.zeros_like(ids[:, -1:])), dim=1)
+            h_h = h_r.clone()          # both continue from the same hidden state: errors do not compound over steps
+        assert len(ch[0]) == 2 and len(ch[1]) == 2
+
+
+def test_reference_trainer_fit_reproduces_the_reference_run(ref, golden_dir, tmp_path):
+    """reference Trainer + data plane + HIP strategy/backend/optimizer == the pure reference run, step for step"""
+    from specforge.launch import build_offline_runtime
+    from specforge.modeling.auto import AutoDraftModel, AutoDraftModelConfig
+    from specforge.modeling.target.target_head import TargetHead
+    from specforge_amd.eagle3 import OnlineEagle3Model
+    from specforge_amd.training import BF16Optimizer
+
+    blob = torch.load(os.path.join(golden_dir, "loss_curve_tiny.pt"), weights_only=False)
+    c = blob["cfg"]
+    dj, feat, td, vp = _write_run_dir(str(tmp_path), blob, ref.DRAFT_ARCHITECTURE)
+    ref.install()
+    draft = AutoDraftModel.from_config(AutoDraftModelConfig.from_file(dj), attention_backend="sdpa", torch_dtype=torch.bfloat16)
+    draft.load_state_dict(blob["init_state"], strict=True)
+    draft.freeze_embedding()
+    head = TargetHead.from_pretrained(td, lm_head_key="lm_head.weight")
+    model = OnlineEagle3Model(draft_model=draft, length=c["ttt"], attention_backend="sdpa")
+    logged = []
+    nsteps = 4
+    trainer = build_offline_runtime(
+        algorithm=ref.registry().resolve(ref.ALGORITHM_NAME), hidden_states_path=feat, draft_model=model, target_head=head,
+        optimizer_factory=lambda m: BF16Optimizer(m, lr=c["lr"], max_grad_norm=c["max_grad_norm"], warmup_ratio=c["warmup_ratio"],
+                                                  total_steps=c["steps"]),
+        run_id="curve-hip", output_dir=os.path.join(str(tmp_path), "out"), ttt_length=c["ttt"], max_len=c["max_len"],
+        batch_size=c["batch_size"], max_steps=nsteps, total_steps=c["steps"], num_epochs=2, seed=c["seed"],
+        logger=lambda m, s: logged.append((s, m)), log_interval=1)
+    assert type(trainer.backend).__name__ == "_HipBackendForTrainer"
+    assert trainer.fit() == nsteps
+    assert [s for s, _ in logged] == list(range(1, nsteps + 1))
+    for (s, got), want in zip(logged, blob["logged"]):
+        assert {"loss", "acc", "ploss_0", "acc_0", "acceptance_rate_0", "grad_norm", "lr"} <= set(got)   # _reduce_eagle3_metrics ran
+        for k, v in want.items():
+            tol = 1e-9 if k == "lr" else 2e-2 * max(1.0, abs(v))
+            assert abs(got[k] - v) <= tol, (s, k, got[k], v)
+    # the checkpoint the reference's manager wrote: reference key set, no embedding, strategy name of the algorithm
+    state = torch.load(os.path.join(str(tmp_path), "out", "curve-hip-latest", "training_state.pt"), weights_only=False)
+    assert state["strategy"] == ref.ALGORITHM_NAME and state["global_step"] == nsteps
+    want_keys = [k for k in blob["init_state"] if "embed" not in k]
+    assert sorted(state["draft_state_dict"]) == sorted(want_keys)
+    assert "replicated_optimizer_state" in state and "fp32_params" in state["replicated_optimizer_state"]
+
+
+def test_cli_train_path_and_sglang_export_round_trip(ref, golden_dir, tmp_path):
+    """the SAME run YAML / draft JSON a reference run would use (strategy ``eagle3``, ``LlamaForCausalLMEagle3``)"""
+    import yaml
+
+    from specforge import cli
+    from specforge.application.composition import resolve_run
+    from specforge.config import load_config
+    from specforge.export.to_sglang import export_to_sglang
+    from specforge.modeling.auto import AutoDraftModel, AutoDraftModelConfig
+
+    blob = torch.load(os.path.join(golden_dir, "loss_curve_tiny.pt"), weights_only=False)
+    work = str(tmp_path)
+    dj, feat, td, vp = _write_run_dir(work, blob, "LlamaForCausalLMEagle3")
+    run = dict(model=dict(target_model_path=td, draft_model_config=dj, embedding_key="model.embed_tokens.weight",
+                          vocab_mapping_path=vp, torch_dtype="bfloat16"),
+               data=dict(hidden_states_path=feat, max_length=24),
+               training=dict(strategy="eagle3", num_epochs=1, batch_size=2, learning_rate=1e-3, max_grad_norm=0.5, ttt_length=3,
+                             attention_backend="sdpa", save_interval=0, log_interval=1, dist_timeout=5, seed=0, max_steps=2),
+               run_id="hipcli", output_dir=os.path.join(work, "out"),
+               deployment=dict(mode="local_colocated", trainer=dict(nnodes=1, nproc_per_node=1)))
+    yp = os.path.join(work, "run.yaml")
+    yaml.safe_dump(run, open(yp, "w"))
+    ref.install(override=True)
+    try:
+        resolved = resolve_run(load_config(yp), registry=ref.registry(override=True))
+        assert resolved.algorithm.name == "eagle3"
+        import torch.distributed as dist
+
+        if dist.is_initialized():          # cli._train owns init/destroy of the process group
+            dist.destroy_process_group()
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            os.environ.pop(k, None)
+        assert cli._train(resolved) == 2
+    finally:
+        ref.uninstall()
+        RH.init_single_rank(29585)
+    ckpt = os.path.join(work, "out")
+    state = torch.load(os.path.join(ckpt, "hipcli-latest", "training_state.pt"), weights_only=False)
+    assert state["strategy"] == "eagle3"
+    out = export_to_sglang(ckpt, dj, os.path.join(work, "sglang"))       # materialises the REFERENCE class (plugin uninstalled)
+    from safetensors.torch import load_file
+
+    sd = load_file(os.path.join(out, "model.safetensors"))
+    assert {"fc.weight", "norm.weight", "lm_head.weight", "t2d", "d2t"} <= set(sd) and not any("embed" in k for k in sd)
+    for k, v in state["draft_state_dict"].items():
+        assert torch.equal(sd[k], v), k
+    rm = AutoDraftModel.from_config(AutoDraftModelConfig.from_file(dj), torch_dtype=torch.bfloat16)
+    missing, unexpected = rm.load_state_dict(sd, strict=False)
+    assert not unexpected and all("embed" in k for k in missing)
+    assert json.load(open(os.path.join(out, "config.json")))["architectures"] == ["LlamaForCausalLMEagle3"]
