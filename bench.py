@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seq", type=int, default=512)
     ap.add_argument("--no-dense-mask", action="store_true", help="skip the dense-position-mask variant")
+    ap.add_argument("--dp-single", action="store_true", help="one gradient all-reduce after the sweep instead of overlapped buckets (A/B)")
+    ap.add_argument("--force-dp", action="store_true", help="run the gradient collectives even at world size 1 (RCCL path on a 1-GPU box)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (launcher smoke test)")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: all ranks on cuda:0 (with --dist-backend gloo)")
     args = ap.parse_args()
@@ -170,7 +172,8 @@ def main():
     eagle = OnlineEagle3Model(model, length=args.ttt).train()
     head = TargetHead((torch.randn(cfg["vocab_size"], cfg["target_hidden_size"], device=dev) * 0.02).to(torch.bfloat16))
     strat = Eagle3TrainStrategy(eagle, target_head=head)
-    backend = HipDPTrainingBackend(optimizer_factory=lambda m: BF16Optimizer(m, lr=1e-4, max_grad_norm=0.5, total_steps=10_000))
+    backend = HipDPTrainingBackend(optimizer_factory=lambda m: BF16Optimizer(m, lr=1e-4, max_grad_norm=0.5, total_steps=10_000),
+                                   single_collective=args.dp_single, force_collectives=args.force_dp)
     backend.prepare_model(eagle)
     batches = [TrainBatch(make_batch(cfg, B, S, dev, 100 + rank * 10 + i), {"target_repr": "hidden_state"}) for i in range(2)]
 

@@ -29,7 +29,7 @@ extern "C" {
 #define SF_BF16 0
 #define SF_F32 1
 
-#define SF_ABI_VERSION 1
+#define SF_ABI_VERSION 2
 
 int sf_abi_version(void);
 /* 1 if this library is the SIMT-emulator test build, 0 for the gfx950 product build */
@@ -49,10 +49,11 @@ int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_
  * dW = dY^T . X on the tensors exactly as the sweep produced them -- replaces autograd's `grad_output.t() @ input`
  * of every linear layer on the path (llama3_eagle.py:555-566,1513-1515,1674-1693) without materialising a
  * transposed operand.  K % 64 == 0 (pad the token dimension with zero rows), M, N multiples of 8.
- * workspace (optional, fp32, >= 2*M*N floats): lets the launcher split K in two when the tile count would leave the
- * last round of CUs half empty; the partials are reduced in a fixed order (deterministic). */
+ * workspace (optional, fp32, >= 2*M*N floats) + ksplit: 0 = the launcher splits K in two when the tile count would
+ * leave the last round of CUs half empty (and the workspace is there), 1 = never split, 2 = always split (error if the
+ * shape / workspace do not allow it); the partials are reduced in a fixed order (deterministic). */
 int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N, int K,
-               float alpha, float beta, float* workspace, long workspace_floats, void* stream);
+               float alpha, float beta, float* workspace, long workspace_floats, int ksplit, void* stream);
 
 /* Same GEMM with an fp32 row-mapped addend joined to the accumulator before the single rounding:
  *   C[r][n] = round( alpha * (A.B^T)[r][n] + Cadd[(r / S) * Spad + r % S + off][n] )

@@ -28,6 +28,8 @@ def _deps():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(ROOT, "include", "specforge_amd.h"))
     hdrs.append(os.path.join(ROOT, "tests", "emu", "sf_emu.h"))
+    exp = os.path.join(ROOT, "tools", "experiments")
+    hdrs += [os.path.join(exp, f) for f in os.listdir(exp) if f.endswith(".inc")]
     return [h for h in hdrs if os.path.exists(h)]
 
 
@@ -75,6 +77,19 @@ def build_hip(force=False, verbose=False):
     return lib
 
 
+def build_ablate(force=False, verbose=False):
+    """TOOLS ONLY: hipcc -DSF_ABLATE -> tools/experiments/libsfhip_ablate.so -- the measured-and-rejected kernel variants
+    and the SF_* environment knobs that select them (A/B timing; some give wrong results by design).  Never loaded by the
+    package; tools inject it with ``_lib._inject_library_for_tests``."""
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-I", CSRC, "-DSF_ABLATE",
+             "-Wno-unused-result", "-ffp-contract=fast"]
+    lib = _build(os.path.join(ROOT, "tools", "experiments", "libsfhip_ablate.so"), os.path.join(ROOT, "build", "ablate"),
+                 [HIPCC] + flags, [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"], force)
+    if verbose:
+        print("built", lib)
+    return lib
+
+
 def build_emu(force=False, asan=False, verbose=False):
     """host clang++ -DSF_EMU -> tests/emu/libsfhip_emu.so (SIMT interpreter build)"""
     flags = ["-DSF_EMU", "-O2", "-g", "-std=c++17", "-fPIC", "-x", "c++", "-I", CSRC,
@@ -98,5 +113,7 @@ if __name__ == "__main__":
         build_hip(force="--force" in what, verbose=True)
     if "emu" in what:
         build_emu(force="--force" in what, verbose=True)
+    if "ablate" in what:
+        build_ablate(force="--force" in what, verbose=True)
     if "asan" in what:
         build_emu(force="--force" in what, asan=True, verbose=True)

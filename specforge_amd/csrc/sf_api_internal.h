@@ -26,3 +26,18 @@ static inline int sf_check_launch(const char* what) {
     }
     return SF_OK;
 }
+
+// Tuning knobs.  The PRODUCT library reads no environment variable: every knob is the compile-time default (the name
+// is dropped by the preprocessor, so `strings libsfhip.so` shows none).  Only the tools build (-DSF_ABLATE,
+// `python specforge_amd/build.py ablate` -> tools/experiments/libsfhip_ablate.so) turns them into getenv lookups for
+// A/B timing of measured-and-rejected variants.
+#ifdef SF_ABLATE
+#include <stdlib.h>
+static inline int sf_knob_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#define sf_knob(name, dflt) sf_knob_env(name, dflt)
+#else
+#define sf_knob(name, dflt) (dflt)
+#endif

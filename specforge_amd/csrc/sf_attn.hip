@@ -31,6 +31,12 @@ static const sf_bf16 sf_zero16a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 __device__ const sf_bf16 sf_zero16a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
+#ifdef SF_ABLATE   // profiling experiments of the tools build: 1 = stage tile 0 only, 2 = skip the MFMA / softmax work
+#define SF_ATTN_DBG(p, bit) ((p).dbg & (bit))
+#else
+#define SF_ATTN_DBG(p, bit) false
+#endif
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kNegBig = -1.0e30f;
@@ -180,7 +186,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
         const int key0 = kt * 64;
         sf_wait_vm0();
         sf_syncthreads();  // tile kt landed for everyone; buffer (kt+1)&1 is no longer being read
-        if (kt + 1 < ntiles && !(p.dbg & 1)) {
+        if (kt + 1 < ntiles && !SF_ATTN_DBG(p, 1)) {
             char* nb = smem + ((kt + 1) & 1) * TILE;
             stage_rows64<HD, NW>(nb, kbase, p.ldk, key0 + 64, S, wave, lane);
             stage_rows64<HD, NW>(nb + 64 * HD * 2, vbase, p.ldk, key0 + 64, S, wave, lane);
@@ -188,7 +194,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
         const char* lds_k = smem + (kt & 1) * TILE;
         const char* lds_v = lds_k + 64 * HD * 2;
         if (key0 > qw0 + 31) continue;  // whole tile above this wave's diagonal (wave-uniform)
-        if (p.dbg & 2) continue;
+        if (SF_ATTN_DBG(p, 2)) continue;
         const bool need_mask = (key0 + 63 > qw0) || (key0 + 63 >= kvlen);
         sf_v16f s[2];
 #pragma unroll
@@ -713,7 +719,7 @@ constexpr int kAttnWaves = 8;  // waves per workgroup of the three MFMA attentio
 // SF_ATTN_WAVES=8 pins the 8-wave form.
 static int sf_attn_waves() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("SF_ATTN_WAVES"); v = e ? atoi(e) : 4; }
+    if (v < 0) v = sf_knob("SF_ATTN_WAVES", 4);
     return v;
 }
 
@@ -747,7 +753,7 @@ extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, co
     p.ndiag = ndiag; p.kv_len = kv_len;
     p.o = (sf_bf16*)o; p.ldo = ldo; p.lse = lse;
     p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.scale = scale;
-    { const char* e = getenv("SF_ATTN_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = sf_knob("SF_ATTN_DBG", 0);
     if (sf_attn_waves() == 4) {
         constexpr int NW = 4;
         dim3 grid((unsigned)(((S + NW * 32 - 1) / (NW * 32)) * nh * B));
@@ -843,7 +849,7 @@ extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long l
     AttnBwdArgs p;
     fill_bwd_args(p, q, ldq, dout, lddo, k0, ldk, v0, ldv, kv_len, lse, delta, nullptr, nullptr, 0, dk,
                   dv, lddk, B, S, nh, nkv, scale);
-    static const int dkv_waves = [] { const char* e = getenv("SF_ATTN_DKV_WAVES"); return e ? atoi(e) : kAttnWaves; }();
+    static const int dkv_waves = sf_knob("SF_ATTN_DKV_WAVES", kAttnWaves);
     if (dkv_waves == 4) {
         constexpr int NW = 4;
         dim3 grid((unsigned)(((S + NW * 16 - 1) / (NW * 16)) * nkv * B));

@@ -128,12 +128,9 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) gemm_nt_kernel(GemmArgs p) {
 
 int sf_gemm_nt_256_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, void* stream);
 int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, void* stream);
-// tuning knob for A/B measurements only: SF_GEMM_TILE=128 pins the 128x128 kernel
+// tools build only (-DSF_ABLATE): SF_GEMM_TILE=128 pins the 128x128 kernel
 static bool sf_gemm_use_256() {
-    static const bool use = [] {
-        const char* e = getenv("SF_GEMM_TILE");
-        return !(e && atoi(e) == 128);
-    }();
+    static const bool use = sf_knob("SF_GEMM_TILE", 256) != 128;
     return use;
 }
 
@@ -142,8 +139,8 @@ static int sf_gemm_dispatch(const void* A, long lda, const void* B, long ldb, in
     const int M = e.M, N = e.N;
     // chip-filling shapes (>= one 256x256 tile per CU, long K: every GEMM of the training step) take the 4-wave
     // software-pipelined kernel; smaller ones the 8-wave ping-pong kernel, whose prologue/epilogue is shorter.
-    // SF_GEMM_W4=0 pins the ping-pong kernel, =1 forces the 4-wave kernel for every 256-tile shape (A/B knob).
-    static const int w4_mode = [] { const char* en = getenv("SF_GEMM_W4"); return en ? atoi(en) : -1; }();
+    // (tools build: SF_GEMM_W4=0 pins the ping-pong kernel, =1 forces the 4-wave kernel for every 256-tile shape)
+    static const int w4_mode = sf_knob("SF_GEMM_W4", -1);
     const bool big = (long)((M + 255) / 256) * ((N + 255) / 256) >= 256 && K >= 512;
     const bool w4_ok = !(e.Cadd && e.alpha != 1.0f);   // its addend path starts the accumulators from Cadd
     if (K % 64 == 0 && K >= 64 && M >= 192 && N >= 192 && sf_gemm_use_256() && w4_ok &&

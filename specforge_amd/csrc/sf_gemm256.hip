@@ -204,271 +204,9 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256_kernel(Gemm256Args p) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// v2: same tile / wave geometry and MFMA order, but the DMA half-tiles are cut along the READ sets
-// instead of along the wave groups, so that every LDS slot dies early and can be restaged with a
-// long lead:
-//   slot 0 "A-mh0" = tile rows {g*128 + 0..63},  slot 1 "A-mh1" = rows {g*128 + 64..127}   (g = wave group)
-//   slot 2 "B-nh0" = tile cols {c*64 + 0..31},   slot 3 "B-nh1" = cols {c*64 + 32..63}     (c = wave column)
-//   reads:  p0 A-mh0 + B-nh0 (kept in registers for p3), p1 B-nh1, p2 A-mh1, p3 none
-//   deaths: A-mh0, B-nh0 after p0; B-nh1 after p1; A-mh1 after p2
-//   issue (K-tile t): p0 B-nh1(t+1), p1 A-mh1(t+1), p2 A-mh0(t+2), p3 B-nh0(t+2)
-// Every restage is >= 2 phases after the slot's last ds_read (WAR holds without draining lgkmcnt before
-// the barrier) and >= 5 phases (~1.5-2k cycles) before its first read, vs 2 phases for the A halves in
-// v1.  One `vmcnt(8)` per phase keeps exactly the four newest half-tiles in flight; what phase q reads
-// was retired by the wait of phase q-1, i.e. one full barrier pair earlier (RAW rule for two groups
-// staggered by one barrier).
-template <int OUT_F32, int VAR>
-SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256v2_kernel(Gemm256Args p) {
-    SF_DYN_SMEM(smem);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
-    const int wr = wave >> 2, wc = wave & 3;
-    int tm, tn;
-    tile_coords256((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
-    const int m0 = tm * TM, n0 = tn * TN;
-    const int nkt = p.K / TK;
-
-    // ---- DMA sources: this wave stages pieces 2*wave, 2*wave+1 (8 LDS rows x 128 B each) of every slot;
-    // running pointers, advanced by one K-tile per issue (every slot is issued once per K-tile, in order)
-    const int srow = lane >> 3;
-    const int slc = (lane & 7) ^ (srow & 7);
-    const sf_bf16* src[4][2];
-    int inc[4][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = (2 * wave + j) * 8 + srow;                       // LDS row inside the slot
-            const int ra = (r >> 6) * 128 + h * 64 + (r & 63);             // A tile row
-            const int rb = (r >> 5) * 64 + h * 32 + (r & 31);              // B tile row (output column)
-            const bool okA = m0 + ra < p.M, okB = n0 + rb < p.N;
-            src[h][j] = okA ? p.A + (long)(m0 + ra) * p.lda + slc * 8 : sf_zero16b;
-            src[2 + h][j] = okB ? p.B + (long)(n0 + rb) * p.ldb + slc * 8 : sf_zero16b;
-            inc[h][j] = okA ? TK : 0;
-            inc[2 + h][j] = okB ? TK : 0;
-        }
-    auto issue = [&](int slot, int kt) {  // next K-tile of `slot` into buffer kt&1
-        char* dst = smem + (kt & 1) * kBufBytes + slot * kHalfBytes + (2 * wave) * 1024;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            sf_glds16(src[slot][j], dst + j * 1024);
-            src[slot][j] += inc[slot][j];
-        }
-    };
-
-    const int frow = lane & 15;
-    const int swz0 = (((lane >> 4)) ^ (lane & 7)) << 4;
-    const int swz1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
-    const int a_off = (wr * 64 + frow) * 128;                     // + mh*kHalfBytes + mt*16*128
-    const int b_off = 2 * kHalfBytes + (wc * 32 + frow) * 128;    // + nh*kHalfBytes + nt*16*128
-
-    sf_v4f acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
-    sf_v8s a[4][2], b0[2][2], b1[2][2];
-
-    // ---- prologue: K-tile 0 complete + the two slots of K-tile 1 that steady state issues a tile early
-    issue(0, 0); issue(2, 0); issue(3, 0); issue(1, 0);
-    if (nkt > 1) { issue(0, 1); issue(2, 1); }
-    sf_wait_vm0();
-    raw_barrier();
-    if (wr == 1) raw_barrier();  // stagger: group 1 runs one barrier behind group 0
-
-    for (int t = 0; t < nkt; ++t) {
-        const char* buf = smem + (t & 1) * kBufBytes;
-        const bool steady = t + 2 < nkt;
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            // ------------------------------------------------ load segment
-            if (ph == 0 && !((VAR & 2) && t > 0)) {
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    b0[nt][0] = *reinterpret_cast<const sf_v8s*>(buf + b_off + (nt * 16) * 128 + swz0);
-                    b0[nt][1] = *reinterpret_cast<const sf_v8s*>(buf + b_off + (nt * 16) * 128 + swz1);
-                }
-            }
-            if (ph == 1 && !((VAR & 2) && t > 0)) {
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    b1[nt][0] = *reinterpret_cast<const sf_v8s*>(buf + b_off + kHalfBytes + (nt * 16) * 128 + swz0);
-                    b1[nt][1] = *reinterpret_cast<const sf_v8s*>(buf + b_off + kHalfBytes + (nt * 16) * 128 + swz1);
-                }
-            }
-            if ((ph == 0 || ph == 2) && !((VAR & 2) && t > 0)) {
-                const int mh = ph >> 1;
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    a[mt][0] = *reinterpret_cast<const sf_v8s*>(buf + mh * kHalfBytes + a_off + (mt * 16) * 128 + swz0);
-                    a[mt][1] = *reinterpret_cast<const sf_v8s*>(buf + mh * kHalfBytes + a_off + (mt * 16) * 128 + swz1);
-                }
-            }
-            if (!(VAR & 4)) {
-                if (ph == 0 && t + 1 < nkt) issue(3, t + 1);
-                if (ph == 1 && t + 1 < nkt) issue(1, t + 1);
-                if (ph == 2 && steady) issue(0, t + 2);
-                if (ph == 3 && steady) issue(2, t + 2);
-                if (steady) wait_vm8(); else sf_wait_vm0();
-            }
-            if (!(VAR & 1)) wait_lgkm0();
-            raw_barrier();
-            sched_fence();
-            // ------------------------------------------------ compute segment: one 64x32 quadrant
-            const int mh = (ph >= 2) ? 1 : 0;
-            const int nh = (ph == 1 || ph == 2) ? 1 : 0;
-            sf_setprio_hi();
-            if (!((VAR & 8) && t > 0))
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[mh * 4 + mt][nh * 2 + nt] =
-                            sf_mfma16(nh ? b1[nt][ks] : b0[nt][ks], a[mt][ks], acc[mh * 4 + mt][nh * 2 + nt]);
-            sf_setprio_lo();
-            sched_fence();
-            raw_barrier();
-        }
-    }
-    if (wr == 0) raw_barrier();  // group 0 catches up (equal barrier counts)
-
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            sf_gemm_store4<OUT_F32>(p.e, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + 4 * (lane >> 4), v);
-        }
-}
-
-template <int OUT_F32>
-SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256_mf32_kernel(Gemm256Args p) {
-    SF_DYN_SMEM(smem);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
-    const int wr = wave >> 2, wc = wave & 3;
-    int tm, tn;
-    tile_coords256((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
-    const int m0 = tm * TM, n0 = tn * TN;
-    const int nkt = p.K / TK;
-
-    // ---- DMA sources: this wave stages pieces 2*wave, 2*wave+1 (8 rows x 128 B each) of every half-tile
-    const int srow = lane >> 3;                       // row inside a piece
-    // logical 16-byte chunk fetched into physical chunk lane&7: XOR with ((row>>1)&7), which is conflict-free
-    // for the 32-row fragments of mfma_32x32x16; piece parity j contributes bit 2
-    const int slc2[2] = {(lane & 7) ^ ((srow >> 1) & 7), (lane & 7) ^ ((4 + (srow >> 1)) & 7)};
-    const sf_bf16* srcA[2][2];
-    const sf_bf16* srcB[2][2];
-    long incA[2][2], incB[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = h * 128 + (2 * wave + j) * 8 + srow;
-            const bool okA = m0 + r < p.M, okB = n0 + r < p.N;
-            srcA[h][j] = okA ? p.A + (long)(m0 + r) * p.lda + slc2[j] * 8 : sf_zero16b;
-            srcB[h][j] = okB ? p.B + (long)(n0 + r) * p.ldb + slc2[j] * 8 : sf_zero16b;
-            incA[h][j] = okA ? TK : 0;
-            incB[h][j] = okB ? TK : 0;
-        }
-    auto issue = [&](int op, int h, int kt) {  // op 0 = A, 1 = B; K-tile kt into buffer kt&1
-        char* dst = smem + (kt & 1) * kBufBytes + (op * 2 + h) * kHalfBytes + (2 * wave) * 1024;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const sf_bf16* s = op == 0 ? srcA[h][j] + (long)kt * incA[h][j] : srcB[h][j] + (long)kt * incB[h][j];
-            sf_glds16(s, dst + j * 1024);
-        }
-    };
-
-    // ---- fragment read offsets (bytes inside a half-tile); (row & 7) == (lane & 7) for every fragment row
-    const int frow = lane & 31, hi = lane >> 5;
-    int swz[4];  // k-step ks of 16: chunk 2*ks + hi, XOR ((row>>1)&7) == (lane>>1)&7 for every 32-row fragment
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) swz[ks] = ((2 * ks + hi) ^ ((lane >> 1) & 7)) << 4;
-    const int a_off = frow * 128;                                 // + (mh*64 + mt*32)*128
-    const int b_off = ((wc & 1) * 64 + frow) * 128;               // + (nh*32)*128
-
-    sf_v16f acc[4][2];  // [m tile of 32 rows][n tile of 32 cols]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    sf_v8s a[2][4], b0[4], b1[4];
-
-    // ---- prologue: K-tile 0 complete, B halves of K-tile 1 in flight
-    issue(0, 0, 0); issue(0, 1, 0); issue(1, 0, 0); issue(1, 1, 0);
-    if (nkt > 1) { issue(1, 0, 1); issue(1, 1, 1); }
-    sf_wait_vm0();
-    raw_barrier();
-    if (wr == 1) raw_barrier();  // stagger: group 1 runs one barrier behind group 0
-
-    for (int t = 0; t < nkt; ++t) {
-        const char* bufA = smem + (t & 1) * kBufBytes + wr * kHalfBytes;
-        const char* bufB = smem + (t & 1) * kBufBytes + (2 + (wc >> 1)) * kHalfBytes;
-#pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            // ------------------------------------------------ load segment
-            if (ph == 0) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) b0[ks] = *reinterpret_cast<const sf_v8s*>(bufB + b_off + swz[ks]);
-            }
-            if (ph == 1) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) b1[ks] = *reinterpret_cast<const sf_v8s*>(bufB + b_off + 32 * 128 + swz[ks]);
-            }
-            if (ph == 0 || ph == 2) {
-                const int mh = ph >> 1;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        a[mt][ks] = *reinterpret_cast<const sf_v8s*>(bufA + a_off + (mh * 64 + mt * 32) * 128 + swz[ks]);
-            }
-            if (ph == 0 && t + 1 < nkt) issue(0, 0, t + 1);
-            if (ph == 1 && t + 1 < nkt) issue(0, 1, t + 1);
-            if (ph == 2 && t + 2 < nkt) issue(1, 0, t + 2);
-            if (ph == 3) {
-                if (t + 2 < nkt) {
-                    issue(1, 1, t + 2);
-                    wait_vm4();      // all of K-tile t+1 has landed (this wave's pieces)
-                } else {
-                    sf_wait_vm0();
-                }
-            }
-            wait_lgkm0();            // my ds_reads are done before anyone may restage what I read
-            raw_barrier();
-            sched_fence();
-            // ------------------------------------------------ compute segment: one 64x32 quadrant
-            const int mh = (ph >= 2) ? 1 : 0;
-            const int nh = (ph == 1 || ph == 2) ? 1 : 0;
-            if (!(p.flags & 1)) sf_setprio_hi();
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    acc[mh * 2 + mt][nh] = sf_mfma32(nh ? b1[ks] : b0[ks], a[mt][ks], acc[mh * 2 + mt][nh]);
-            if (!(p.flags & 1)) sf_setprio_lo();
-            sched_fence();
-            raw_barrier();
-        }
-    }
-    if (wr == 0) raw_barrier();  // group 0 catches up (equal barrier counts)
-
-    // ---- epilogue: lane owns C[m][n..n+3]
-    // D[n][m] layout of the swapped 32x32 MFMA: lane owns m = lane&31 and, per register quad q, n = 8q + 4hi + 0..3
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                sf_gemm_store4<OUT_F32>(p.e, m0 + wr * 128 + i * 32 + (lane & 31), n0 + wc * 64 + j * 32 + 8 * q + 4 * hi, v);
-            }
-}
+#ifdef SF_ABLATE
+#include "../../tools/experiments/sf_gemm256_variants.inc"
+#endif
 
 }  // namespace
 
@@ -497,20 +235,24 @@ int sf_gemm_nt_256_launch(const void* A, long lda, const void* B, long ldb, int 
     p.M = M; p.N = N; p.K = K;
     p.tiles_m = (M + TM - 1) / TM;
     p.tiles_n = (N + TN - 1) / TN;
-    { const char* e = getenv("SF_GEMM_GM"); p.gm = e ? atoi(e) : 4; if (p.gm < 1) p.gm = 1; }
-    { const char* e = getenv("SF_GEMM_FLAGS"); p.flags = e ? atoi(e) : 0; }
+    p.gm = sf_knob("SF_GEMM_GM", 4);
+    if (p.gm < 1) p.gm = 1;
+    p.flags = sf_knob("SF_GEMM_FLAGS", 0);
     const long nblk = (long)p.tiles_m * p.tiles_n;
 #ifndef SF_EMU
     static bool attr_set = false;
     if (!attr_set) {  // 128 KiB of dynamic LDS needs the opt-in
         hipFuncSetAttribute((const void*)gemm_nt_256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes);
         hipFuncSetAttribute((const void*)gemm_nt_256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes);
+#ifdef SF_ABLATE
         hipFuncSetAttribute((const void*)gemm_nt_256_mf32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes);
         hipFuncSetAttribute((const void*)gemm_nt_256_mf32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes);
+#endif
         (void)hipGetLastError();
         attr_set = true;
     }
 #endif
+#ifdef SF_ABLATE   // A/B variants, tools only (tools/experiments/sf_gemm256_variants.inc)
     static const int variant = [] { const char* e = getenv("SF_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
     if (variant >= 1) {
 #define SF_V2_CASE(V)                                                                                                    \
@@ -533,7 +275,10 @@ int sf_gemm_nt_256_launch(const void* A, long lda, const void* B, long ldb, int 
             SF_LAUNCH((gemm_nt_256_mf32_kernel<1>), dim3((unsigned)nblk), dim3(512), 2 * kBufBytes, stream, p);
         else
             SF_LAUNCH((gemm_nt_256_mf32_kernel<0>), dim3((unsigned)nblk), dim3(512), 2 * kBufBytes, stream, p);
-    } else if (c_dtype == SF_F32)
+        return sf_check_launch("sf_gemm_nt(256 mf32)");
+    }
+#endif
+    if (c_dtype == SF_F32)
         SF_LAUNCH((gemm_nt_256_kernel<1>), dim3((unsigned)nblk), dim3(512), 2 * kBufBytes, stream, p);
     else
         SF_LAUNCH((gemm_nt_256_kernel<0>), dim3((unsigned)nblk), dim3(512), 2 * kBufBytes, stream, p);

@@ -232,7 +232,8 @@ SF_GLOBAL void tn_splitk_reduce_kernel(const float* ws, int ksplit, void* C, lon
 #endif
 
 extern "C" int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
-                          int K, float alpha, float beta, float* workspace, long workspace_floats, void* stream) {
+                          int K, float alpha, float beta, float* workspace, long workspace_floats, int ksplit,
+                          void* stream) {
     SF_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sf_gemm_tn: negative shape");
     SF_CHECK_ARG(K % 64 == 0, "sf_gemm_tn: K must be a multiple of 64 (pad the contraction with zero rows)");
     SF_CHECK_ARG(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sf_gemm_tn: M, N, lda, ldb must be multiples of 8");
@@ -252,19 +253,22 @@ extern "C" int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void
     p.M = M; p.N = N; p.K = K;
     p.tiles_m = (M + TM - 1) / TM;
     p.tiles_n = (N + TN - 1) / TN;
-    { const char* en = getenv("SF_GEMM_GM"); p.gm = en ? atoi(en) : 4; if (p.gm < 1) p.gm = 1; }
+    p.gm = sf_knob("SF_GEMM_GM", 4);
+    if (p.gm < 1) p.gm = 1;
+    SF_CHECK_ARG(ksplit == 0 || ksplit == 1 || ksplit == 2, "sf_gemm_tn: ksplit must be 0 (automatic), 1 (never) or 2 (two-way)");
     const long nblk = (long)p.tiles_m * p.tiles_n;
     SF_CHECK_ARG(nblk < (1L << 31), "sf_gemm_tn: grid too large");
     // Split-K by 2 when the tile count leaves the last round of the 256 CUs at most half full (e.g. 384 or 896 tiles:
     // 1.5 / 3.5 rounds -> 3 / 7 full rounds of half-length blocks) and the caller provided room for the fp32 partials.
     p.ksplit = 1;
     p.ws = nullptr;
-    static const int split_mode = [] { const char* en = getenv("SF_GEMM_SPLITK"); return en ? atoi(en) : -1; }();
     {
         const long rem = nblk % 256;
         const bool helps = rem > 0 && rem <= 128 && nblk < 2048 && ((2 * nblk) % 256 == 0 || (2 * nblk) % 256 > 192);
         const bool fits = workspace && workspace_floats >= 2L * M * N && (K / TK) % 2 == 0 && K >= 4096 && N % 4 == 0;
-        if (fits && split_mode != 0 && (helps || split_mode == 2)) { p.ksplit = 2; p.ws = workspace; }
+        SF_CHECK_ARG(ksplit != 2 || fits, "sf_gemm_tn: ksplit = 2 needs a workspace of 2*M*N floats, K >= 4096 with an even "
+                                          "number of 64-row K-tiles, and N % 4 == 0");
+        if (fits && ksplit != 1 && (helps || ksplit == 2)) { p.ksplit = 2; p.ws = workspace; }
     }
     if (p.ksplit > 1) {
         SF_TN_SMEM((gemm_tn_256w4_kernel<1>));
@@ -277,12 +281,14 @@ extern "C" int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void
             SF_LAUNCH((tn_splitk_reduce_kernel<0>), dim3(grid), dim3(256), 0, stream, (const float*)p.ws, p.ksplit, C, ldc, M, N, alpha, beta);
         return sf_check_launch("sf_gemm_tn(split-K)");
     }
-    static const bool spread = [] { const char* en = getenv("SF_GEMM_TN_SPREAD"); return en ? atoi(en) == 1 : false; }();
+#ifdef SF_ABLATE
+    static const bool spread = sf_knob("SF_GEMM_TN_SPREAD", 0) == 1;
     if (spread && c_dtype != SF_F32) {
         SF_TN_SMEM((gemm_tn_256w4_kernel<0, 1>));
         SF_LAUNCH((gemm_tn_256w4_kernel<0, 1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
         return sf_check_launch("sf_gemm_tn(spread)");
     }
+#endif
     if (c_dtype == SF_F32) {
         SF_TN_SMEM((gemm_tn_256w4_kernel<1>));
         SF_LAUNCH((gemm_tn_256w4_kernel<1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);

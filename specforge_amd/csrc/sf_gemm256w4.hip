@@ -234,471 +234,9 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// Soft-barrier variant (SF_GEMM_SOFT=1).  Ablation: deleting the per-K-tile s_barrier from the 4-wave loop
-// lifts it from 1.69 to 1.95 PFLOP/s (zero-filled 8192^3) -- the four waves of a workgroup drift apart by LDS /
-// DMA timing and every K-tile pays the slowest one.  Here the barrier's two halves are separate program points on a
-// monotonic LDS counter: a wave ARRIVES at the end of half-step 2t (its DMA pieces of tile t+1 have landed, its reads
-// of buffer t&1 have returned) and only WAITS for the other three at group G of half-step 2t+1, right before its
-// first read of tile t+1 / first DMA into buffer t&1 -- G groups (G x 64 cycles) of skew are absorbed for free.
-// Accumulators pinned to AGPRs, LDS-DMA from inline asm (the loop contains a spin loop; the builtin forms'
-// register allocation would not survive it).
-constexpr int kSoftG = 8;
-
-// SOFT = 0: the same asm-MFMA / opaque-DMA loop with the plain s_barrier and loads from group 0 (A/B reference point)
-template <int OUT_F32, int SOFT = 1>
-SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4s_kernel(GemmW4Args p) {
-    constexpr int G0 = SOFT ? kSoftG : 0;
-    SF_DYN_SMEM(smem);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
-    const int wr = wave >> 1, wc = wave & 1;
-    int tm, tn;
-    w4_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
-    const int m0 = tm * TM, n0 = tn * TN;
-    const int nkt = p.K / TK;
-    unsigned* cnt = reinterpret_cast<unsigned*>(smem + 2 * kBufBytes);
-
-    const int srow = lane >> 3;
-    const int slc = (lane & 7) ^ (srow & 7);
-    const sf_bf16* src[16];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        int ra = m0 + (8 * wave + j) * 8 + srow, rb = n0 + (8 * wave + j) * 8 + srow;
-        ra = ra < p.M ? ra : p.M - 1;
-        rb = rb < p.N ? rb : p.N - 1;
-        src[j] = p.A + (long)ra * p.lda + slc * 8;
-        src[8 + j] = p.B + (long)rb * p.ldb + slc * 8;
-    }
-    auto dma = [&](int g, int kt) {
-        char* dst = smem + (kt & 1) * kBufBytes + (g >> 3) * kOpBytes + (8 * wave + (g & 7)) * 1024;
-        sf_glds16_opaque(src[g], dst);
-        src[g] += TK;
-    };
-    const int frow = lane & 15;
-    int swz[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) swz[ks] = ((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
-    const int a_off = (wr * 128 + frow) * 128;
-    const int b_off = kOpBytes + (wc * 128 + frow) * 128;
-
-    sf_v4f acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
-    sf_v8s f[2][16];
-    auto read_frag = [&](int set, int g, const char* buf, int ks) {
-        if (g < 8) f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + b_off + g * 2048 + swz[ks]);
-        else f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + a_off + (g - 8) * 2048 + swz[ks]);
-    };
-
-    if (tid == 0) *cnt = 0u;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) dma(g, 0);
-    if (nkt > 1) {
-#pragma unroll
-        for (int g = 0; g < 16; ++g) dma(g, 1);
-    }
-    w4_wait_all();
-    sf_syncthreads();
-#pragma unroll
-    for (int g = 0; g < 16; ++g) read_frag(0, g, smem, 0);
-
-    auto tile = [&](auto READ_NEXT, auto DO_DMA, int t) {
-        const char* cur = smem + (t & 1) * kBufBytes;
-        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
-                sf_mfma16_acc(f[0][nt], f[0][8 + mt], acc[mt][nt]);
-            }
-            w4_fence();
-            if (g < 8) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
-            w4_fence();
-        }
-        w4_wait_all();        // my DMA pieces of tile t+1 have landed, my reads of buffer t&1 have returned
-        if (SOFT) sf_flag_arrive(cnt);  // ... and I say so; nobody waits here
-        else w4_barrier();
-        const unsigned target = 4u * (unsigned)(t + 1);
-        unsigned seen = 0;
-        int fi = 0, di = 0;   // next fragment / DMA piece to issue (compile-time after unrolling)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
-                sf_mfma16_acc(f[1][nt], f[1][8 + mt], acc[mt][nt]);
-            }
-            w4_fence();
-            if (SOFT && (decltype(READ_NEXT)::value || decltype(DO_DMA)::value)) {
-                if (g == G0 - 2) seen = sf_flag_peek(cnt);                       // early look, latency hidden
-                if (g == G0 && seen < target) sf_flag_wait(cnt, target);          // slow path only under real skew
-            }
-            if (g >= G0) {
-                const int n = (16 - G0) >= 16 ? 1 : ((16 - G0) >= 12 ? (g < G0 + 4 ? 2 : 1) : 2);   // 16 issues over groups G0 .. 15
-#pragma unroll
-                for (int k = 0; k < n; ++k) {
-                    if constexpr (decltype(READ_NEXT)::value) { if (fi < 16) read_frag(0, fi, nxt, 0); }
-                    ++fi;
-                    if constexpr (decltype(DO_DMA)::value) { if (di < 16) dma(di, t + 2); }
-                    ++di;
-                }
-            }
-            w4_fence();
-        }
-    };
-    int t = 0;
-    for (; t + 2 < nkt; ++t) tile(std::true_type{}, std::true_type{}, t);
-    if (t + 1 < nkt) { tile(std::true_type{}, std::false_type{}, t); ++t; }
-    tile(std::false_type{}, std::false_type{}, t);
-
-    sf_mfma_drain();
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            w4_store4<OUT_F32, 0>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Register-staged variant (experiment knob SF_GEMM_W4R=1): the same 4-wave pipeline, but operand tiles go
-// HBM -> VGPR (global_load_dwordx4, issued a full K-tile before they are needed) -> LDS (ds_write_b128 into the
-// buffer the barrier has just freed).  The VGPR stage is a third pipeline slot that costs no LDS, which doubles the
-// load lead (the LDS-DMA form can only start a tile once its LDS buffer is free), and a global_load + ds_write pair
-// may cost fewer issue cycles than one LDS-DMA instruction (~60 cycles each, 16 per wave and K-tile).
-// Accumulators are pinned to AGPRs (sf_mfma16_acc) so that the extra 64 staging registers cannot disturb them.
-template <int OUT_F32>
-SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4r_kernel(GemmW4Args p) {
-    SF_DYN_SMEM(smem);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
-    const int wr = wave >> 1, wc = wave & 1;
-    int tm, tn;
-    w4_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
-    const int m0 = tm * TM, n0 = tn * TN;
-    const int nkt = p.K / TK;
-
-    const int srow = lane >> 3;
-    const int slc = (lane & 7) ^ (srow & 7);
-    const sf_bf16* src[16];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        int ra = m0 + (8 * wave + j) * 8 + srow, rb = n0 + (8 * wave + j) * 8 + srow;
-        ra = ra < p.M ? ra : p.M - 1;
-        rb = rb < p.N ? rb : p.N - 1;
-        src[j] = p.A + (long)ra * p.lda + slc * 8;
-        src[8 + j] = p.B + (long)rb * p.ldb + slc * 8;
-    }
-    sf_v8s stage[16];
-    auto gload = [&](int g) {   // piece g of the next un-fetched K-tile -> staging registers
-        stage[g] = *reinterpret_cast<const sf_v8s*>(src[g]);
-        src[g] += TK;
-    };
-    auto lwrite = [&](int g, int kt) {   // staging registers -> piece g of buffer kt&1 (the LDS-DMA image, lane-linear)
-        char* dst = smem + (kt & 1) * kBufBytes + (g >> 3) * kOpBytes + (8 * wave + (g & 7)) * 1024 + lane * 16;
-        *reinterpret_cast<sf_v8s*>(dst) = stage[g];
-    };
-
-    const int frow = lane & 15;
-    int swz[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) swz[ks] = ((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
-    const int a_off = (wr * 128 + frow) * 128;
-    const int b_off = kOpBytes + (wc * 128 + frow) * 128;
-
-    sf_v4f acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
-    sf_v8s f[2][16];
-    auto read_frag = [&](int set, int g, const char* buf, int ks) {
-        if (g < 8) f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + b_off + g * 2048 + swz[ks]);
-        else f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + a_off + (g - 8) * 2048 + swz[ks]);
-    };
-
-    // ---- prologue: tiles 0 and 1 in LDS, tile 2 in flight towards the staging registers
-#pragma unroll
-    for (int g = 0; g < 16; ++g) gload(g);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) lwrite(g, 0);
-    if (nkt > 1) {
-#pragma unroll
-        for (int g = 0; g < 16; ++g) gload(g);
-#pragma unroll
-        for (int g = 0; g < 16; ++g) lwrite(g, 1);
-    }
-    if (nkt > 2) {
-#pragma unroll
-        for (int g = 0; g < 16; ++g) gload(g);
-    }
-    sf_syncthreads();
-#pragma unroll
-    for (int g = 0; g < 16; ++g) read_frag(0, g, smem, 0);
-
-    // WRITE_NEXT: tile t+2 exists (it sits in the staging registers); LOAD_NEXT: tile t+3 exists
-    auto tile = [&](auto WRITE_NEXT, auto LOAD_NEXT, int t) {
-        const char* cur = smem + (t & 1) * kBufBytes;
-        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
-                sf_mfma16_acc(f[0][nt], f[0][8 + mt], acc[mt][nt]);
-            }
-            w4_fence();
-            if (g < 8) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
-            w4_fence();
-        }
-        w4_wait_lgkm();     // my fragment reads of buffer t&1 and my ds_writes of tile t+1 are complete ...
-        w4_barrier();       // ... everyone's are: tile t+1 visible, buffer t&1 free (in-flight global loads keep flying)
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = g * 4 + q, mt = idx >> 3, nt = idx & 7;
-                sf_mfma16_acc(f[1][nt], f[1][8 + mt], acc[mt][nt]);
-            }
-            w4_fence();
-            if (g < 4) { read_frag(0, 2 * g, nxt, 0); read_frag(0, 2 * g + 1, nxt, 0); }
-            else if (g < 12) read_frag(0, g + 4, nxt, 0);
-            if constexpr (decltype(WRITE_NEXT)::value) lwrite(g, t + 2);
-            if constexpr (decltype(LOAD_NEXT)::value) gload(g);
-            w4_fence();
-        }
-    };
-    int t = 0;
-    for (; t + 3 < nkt; ++t) tile(std::true_type{}, std::true_type{}, t);
-    for (; t + 2 < nkt; ++t) tile(std::true_type{}, std::false_type{}, t);
-    for (; t < nkt; ++t) tile(std::false_type{}, std::false_type{}, t);
-
-    sf_mfma_drain();
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            w4_store4<OUT_F32, 0>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// 8-wave form of the same loop (2 x 4 waves, 128 x 64 per wave, two waves per SIMD): identical
-// single-barrier-per-K-tile software pipeline, but every SIMD has a second wave whose MFMAs cover the
-// ~60 cycles a wave is stuck issuing each LDS-DMA instruction (measured: in the 4-wave form the DMA issue
-// alone costs 25 % of the MFMA-only rate).  Unlike the ping-pong kernel nothing alternates the two waves
-// explicitly; the hardware arbitrates.
-template <int OUT_F32>
-SF_GLOBAL void SF_LAUNCH_BOUNDS(512, 2) gemm_nt_256w8_kernel(GemmW4Args p) {
-    SF_DYN_SMEM(smem);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
-    const int wr = wave >> 2, wc = wave & 3;
-    int tm, tn;
-    w4_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
-    const int m0 = tm * TM, n0 = tn * TN;
-    const int nkt = p.K / TK;
-
-    // ---- DMA sources: this wave stages pieces 4*wave .. 4*wave+3 (8 rows x 128 B each) of A and of B
-    const int srow = lane >> 3;
-    const int slc = (lane & 7) ^ (srow & 7);
-    const sf_bf16* src[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int ra = m0 + (4 * wave + j) * 8 + srow, rb = n0 + (4 * wave + j) * 8 + srow;
-        ra = ra < p.M ? ra : p.M - 1;
-        rb = rb < p.N ? rb : p.N - 1;
-        src[j] = p.A + (long)ra * p.lda + slc * 8;
-        src[4 + j] = p.B + (long)rb * p.ldb + slc * 8;
-    }
-    auto dma = [&](int g, int kt) {  // piece g (0..3 A, 4..7 B) of the next un-issued K-tile into buffer kt&1
-        char* dst = smem + (kt & 1) * kBufBytes + (g >> 2) * kOpBytes + (4 * wave + (g & 3)) * 1024;
-        sf_glds16(src[g], dst);
-        src[g] += TK;
-    };
-
-    const int frow = lane & 15;
-    int swz[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) swz[ks] = ((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
-    const int a_off = (wr * 128 + frow) * 128;
-    const int b_off = kOpBytes + (wc * 64 + frow) * 128;
-
-    sf_v4f acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
-    sf_v8s f[2][12];  // [set][0..3 = B n-tiles, 4..11 = A m-tiles]
-
-    auto read_frag = [&](int set, int g, const char* buf, int ks) {
-        if (g < 4) f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + b_off + g * 2048 + swz[ks]);
-        else f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + a_off + (g - 4) * 2048 + swz[ks]);
-    };
-
-#pragma unroll
-    for (int g = 0; g < 8; ++g) dma(g, 0);
-    if (nkt > 1) {
-#pragma unroll
-        for (int g = 0; g < 8; ++g) dma(g, 1);
-    }
-    w4_wait_all();
-    w4_barrier();
-#pragma unroll
-    for (int g = 0; g < 12; ++g) read_frag(0, g, smem, 0);
-
-    auto tile = [&](auto READ_NEXT, auto DO_DMA, int t) {
-        const char* cur = smem + (t & 1) * kBufBytes;
-        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = g * 4 + q, mt = idx >> 2, nt = idx & 3;
-                acc[mt][nt] = sf_mfma16(f[0][nt], f[0][4 + mt], acc[mt][nt]);
-            }
-            if (g < 6) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
-            w4_fence();
-        }
-        w4_wait_all();
-        w4_barrier();
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = g * 4 + q, mt = idx >> 2, nt = idx & 3;
-                acc[mt][nt] = sf_mfma16(f[1][nt], f[1][4 + mt], acc[mt][nt]);
-            }
-            if constexpr (decltype(READ_NEXT)::value) {
-                if (g < 6) { read_frag(0, 2 * g, nxt, 0); read_frag(0, 2 * g + 1, nxt, 0); }
-            }
-            if constexpr (decltype(DO_DMA)::value) dma(g, t + 2);
-            w4_fence();
-        }
-    };
-
-    int t = 0;
-    for (; t + 2 < nkt; ++t) tile(std::true_type{}, std::true_type{}, t);
-    if (t + 1 < nkt) { tile(std::true_type{}, std::false_type{}, t); ++t; }
-    tile(std::false_type{}, std::false_type{}, t);
-
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            w4_store4<OUT_F32>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 64 + j * 16 + 4 * (lane >> 4), acc[i][j]);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Same structure with mfma_f32_32x32x16_bf16: per flop it reads half the operand and accumulator
-// registers of the 16x16x32 form and issues half the instructions.  Every GEMM of the training step is
-// POWER-limited on real (non-zero) data -- zero-filled operands run the same kernels ~20 % faster at a
-// higher clock -- so energy per flop, not issue slots, is what this variant buys.
-//   wave block 128 x 128 = 4 x 4 tiles of 32 x 32 (16 accumulator registers each);
-//   a K-tile is four k16-steps of 16 MFMAs; fragment sets (4 B + 4 A ds_read_b128) are double-buffered;
-//   the barrier sits after k16-step 2 (all reads of the tile issued and returned); k16-step 3 reads the next
-//   tile's first fragments and stages the A pieces of tile t+2, k16-step 0 of the next tile stages its B pieces.
-//   LDS chunk swizzle: physical = logical ^ ((row >> 1) & 7) (conflict-free for 32-row fragments).
-template <int OUT_F32>
-SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4m32_kernel(GemmW4Args p) {
-    SF_DYN_SMEM(smem);
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
-    const int wr = wave >> 1, wc = wave & 1;
-    int tm, tn;
-    w4_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
-    const int m0 = tm * TM, n0 = tn * TN;
-    const int nkt = p.K / TK;
-
-    const int srow = lane >> 3;
-    const char* tileA = (const char*)(p.A + (long)m0 * p.lda);
-    const char* tileB = (const char*)(p.B + (long)n0 * p.ldb);
-    unsigned off[16];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = (8 * wave + j) * 8 + srow;               // LDS row of this lane's 16 bytes
-        const int slc = (lane & 7) ^ ((r >> 1) & 7);           // logical chunk fetched into physical chunk lane&7
-        const int ra = m0 + r < p.M ? r : p.M - 1 - m0;
-        const int rb = n0 + r < p.N ? r : p.N - 1 - n0;
-        off[j] = (unsigned)(((long)ra * p.lda + slc * 8) * 2);
-        off[8 + j] = (unsigned)(((long)rb * p.ldb + slc * 8) * 2);
-    }
-    // piece g (0..7 A, 8..15 B) of K-tile kt into buffer kt&1.  A "tile" past the end re-fetches tile nkt-1 into a
-    // buffer nobody reads again, which keeps the loop body free of tail cases (2 redundant L2-resident tiles per
-    // workgroup).
-    auto dma = [&](int g, int kt) {
-        char* dst = smem + (kt & 1) * kBufBytes + (g >> 3) * kOpBytes + (8 * wave + (g & 7)) * 1024;
-        const int kc = kt < nkt ? kt : nkt - 1;
-        sf_glds16((g < 8 ? tileA : tileB) + (long)kc * (TK * 2) + off[g], dst);
-    };
-
-    const int frow = lane & 31, hi = lane >> 5;
-    int swz[4];  // k16-step ks: logical chunk 2*ks + hi
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) swz[ks] = ((2 * ks + hi) ^ ((lane >> 1) & 7)) << 4;
-    const int a_off = (wr * 128 + frow) * 128;
-    const int b_off = kOpBytes + (wc * 128 + frow) * 128;
-
-    sf_v16f acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    sf_v8s f[2][8];  // [set][0..3 = B n-tiles, 4..7 = A m-tiles]
-
-    auto read_frag = [&](int set, int g, const char* buf, int ks) {
-        if (g < 4) f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + b_off + g * 4096 + swz[ks]);
-        else f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + a_off + (g - 4) * 4096 + swz[ks]);
-    };
-
-#pragma unroll
-    for (int g = 0; g < 16; ++g) dma(g, 0);
-#pragma unroll
-    for (int g = 0; g < 8; ++g) dma(g, 1);   // A pieces of tile 1; its B pieces follow in k16-step 0 of tile 0
-    w4_wait_all();
-    w4_barrier();
-#pragma unroll
-    for (int g = 0; g < 8; ++g) read_frag(0, g, smem, 0);
-
-    for (int t = 0; t < nkt; ++t) {
-        const char* cur = smem + (t & 1) * kBufBytes;
-        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
-        auto quarter = [&](auto QC) SF_INLINE_LAMBDA {
-            constexpr int q = decltype(QC)::value;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int mt = i >> 2, nt = i & 3;
-                acc[mt][nt] = sf_mfma32(f[q & 1][nt], f[q & 1][4 + mt], acc[mt][nt]);
-                if (i < 8) {  // the next k16-step's fragments, front-loaded
-                    if constexpr (q < 3) read_frag((q + 1) & 1, i, cur, q + 1);
-                    else read_frag(0, i, nxt, 0);
-                } else {
-                    if constexpr (q == 0) dma(8 + (i - 8), t + 1);   // B pieces of tile t+1
-                    if constexpr (q == 3) dma(i - 8, t + 2);         // A pieces of tile t+2
-                }
-                w4_fence();
-            }
-        };
-        quarter(std::integral_constant<int, 0>{});
-        quarter(std::integral_constant<int, 1>{});
-        quarter(std::integral_constant<int, 2>{});
-        w4_wait_all();   // my pieces of tile t+1 have landed; my reads of buffer t&1 have returned
-        w4_barrier();    // -> tile t+1 visible to everyone, buffer t&1 free for tile t+2
-        quarter(std::integral_constant<int, 3>{});
-    }
-    sf_wait_vm0();  // no LDS-DMA may land after this workgroup's LDS has been handed to the next one
-
-    // ---- epilogue: D[n][m] layout of the swapped 32x32 MFMA: lane owns m = lane&31 and, per register quad q,
-    // n = 8q + 4hi + 0..3
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                w4_store4<OUT_F32>(p, m0 + wr * 128 + i * 32 + (lane & 31), n0 + wc * 128 + j * 32 + 8 * q + 4 * hi,
-                                   sf_v4f{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
-}
+#ifdef SF_ABLATE
+#include "../../tools/experiments/sf_gemm256w4_variants.inc"
+#endif
 
 }  // namespace
 
@@ -727,8 +265,10 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     p.M = M; p.N = N; p.K = K;
     p.tiles_m = (M + TM - 1) / TM;
     p.tiles_n = (N + TN - 1) / TN;
-    { const char* e = getenv("SF_GEMM_GM"); p.gm = e ? atoi(e) : 4; if (p.gm < 1) p.gm = 1; }
+    p.gm = sf_knob("SF_GEMM_GM", 4);
+    if (p.gm < 1) p.gm = 1;
     const long nblk = (long)p.tiles_m * p.tiles_n;
+#ifdef SF_ABLATE   // A/B variants, tools only (tools/experiments/sf_gemm256w4_variants.inc)
     static const bool m32 = [] { const char* e = getenv("SF_GEMM_MFMA"); return e ? atoi(e) == 32 : false; }();
     if (m32) {
         if (c_dtype == SF_F32) {
@@ -809,6 +349,7 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
         }
         return sf_check_launch("sf_gemm_nt(256w4 buf)");
     }
+#endif
     if (p.e.Cadd) {
         SF_CHECK_ARG(p.e.alpha == 1.0f, "sf_gemm_nt_rowadd: the 4-wave kernel needs alpha == 1");
         if (c_dtype == SF_F32) {

@@ -61,16 +61,17 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, alpha: float
 
 
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0,
-            workspace: Optional[torch.Tensor] = None):
+            workspace: Optional[torch.Tensor] = None, ksplit: int = 0):
     """out[M,N] = alpha * a[K,M]^T @ b[K,N] (+ beta*out); a, b bf16 (row-major, K outermost); out bf16|fp32.
-    workspace: optional fp32 scratch (>= 2*M*N) that allows a 2-way split of K for awkward tile counts."""
+    workspace: optional fp32 scratch (>= 2*M*N) that allows a 2-way split of K for awkward tile counts
+    (ksplit: 0 = the launcher decides, 1 = never, 2 = always)."""
     L = _lib.lib()
     K, M = a.shape
     K2, N = b.shape
     assert K == K2 and out.shape == (M, N) and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
     assert workspace is None or workspace.dtype == torch.float32
     _lib.check(L.sf_gemm_tn(_p(a), _rowmajor(a), _p(b), _rowmajor(b), _p(out), _dt(out), _rowmajor(out), M, N, K, alpha,
-                            beta, _p(workspace), workspace.numel() if workspace is not None else 0, _stream()), "sf_gemm_tn")
+                            beta, _p(workspace), workspace.numel() if workspace is not None else 0, ksplit, _stream()), "sf_gemm_tn")
     return out
 
 

@@ -190,7 +190,11 @@ class ParallelConfig:
 class HipDPTrainingBackend:
     name = "hip_dp"
 
-    def __init__(self, parallel_config: Optional[ParallelConfig] = None, *, optimizer_factory=None, process_group=None):
+    def __init__(self, parallel_config: Optional[ParallelConfig] = None, *, optimizer_factory=None, process_group=None,
+                 single_collective: bool = False, force_collectives: bool = False):
+        """``single_collective``: one all-reduce of the whole flat gradient after the sweep instead of the overlapped
+        per-bucket ones (A/B option for multi-GPU boxes).  ``force_collectives``: run the collectives even at world
+        size 1 (exercises the RCCL path on a single-GPU box)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.parallel_config = parallel_config or ParallelConfig(world_size=self.world, dp_size=self.world,
@@ -199,7 +203,8 @@ class HipDPTrainingBackend:
         self.module: Optional[OnlineEagle3Model] = None
         self.optimizer: Optional[BF16Optimizer] = None
         self._handles: List[Any] = []
-        self._single_collective = os.environ.get("SF_DP_SINGLE") == "1"
+        self._single_collective = bool(single_collective)
+        self._force_collectives = bool(force_collectives)
         self._pending_single = False
         self._sync_this_backward = True
         self.no_sync_backwards = 0  # telemetry: micro-steps that skipped the collective
@@ -210,8 +215,7 @@ class HipDPTrainingBackend:
 
     def prepare_model(self, model: OnlineEagle3Model, *, wrap: bool = True, optimizer_target=None) -> nn.Module:
         self.module = model
-        # SF_FORCE_DP=1: run the collectives even at world_size 1 (exercises the RCCL path on a single-GPU box)
-        use_dp = self.world > 1 or (os.environ.get("SF_FORCE_DP") == "1" and dist.is_available() and dist.is_initialized())
+        use_dp = self.world > 1 or (self._force_collectives and dist.is_available() and dist.is_initialized())
         model.engine.on_bucket_ready = self._bucket_ready if use_dp else None
         if use_dp:  # replicas must start identical (DDP broadcasts rank 0's parameters)
             dist.broadcast(model.engine.flat.data, src=0, group=self.group)
@@ -233,7 +237,7 @@ class HipDPTrainingBackend:
     def _bucket_ready(self, lo: int, hi: int) -> None:
         if not self._sync_this_backward:
             return
-        if self._single_collective:      # SF_DP_SINGLE=1: one all-reduce of the whole flat gradient after the sweep
+        if self._single_collective:      # one all-reduce of the whole flat gradient after the sweep
             self._pending_single = True
             return
         # async SUM over RCCL: enqueued behind the wgrad GEMM that produced the bucket, runs on the

@@ -108,7 +108,7 @@ def grad_errors(got, ref):
     return rows
 
 
-def compare(name, c, *, loss_tol=5e-3, ids_min=0.9995, grad_max_rel=2e-2, grad_fro_rel=2e-2, with_bf16_yardstick=True):
+def compare(name, c, *, loss_tol=5e-3, ids_min=0.9995, grad_cap=6e-2, yardstick_factor=1.1):
     """runs both sides, writes the report, asserts the bars; returns the report dict."""
     dev = torch.device("cuda", 0)
     ttt = c["ttt"]
@@ -126,7 +126,7 @@ def compare(name, c, *, loss_tol=5e-3, ids_min=0.9995, grad_max_rel=2e-2, grad_f
         ids_agree=float((hip["ids"] == ref["ids"]).float().mean()),
         pos_mask_agree=float((hip["pos_mask"] == ref["pos_mask"]).float().mean()),
         grads=grad_errors(hip["grads"], ref["grads"]))
-    if with_bf16_yardstick:
+    if True:
         bf = run_oracle(*case, ttt, dev, torch.bfloat16)
         rep["oracle_bf16_vs_fp32"] = dict(
             ploss_max_abs=float((bf["plosses"] - ref["plosses"]).abs().max()),
@@ -150,6 +150,15 @@ def compare(name, c, *, loss_tol=5e-3, ids_min=0.9995, grad_max_rel=2e-2, grad_f
     t2d = case[4]
     lm = torch.cat((case[6]["loss_mask"],), 0)
     assert torch.equal(hip["pos_mask"], t2d[hip["ids"]].int() * lm.int())
-    bad = {k: v for k, v in worst.items() if v[0] > grad_max_rel or v[1] > grad_fro_rel}
+    # gradients: the bf16 rounding error of a step grows with the contraction depths (measured r2, Frobenius-relative:
+    # 1.4 % at H 2048, 2.2 % at H 4096, 4.6 % at H 7168 / I 40960), so the bar is relative to the yardstick: per tensor the
+    # HIP path must be no further from the fp32 truth than 1.1x what the reference's own bf16 run is (measured: 0.65-0.75x),
+    # with an absolute cap of 6e-2 on both measures
+    yard = rep["oracle_bf16_vs_fp32"]["grads"]
+    bad = {}
+    for k, v in h["grads"].items():
+        if v["fro_rel"] > max(2e-2, yardstick_factor * yard[k]["fro_rel"]) or v["fro_rel"] > grad_cap or v["max_rel"] > max(
+                2e-2, yardstick_factor * yard[k]["max_rel"], 2 * yard[k]["fro_rel"]) or v["max_rel"] > 1.5 * grad_cap:
+            bad[k] = (v, yard[k])
     assert not bad, bad
     return rep

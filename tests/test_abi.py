@@ -27,8 +27,34 @@ def test_hip_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libsfhip.so lacks {n}"
     assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
     lib.sf_abi_version.restype = ctypes.c_int
-    assert lib.sf_abi_version() == 1
+    assert lib.sf_abi_version() == 2
     assert lib.sf_is_emulated() == 0
+
+
+def test_product_library_reads_no_environment_knobs():
+    """ablation / variant code paths selected by SF_* environment variables must not exist in the product
+    binary -- an inherited variable could silently change (or corrupt) training.  Knobs are compile-time constants
+    unless the TOOLS build defines SF_ABLATE (specforge_amd/csrc/sf_api_internal.h)."""
+    from specforge_amd import build
+
+    blob = open(build.build_hip(), "rb").read()
+    for needle in (b"SF_GEMM_", b"SF_ATTN_", b"getenv"):
+        assert needle not in blob, needle
+    src = os.path.join(ROOT, "specforge_amd", "csrc")
+    for f in os.listdir(src):
+        depth, guard = 0, None          # preprocessor nesting; `guard` = depth at which an SF_ABLATE block opened
+        for line in open(os.path.join(src, f)):
+            t = line.strip()
+            if t.startswith(("#if", "#ifdef", "#ifndef")):
+                depth += 1
+                if guard is None and t.startswith("#ifdef SF_ABLATE"):
+                    guard = depth
+            elif t.startswith("#endif"):
+                if guard == depth:
+                    guard = None
+                depth -= 1
+            elif guard is None:
+                assert "getenv(" not in line, f"{f}: getenv outside an SF_ABLATE block: {t}"
 
 
 def test_product_path_has_no_cpu_fallback(monkeypatch, tmp_path):

@@ -78,16 +78,17 @@ def test_gemm_tn(backend, M, N, K, out_dtype):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
-def test_gemm_tn_split_k(backend, monkeypatch, out_dtype):
+def test_gemm_tn_split_k(backend, out_dtype):
     """2-way split of the contraction through the fp32 workspace == the unsplit product (fixed-order reduction)"""
-    monkeypatch.setenv("SF_GEMM_SPLITK", "2")   # force the split for any shape that fits (read once per process)
     M, N, K = 136, 200, 4096
     a = _rand((K, M), torch.bfloat16, 1)
     b = _rand((K, N), torch.bfloat16, 2)
     ref = a.float().t() @ b.float()
     ws = torch.empty(2 * M * N, dtype=torch.float32, device=backend)
     out = torch.ones(M, N, dtype=out_dtype, device=backend)
-    ops.gemm_tn(_dev(backend, a), _dev(backend, b), out, alpha=0.5, beta=2.0, workspace=ws)
+    ops.gemm_tn(_dev(backend, a), _dev(backend, b), out, alpha=0.5, beta=2.0, workspace=ws, ksplit=2)
+    with pytest.raises(Exception, match="ksplit = 2 needs"):
+        ops.gemm_tn(_dev(backend, a), _dev(backend, b), out, ksplit=2)          # no workspace
     tol = 1e-3 if out_dtype == torch.float32 else 2e-2
     torch.testing.assert_close(out.float().cpu(), 0.5 * ref + 2.0, rtol=tol, atol=tol * math.sqrt(K))
 
