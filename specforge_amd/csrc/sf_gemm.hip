@@ -141,7 +141,12 @@ static int sf_gemm_dispatch(const void* A, long lda, const void* B, long ldb, in
     // software-pipelined kernel; smaller ones the 8-wave ping-pong kernel, whose prologue/epilogue is shorter.
     // (tools build: SF_GEMM_W4=0 pins the ping-pong kernel, =1 forces the 4-wave kernel for every 256-tile shape)
     static const int w4_mode = sf_knob("SF_GEMM_W4", -1);
+#ifdef SF_EMU   // interpreter build (tests): "chip-filling" means nothing there -- long-K shapes take the 4-wave kernel so that
+                // both 256-tile kernels are exercised by the CPU suite
+    const bool big = K >= 512;
+#else
     const bool big = (long)((M + 255) / 256) * ((N + 255) / 256) >= 256 && K >= 512;
+#endif
     const bool w4_ok = !(e.Cadd && e.alpha != 1.0f);   // its addend path starts the accumulators from Cadd
     if (K % 64 == 0 && K >= 64 && M >= 192 && N >= 192 && sf_gemm_use_256() && w4_ok &&
         (w4_mode == 1 || (w4_mode < 0 && big)))

@@ -48,11 +48,15 @@ struct GemmW4Args {
 SF_DEVICE void w4_barrier() { sfemu::block_barrier(); }
 SF_DEVICE void w4_wait_all() {}
 SF_DEVICE void w4_wait_lgkm() {}
+SF_DEVICE void w4_wait_vm16() {}
+SF_DEVICE void w4_wait_vm0() {}
 SF_DEVICE void w4_fence() {}
 #else
 SF_DEVICE void w4_barrier() { __builtin_amdgcn_s_barrier(); }
 SF_DEVICE void w4_wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 SF_DEVICE void w4_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+SF_DEVICE void w4_wait_vm16() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }   // all but the newest 16 LDS-DMA pieces
+SF_DEVICE void w4_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 SF_DEVICE void w4_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
 
@@ -75,7 +79,7 @@ SF_DEVICE void w4_store4(const GemmW4Args& p, int m, int n, sf_v4f acc) {
 }
 
 // ABL (timing ablations only, results are wrong): bit0 = no ds_reads after the first tile, bit1 = no DMA in the loop
-template <int OUT_F32, int ABL = 0, int BUF = 0, int ADD = 0>
+template <int OUT_F32, int ABL = 0, int BUF = 0, int ADD = 0, int SCHED = 1>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     SF_DYN_SMEM(smem);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
@@ -121,7 +125,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
         if (BUF) {
             sf_buf_glds16(g < 8 ? bufA : bufB, voff[g], (unsigned)kt * (TK * 2), dst);
         } else {
-            sf_glds16(src[g], dst);
+            if (SCHED == 1) sf_glds16_opaque(src[g], dst); else sf_glds16(src[g], dst);
             src[g] += TK;
         }
     };
@@ -220,10 +224,57 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
         }
     };
 
+    // SCHED 1 ("early release"): all 16 fragment reads of tile t's second k-half are issued in the first 32 MFMAs, so the
+    // tile's LDS buffer is handed back after ~1/3 of the iteration (barrier 1) and the 16 DMA pieces of tile t+2 go out
+    // over MFMAs 40..104 -- a FULL iteration more lead than issuing them in the second half-step; they are waited for
+    // with a COUNTED vmcnt at MFMA ~104 of the NEXT iteration (this iteration's own 16 pieces stay in flight), followed by
+    // barrier 2 and the first-half reads of tile t+1.  DMA lead: 1.0 .. 1.5 iterations (2200 .. 3300 cycles) instead of
+    // 0.5 .. 1.0 -- HBM latency under a full chip of streaming GEMM tiles is above the shorter lead.
+    //   RAW: tile t+1 is read only after (own pieces landed: vmcnt) + barrier 2.
+    //   WAR: buffer t&1 is re-staged only after (own reads returned: lgkmcnt(0)) + barrier 1; its first-half fragments
+    //        were read at the end of iteration t-1.
+    auto tile1 = [&](auto READ_NEXT, auto DO_DMA, int t) {
+        const char* cur = smem + (t & 1) * kBufBytes;
+        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = (g & 15) * 4 + q, mt = idx >> 3, nt = idx & 7;
+                if (g < 16) acc[mt][nt] = sf_mfma16(f[0][nt], f[0][8 + mt], acc[mt][nt]);
+                else acc[mt][nt] = sf_mfma16(f[1][nt], f[1][8 + mt], acc[mt][nt]);
+            }
+            w4_fence();
+            if (g < 8) { read_frag(1, 2 * g, cur, 1); read_frag(1, 2 * g + 1, cur, 1); }
+            if (g == 9) {
+                w4_wait_lgkm();      // my reads of buffer t&1 have returned
+                w4_barrier();        // -> buffer t&1 is free for tile t+2
+            }
+            if constexpr (decltype(DO_DMA)::value) {
+                if (g >= 10 && g < 26) dma(g - 10, t + 2);
+            }
+            if (g == 25) {
+                if constexpr (decltype(DO_DMA)::value) w4_wait_vm16(); else w4_wait_vm0();   // my pieces of tile t+1 landed
+                w4_barrier();        // -> tile t+1 visible to everyone
+            }
+            if constexpr (decltype(READ_NEXT)::value) {
+                if (g >= 26 && g < 31) { read_frag(0, 3 * (g - 26), nxt, 0); read_frag(0, 3 * (g - 26) + 1, nxt, 0); read_frag(0, 3 * (g - 26) + 2, nxt, 0); }
+                if (g == 31) read_frag(0, 15, nxt, 0);
+            }
+            w4_fence();
+        }
+    };
+
     int t = 0;
-    for (; t + 2 < nkt; ++t) tile(std::true_type{}, std::true_type{}, t);
-    if (t + 1 < nkt) { tile(std::true_type{}, std::false_type{}, t); ++t; }
-    tile(std::false_type{}, std::false_type{}, t);
+    if constexpr (SCHED == 1) {
+        for (; t + 2 < nkt; ++t) tile1(std::true_type{}, std::true_type{}, t);
+        if (t + 1 < nkt) { tile1(std::true_type{}, std::false_type{}, t); ++t; }
+        tile1(std::false_type{}, std::false_type{}, t);
+    } else {
+        for (; t + 2 < nkt; ++t) tile(std::true_type{}, std::true_type{}, t);
+        if (t + 1 < nkt) { tile(std::true_type{}, std::false_type{}, t); ++t; }
+        tile(std::false_type{}, std::false_type{}, t);
+    }
 
     // ---- epilogue: lane owns C[m][n..n+3]
 #pragma unroll
@@ -335,17 +386,29 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     }
     static const int abl = [] { const char* e = getenv("SF_GEMM_ABL"); return e ? atoi(e) : 0; }();
 #define SF_ABL_CASE(V) \
-    if (abl == V) { SF_W4_SMEM((gemm_nt_256w4_kernel<0, V>)); SF_LAUNCH((gemm_nt_256w4_kernel<0, V>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p); return sf_check_launch("abl"); }
+    if (abl == V) { SF_W4_SMEM((gemm_nt_256w4_kernel<0, V, 0, 0, 0>)); SF_LAUNCH((gemm_nt_256w4_kernel<0, V, 0, 0, 0>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p); return sf_check_launch("abl"); }
     SF_ABL_CASE(1) SF_ABL_CASE(2) SF_ABL_CASE(3) SF_ABL_CASE(4) SF_ABL_CASE(8) SF_ABL_CASE(9) SF_ABL_CASE(12) SF_ABL_CASE(16) SF_ABL_CASE(24)
 #undef SF_ABL_CASE
+    const int sched = sf_knob("SF_GEMM_SCHED", 1);   // 0 = the round-1 schedule (DMA issued in the second half-step, vmcnt(0))
+    if (sched == 0) {
+        SF_CHECK_ARG(c_dtype != SF_F32, "SF_GEMM_SCHED=0: bf16 output only (A/B knob)");
+        if (p.e.Cadd) {
+            SF_W4_SMEM((gemm_nt_256w4_kernel<0, 0, 0, 1, 0>));
+            SF_LAUNCH((gemm_nt_256w4_kernel<0, 0, 0, 1, 0>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+        } else {
+            SF_W4_SMEM((gemm_nt_256w4_kernel<0, 0, 0, 0, 0>));
+            SF_LAUNCH((gemm_nt_256w4_kernel<0, 0, 0, 0, 0>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+        }
+        return sf_check_launch("sf_gemm_nt(256w4 sched0)");
+    }
     static const bool bufdma = [] { const char* e = getenv("SF_GEMM_BUF"); return e ? atoi(e) == 1 : false; }();
     if (bufdma) {
         if (c_dtype == SF_F32) {
-            SF_W4_SMEM((gemm_nt_256w4_kernel<1, 0, 1>));
-            SF_LAUNCH((gemm_nt_256w4_kernel<1, 0, 1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+            SF_W4_SMEM((gemm_nt_256w4_kernel<1, 0, 1, 0, 0>));
+            SF_LAUNCH((gemm_nt_256w4_kernel<1, 0, 1, 0, 0>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
         } else {
-            SF_W4_SMEM((gemm_nt_256w4_kernel<0, 0, 1>));
-            SF_LAUNCH((gemm_nt_256w4_kernel<0, 0, 1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+            SF_W4_SMEM((gemm_nt_256w4_kernel<0, 0, 1, 0, 0>));
+            SF_LAUNCH((gemm_nt_256w4_kernel<0, 0, 1, 0, 0>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
         }
         return sf_check_launch("sf_gemm_nt(256w4 buf)");
     }

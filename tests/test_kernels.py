@@ -29,7 +29,7 @@ def _rand(shape, dtype, seed, scale=1.0):
 
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (64, 48, 288), (257, 384, 512), (256, 256, 64),
-                                   (520, 264, 192), (300, 200, 128)])
+                                   (520, 264, 192), (300, 200, 128), (300, 260, 640), (256, 512, 64 * 11)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_nt(backend, M, N, K, out_dtype):
     a = _rand((M, K), torch.bfloat16, 1)
@@ -42,7 +42,7 @@ def test_gemm_nt(backend, M, N, K, out_dtype):
     torch.testing.assert_close(out.float().cpu(), ref, rtol=tol, atol=tol * math.sqrt(K))
 
 
-@pytest.mark.parametrize("M,N,K,S,T", [(64, 48, 64, 16, 3), (512, 264, 128, 64, 2)])
+@pytest.mark.parametrize("M,N,K,S,T", [(64, 48, 64, 16, 3), (512, 264, 128, 64, 2), (256, 200, 576, 32, 2)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_nt_rowadd(backend, M, N, K, S, T, out_dtype):
     """fp32 row-mapped addend joins the accumulator before the single rounding (embedding half of the TTT QKV)"""
