@@ -1,0 +1,5 @@
+// instantiations of the 4-wave NT GEMM (sf_gemm256w4_kernel.h): OUT_F32 = 0, ADD = 0, both operand orders
+#include "sf_gemm256w4_kernel.h"
+
+SF_W4_DEFINE(0, 0, 12)
+SF_W4_DEFINE(0, 0, 13)

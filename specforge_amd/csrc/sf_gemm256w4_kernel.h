@@ -1,0 +1,333 @@
+// 256x256x64 bf16 MFMA GEMM (NT form), 4 waves x (128 x 128) -- one wave per SIMD, software-pipelined in ONE
+// instruction stream per wave, every non-MFMA instruction placed in its own MFMA slot by a compile-time plan.
+//
+//   * 256 threads; wave (wr, wc) of a 2 x 2 grid owns a 128 x 128 output block = 8 x 8 mfma_f32_16x16x32_bf16 tiles
+//     (256 accumulator registers pinned to AGPRs; one wave per SIMD with the full 512-entry register file).
+//   * LDS = 2 K-tile buffers x {A 256 rows, B 256 rows} x 128 B, XOR-swizzled 16-byte chunks = 128 KiB, filled by
+//     LDS-DMA (buffer_load ... lds through raw buffer descriptors: the K advance is a scalar offset, no vector
+//     arithmetic in the loop).
+//   * a K-tile = 128 MFMAs = two k-halves of 64; fragments are double-buffered in registers (set 0 = k-half 0,
+//     set 1 = k-half 1).
+//   * Schedule of iteration t (round 2; measured against hipBLASLt's hand-scheduled kernel of the same geometry, whose
+//     main loop issues exactly one filler per MFMA gap and is ~99 % matrix-pipe-bound in cycles):
+//       slots   0..45  : the 16 fragment reads of (t, k-half 1), one operand at a time, one read per >= 2 MFMAs
+//       slot   21 / 51 : lgkmcnt(0) + s_barrier -> that OPERAND's half of buffer t&1 is free (released separately,
+//                        so its re-staging starts after 1/6 of the iteration instead of 1/2)
+//       slots  22..95  : the 16 LDS-DMA pieces of tile t+2, never two fillers in one slot (an LDS-DMA issue costs
+//                        60-180 cycles when bunched with ds_reads; a burst of one per 2 MFMAs measured -7 %)
+//       slot  108      : s_waitcnt vmcnt(16) + s_barrier -> tile t+1 (issued during iteration t-1) is visible; this
+//                        iteration's 16 pieces stay in flight.  DMA lead: 1.1 .. 1.7 iterations (2400 .. 3700 cycles).
+//       slots 110..126 : the 16 fragment reads of (t+1, k-half 0)
+//     Two plans differ in which operand goes first: B first is faster when N is narrow (<= 8192: +4..6 % over A
+//     first), A first when N is wide (+2..4 %) -- measured, profiles/r2_gemm_ab.jsonl; the launcher picks by N.
+//     RAW: a tile is read only after (own pieces landed: counted vmcnt) + barrier.  WAR: an operand half is re-staged
+//     only after (own reads returned: lgkmcnt(0)) + barrier; its k-half-0 fragments were read in iteration t-1.
+//   * round-1 schedule (one barrier per K-tile, groups of 4 MFMAs + 2 reads, DMA in the second half-step, vmcnt(0)):
+//     30 % more cycles than hipBLASLt on the same shape; this one 10 % (SQ_WAVE_CYCLES, profiles/r2_gemm_pmc.txt).
+//     It and the intermediate plans live in tools/experiments/sf_gemm256w4_sched.inc (tools build only).
+#pragma once
+#include "sf_api_internal.h"
+#include "sf_util.h"
+#include "sf_gemm_epilogue.h"
+#include <stdlib.h>
+#include <type_traits>
+
+#define SF_INLINE_LAMBDA __attribute__((always_inline))
+
+#ifdef SF_EMU
+#define SF_W4_SMEM(kernel)
+#else
+#define SF_W4_SMEM(kernel)                                                                                       \
+    do {                                                                                                         \
+        static bool done_ = false;                                                                               \
+        if (!done_) {                                                                                            \
+            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes); \
+            (void)hipGetLastError();                                                                             \
+            done_ = true;                                                                                        \
+        }                                                                                                        \
+    } while (0)
+#endif
+
+
+// (has linkage: the per-instantiation launch functions take it across translation units)
+struct GemmW4Args {
+    const sf_bf16* A; long lda;
+    const sf_bf16* B; long ldb;
+    SfGemmEpi e;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    int gm;
+};
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int kOpBytes = 256 * TK * 2;       // 32 KiB: one operand's K-tile
+constexpr int kBufBytes = 2 * kOpBytes;      // A + B
+
+
+#ifdef SF_EMU
+SF_DEVICE void w4_barrier() { sfemu::block_barrier(); }
+SF_DEVICE void w4_wait_all() {}
+SF_DEVICE void w4_wait_lgkm() {}
+SF_DEVICE void w4_wait_vm16() {}
+SF_DEVICE void w4_wait_vm13() {}
+SF_DEVICE void w4_wait_vm0() {}
+SF_DEVICE void w4_fence() {}
+#else
+SF_DEVICE void w4_barrier() { __builtin_amdgcn_s_barrier(); }
+SF_DEVICE void w4_wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+SF_DEVICE void w4_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+SF_DEVICE void w4_wait_vm16() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }   // all but the newest 16 LDS-DMA pieces
+SF_DEVICE void w4_wait_vm13() { asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
+SF_DEVICE void w4_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+SF_DEVICE void w4_fence() { __builtin_amdgcn_sched_barrier(0); }
+#endif
+
+SF_DEVICE void w4_tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int GM, int& tm, int& tn) {
+    const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    const int seq = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+    const int per_group = GM * tiles_n;
+    const int g = seq / per_group;
+    const int first_m = g * GM;
+    const int gsize = (tiles_m - first_m < GM) ? (tiles_m - first_m) : GM;
+    const int in_g = seq - g * per_group;
+    tm = first_m + in_g % gsize;
+    tn = in_g / gsize;
+}
+
+template <int OUT_F32, int ADD = 1>
+SF_DEVICE void w4_store4(const GemmW4Args& p, int m, int n, sf_v4f acc) {
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    sf_gemm_store4<OUT_F32, ADD>(p.e, m, n, v);
+}
+
+// ---- slot plans of the fine-grained schedules: which of a K-tile's 128 MFMA slots each non-MFMA instruction follows.
+// A slot holds at most one filler (the MI355X notes: a 16x16x32 MFMA leaves room for ~2 single-issue instructions in
+// its shadow; two ds_read_b128 or a DMA with its address arithmetic in ONE gap overflow it and idle the matrix pipe).
+//   rd1[r] : read of fragment r of (tile t, k-half 1)      -> register set 1   (set 1 is consumed by MFMAs 64..127)
+//   dma[g] : LDS-DMA piece g of tile t+2                    -> buffer t&1
+//   rd0[r] : read of fragment r of (tile t+1, k-half 0)     -> register set 0   (set 0 is consumed by MFMAs 0..63)
+//   bar1   : lgkmcnt(0) + s_barrier after this slot  (every wave's reads of buffer t&1 returned: it may be re-staged)
+//   bar2   : vmcnt + s_barrier after this slot       (every wave's pieces of tile t+1 landed: it may be read)
+// compile-time loop: the body receives std::integral_constant<int, I> (a 128-trip `#pragma unroll` loop with nested
+// conditionals is not reliably unrolled, and runtime-indexed fragment / accumulator arrays would go to scratch)
+template <int I, int N, class F>
+SF_DEVICE void w4_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        w4_static_for<I + 1, N>(f);
+    }
+}
+
+template <class P, class = void> struct w4_has_split : std::false_type {};
+template <class P> struct w4_has_split<P, std::void_t<decltype(P::barB)>> : std::true_type {
+    static constexpr bool barB(int i) { return P::barB == i; }
+    static constexpr bool barA(int i) { return P::barA == i; }
+};
+
+// Plan interface: the MFMA slot (0..127) after which each filler of iteration t is issued.
+//   rd1(r) : read of fragment r (0..7 = B n-tiles, 8..15 = A m-tiles) of (tile t, k-half 1)  -> register set 1
+//   dma(g) : LDS-DMA piece g (0..7 = A rows, 8..15 = B rows) of tile t+2                     -> buffer t&1
+//   rd0(r) : read of fragment r of (tile t+1, k-half 0)                                       -> register set 0
+//   barB / barA : lgkmcnt(0) + s_barrier after these slots (first / second operand half released)
+//   bar2   : counted vmcnt + s_barrier after this slot (tile t+1 published); vm = pieces of THIS iteration in flight then
+struct W4PlanBFirst {   // B (weights) released and re-staged first: faster for narrow N
+    static constexpr int barB = 21, barA = 51, bar1 = -1, bar2 = 108, vm = 16;
+    static constexpr int rd1(int r) {
+        constexpr int s[16] = {0, 2, 4, 6, 8, 10, 12, 14, 24, 27, 30, 33, 36, 39, 42, 45};
+        return s[r];
+    }
+    static constexpr int dma(int g) {
+        constexpr int b[8] = {22, 26, 29, 32, 35, 38, 41, 44};
+        constexpr int a[8] = {53, 59, 65, 71, 77, 83, 89, 95};
+        return g < 8 ? a[g] : b[g - 8];
+    }
+    static constexpr int rd0(int r) { return 110 + r + (r >= 8 ? 1 : 0); }   // 110..117, 119..126
+};
+struct W4PlanAFirst {   // A (activations) first: faster for wide N
+    static constexpr int barB = 21, barA = 51, bar1 = -1, bar2 = 108, vm = 16;
+    static constexpr int rd1(int r) {
+        constexpr int s[16] = {24, 27, 30, 33, 36, 39, 42, 45, 0, 2, 4, 6, 8, 10, 12, 14};
+        return s[r];
+    }
+    static constexpr int dma(int g) {
+        constexpr int first[8] = {22, 26, 29, 32, 35, 38, 41, 44};
+        constexpr int second[8] = {53, 59, 65, 71, 77, 83, 89, 95};
+        return g < 8 ? first[g] : second[g - 8];
+    }
+    static constexpr int rd0(int r) { return 110 + r + (r >= 8 ? 1 : 0); }
+};
+#ifdef SF_ABLATE
+#include "../../tools/experiments/sf_gemm256w4_sched.inc"
+#else
+template <int SCHED> using W4PlanFor = std::conditional_t<SCHED == 13, W4PlanAFirst, W4PlanBFirst>;
+#endif
+
+// SCHED: 12 = W4PlanBFirst, 13 = W4PlanAFirst (product); 0 and 2..11 exist in the tools build only.
+// ABL (tools build, timing ablations of the round-1 schedule only, results are wrong): bit0 = no ds_reads after the first
+// tile, bit1 = no DMA in the loop, ...
+template <int OUT_F32, int ADD = 0, int SCHED = 12, int ABL = 0>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
+    SF_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
+    const int wr = wave >> 1, wc = wave & 1;
+    int tm, tn;
+    w4_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int nkt = p.K / TK;
+
+    // ---- DMA sources: this wave stages pieces 8*wave .. 8*wave+7 (8 rows x 128 B each) of A and of B through raw
+    // buffer descriptors rooted at the tile origin: one 32-bit byte offset per piece and lane (constant over the K
+    // loop), the K advance in the scalar offset.  Rows past the matrix edge re-read the last valid row: they only feed
+    // accumulators that are never stored.
+    const int srow = lane >> 3;
+    const int slc = (lane & 7) ^ (srow & 7);  // logical 16-byte chunk fetched into physical chunk lane&7
+    const SfBuf bufA = sf_make_buf(p.A + (long)m0 * p.lda, 0x7fffffffu);
+    const SfBuf bufB = sf_make_buf(p.B + (long)n0 * p.ldb, 0x7fffffffu);
+    unsigned voff[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int ra = (8 * wave + j) * 8 + srow, rb = ra;
+        ra = m0 + ra < p.M ? ra : p.M - 1 - m0;
+        rb = n0 + rb < p.N ? rb : p.N - 1 - n0;
+        voff[j] = (unsigned)(((long)ra * p.lda + slc * 8) * 2);
+        voff[8 + j] = (unsigned)(((long)rb * p.ldb + slc * 8) * 2);
+    }
+    auto dma = [&](int g, int kt) {  // piece g (0..7 A, 8..15 B) of K-tile kt into buffer kt&1
+        char* dst = smem + (kt & 1) * kBufBytes + (g >> 3) * kOpBytes + (8 * wave + (g & 7)) * 1024;
+        sf_buf_glds16(g < 8 ? bufA : bufB, voff[g], (unsigned)kt * (TK * 2), dst);
+    };
+
+    // ---- fragment read offsets; (row & 7) == (lane & 7) for every fragment row
+    const int frow = lane & 15;
+    int swz[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) swz[ks] = ((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
+    const int a_off = (wr * 128 + frow) * 128;
+    const int b_off = kOpBytes + (wc * 128 + frow) * 128;
+
+    sf_v4f acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
+    if (ADD) {
+        // row-mapped fp32 addend: START the accumulators from it (alpha == 1 is enforced by the launcher), so the
+        // K loop and the epilogue are exactly the plain kernel's -- the loads overlap the staging of K-tiles 0 and 1
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+            if (m < p.M) {
+                const int bb = m / p.e.add_S;
+                const float* a = p.e.Cadd + ((long)bb * p.e.add_Spad + (m - bb * p.e.add_S) + p.e.add_off) * p.e.ldadd;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = n0 + wc * 128 + j * 16 + 4 * (lane >> 4);
+                    if (n + 3 < p.N) acc[i][j] = *reinterpret_cast<const sf_v4f*>(a + n);
+                    else
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < p.N) acc[i][j][r] = a[n + r];
+                }
+            }
+        }
+    }
+    sf_v8s f[2][16];  // [set][0..7 = B n-tiles, 8..15 = A m-tiles]
+
+    auto read_frag = [&](int set, int g, const char* buf, int ks) {
+        if (g < 8) f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + b_off + g * 2048 + swz[ks]);
+        else f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + a_off + (g - 8) * 2048 + swz[ks]);
+    };
+
+    // ---- prologue: K-tiles 0 and 1 staged, fragments of k-half 0 of tile 0 in registers
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dma(g, 0);
+    if (nkt > 1) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dma(g, 1);
+    }
+    w4_wait_all();
+    w4_barrier();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) read_frag(0, g, smem, 0);
+
+    // ---- one K-tile by plan P: READ_NEXT = tile t+1 exists, DO_DMA = tile t+2 exists
+    auto tilep = [&](auto PLAN, auto READ_NEXT, auto DO_DMA, int t) {
+        using P = decltype(PLAN);
+        const char* cur = smem + (t & 1) * kBufBytes;
+        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
+        w4_static_for<0, 128>([&](auto I) SF_INLINE_LAMBDA {
+            constexpr int i = decltype(I)::value, idx = i & 63, mt = idx >> 3, nt = idx & 7;
+            // accumulators pinned to AGPRs (asm form): the builtin's allocation does not survive this interleave
+            if constexpr (i < 64) sf_mfma16_acc(f[0][nt], f[0][8 + mt], acc[mt][nt]);
+            else sf_mfma16_acc(f[1][nt], f[1][8 + mt], acc[mt][nt]);
+            w4_fence();
+            w4_static_for<0, 16>([&](auto R) SF_INLINE_LAMBDA {
+                constexpr int r = decltype(R)::value;
+                if constexpr (P::rd1(r) == i) read_frag(1, r, cur, 1);
+            });
+            if constexpr (P::bar1 == i && P::bar1 != P::bar2) { w4_wait_lgkm(); w4_barrier(); }
+            if constexpr (w4_has_split<P>::value) {
+                if constexpr (w4_has_split<P>::barB(i) || w4_has_split<P>::barA(i)) { w4_wait_lgkm(); w4_barrier(); }
+            }
+            if constexpr (decltype(DO_DMA)::value) {
+                w4_static_for<0, 16>([&](auto G) SF_INLINE_LAMBDA {
+                    constexpr int g = decltype(G)::value;
+                    if constexpr (P::dma(g) == i) dma(g, t + 2);
+                });
+            }
+            if constexpr (P::bar2 == i) {
+                if constexpr (P::bar1 == P::bar2) w4_wait_all();
+                else if constexpr (decltype(DO_DMA)::value && P::vm == 16) w4_wait_vm16();
+                else w4_wait_vm0();
+                w4_barrier();
+            }
+            if constexpr (decltype(READ_NEXT)::value) {
+                w4_static_for<0, 16>([&](auto R) SF_INLINE_LAMBDA {
+                    constexpr int r = decltype(R)::value;
+                    if constexpr (P::rd0(r) == i) read_frag(0, r, nxt, 0);
+                });
+            }
+            w4_fence();
+        });
+    };
+
+#ifdef SF_ABLATE
+    if constexpr (SCHED == 0) {
+#include "../../tools/experiments/sf_gemm256w4_sched0.inc"
+    } else
+#endif
+    {
+        using P = W4PlanFor<SCHED>;
+        int t = 0;
+        for (; t + 2 < nkt; ++t) tilep(P{}, std::true_type{}, std::true_type{}, t);
+        if (t + 1 < nkt) { tilep(P{}, std::true_type{}, std::false_type{}, t); ++t; }
+        tilep(P{}, std::false_type{}, std::false_type{}, t);
+        sf_mfma_drain();   // asm MFMAs are invisible to the hazard recogniser: let the last ones retire before acc is read
+    }
+
+    // ---- epilogue: lane owns C[m][n..n+3]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            w4_store4<OUT_F32, 0>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
+}
+
+#ifdef SF_ABLATE
+#include "../../tools/experiments/sf_gemm256w4_variants.inc"
+#endif
+
+}  // namespace
+
+// one launch function per instantiation; each lives in its own translation unit (sf_gemm256w4_i*.hip) so that the
+// eight 128-slot kernels compile in parallel (~25 s each; together in one unit they took > 10 minutes)
+#define SF_W4_DECLARE(F32, ADD, SCHED) int sf_w4_launch_##F32##_##ADD##_##SCHED(const GemmW4Args& p, long nblk, void* stream)
+#define SF_W4_DEFINE(F32, ADD, SCHED)                                                                                  \
+    SF_W4_DECLARE(F32, ADD, SCHED) {                                                                                   \
+        SF_W4_SMEM((gemm_nt_256w4_kernel<F32, ADD, SCHED>));                                                           \
+        SF_LAUNCH((gemm_nt_256w4_kernel<F32, ADD, SCHED>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p); \
+        return sf_check_launch("sf_gemm_nt(256w4)");                                                                   \
+    }
+SF_W4_DECLARE(0, 0, 12); SF_W4_DECLARE(0, 0, 13); SF_W4_DECLARE(1, 0, 12); SF_W4_DECLARE(1, 0, 13);
+SF_W4_DECLARE(0, 1, 12); SF_W4_DECLARE(0, 1, 13); SF_W4_DECLARE(1, 1, 12); SF_W4_DECLARE(1, 1, 13);

@@ -16,7 +16,8 @@ _lib._emulated = False
 dev = "cuda"
 variants = sys.argv[1:] or ["base"]
 SHAPES = [(16384, 4096, 4096), (16384, 4096, 14336), (16384, 28672, 4096), (16384, 32000, 4096), (16384, 4096, 32000),
-          (16384, 14336, 4096), (8192, 8192, 8192)]
+          (16384, 14336, 4096), (8192, 8192, 8192), (16384, 4096, 6144), (16384, 4096, 12288), (4096, 128256, 4096),
+          (16384, 4096, 28672)]
 ROUNDS = 5
 
 
