@@ -64,6 +64,7 @@ SF_DEVICE void tn_tile_coords(int bid, int nblk, int tiles_m, int tiles_n, int G
     tn = in_g / gsize;
 }
 
+#ifdef SF_ABLATE   // round-1 schedule (one barrier per K-tile, vmcnt(0)): tools build only, SF_GEMM_TN_PLAN=-1
 template <int OUT_F32, int SPREAD = 0>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4_kernel(GemmTnArgs p) {
     SF_DYN_SMEM(smem);
@@ -190,6 +191,173 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4_kernel(GemmTnArgs p) {
         }
 }
 
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 2: the same kernel under the plan-scheduled main loop of sf_gemm256w4_kernel.h -- every non-MFMA instruction in
+// its own MFMA slot, the two operands' LDS halves released separately (3 barriers), counted vmcnt(16), DMA lead 1.1-1.6
+// iterations, buffer-descriptor LDS-DMA from inline asm with the K advance on the descriptor base (a scalar 64-bit add
+// per operand and K-tile; the per-lane offsets are loop constants).  A K-tile here carries 64 transposed fragment reads
+// (two ds_read_b64_tr_b16 per fragment), so the plan is denser: reads take one slot each.
+//   rd1(r), rd0(r): r = 2*fragment + half (fragments 0..7 = B n-tiles, 8..15 = A m-tiles; half 0 = k 0..3, 1 = k 4..7 of
+//   each 8-k group)
+template <int AFIRST>
+struct TnPlan {
+    static constexpr int barB = 21, barA = 51, bar2 = 92, vm = 16;
+    static constexpr int first(int r) { return r; }                                   // 0 .. 15: first operand, k-half 1
+    static constexpr int second(int r) { return 23 + r + r / 2; }                     // 23,24,26,27,...,44,45 (DMA in between)
+    static constexpr int rd1(int r) {
+        const bool isA = r >= 16;
+        return (isA == (AFIRST != 0)) ? first(r & 15) : second(r & 15);
+    }
+    static constexpr int dma(int g) {      // pieces 0..7 = A halves, 8..15 = B halves
+        constexpr int early[8] = {22, 25, 28, 31, 34, 37, 40, 43};
+        constexpr int late[8] = {53, 58, 63, 68, 73, 78, 83, 88};
+        const bool isA = g < 8;
+        return (isA == (AFIRST != 0)) ? early[g & 7] : late[g & 7];
+    }
+    static constexpr int rd0(int r) { return 94 + r; }                                // 94 .. 125, one read per slot
+};
+
+// slot -> filler lookups, evaluated by the constant evaluator (no template instantiation per candidate)
+template <class P> constexpr int tn_rd1_at(int i) { for (int r = 0; r < 32; ++r) if (P::rd1(r) == i) return r; return -1; }
+template <class P> constexpr int tn_rd0_at(int i) { for (int r = 0; r < 32; ++r) if (P::rd0(r) == i) return r; return -1; }
+template <class P> constexpr int tn_dma_at(int i) { for (int g = 0; g < 16; ++g) if (P::dma(g) == i) return g; return -1; }
+
+template <int I, int N, class F>
+SF_DEVICE void tn_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        tn_static_for<I + 1, N>(f);
+    }
+}
+#define SF_TN_LAMBDA __attribute__((always_inline))
+#ifdef SF_EMU
+SF_DEVICE void tn_wait_lgkm() {}
+SF_DEVICE void tn_wait_vm16() {}
+SF_DEVICE void tn_wait_vm0() {}
+#else
+SF_DEVICE void tn_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+SF_DEVICE void tn_wait_vm16() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+SF_DEVICE void tn_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+
+template <int OUT_F32, int AFIRST>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4p_kernel(GemmTnArgs p) {
+    using P = TnPlan<AFIRST>;
+    SF_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
+    const int wr = wave >> 1, wc = wave & 1;
+    int tm, tn;
+    tn_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int nkt = p.K / TK / p.ksplit;
+    const long k0 = (long)blockIdx.y * nkt * TK;      // first contraction row of this split
+    if (p.ksplit > 1) {                               // partial sums go to the fp32 workspace, plain store
+        p.e.C = p.ws + (long)blockIdx.y * p.M * p.N;
+        p.e.ldc = p.N;
+        p.e.alpha = 1.f;
+        p.e.beta = 0.f;
+    }
+
+    // ---- DMA sources: half hh (0,1 = A columns m0+0.., m0+128..; 2,3 = B) is 16 pieces of 4 k-rows x 256 B; this wave
+    // stages pieces 4*wave .. 4*wave+3 of every half.  Lane: k-row skr = lane>>4 of the piece, physical chunk lane&15.
+    // Per-lane byte offset from the K-tile's first row of the operand (loop constant); the descriptor base advances.
+    const int skr = lane >> 4;
+    unsigned voff[16];
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int krow = (4 * wave + j) * 4 + skr;
+            const int hk = (krow & 3) | (((krow >> 3) & 1) << 2);
+            const int lc = (lane & 15) ^ (hk << 1);            // logical 16-byte chunk fetched into physical chunk lane&15
+            const bool isA = hh < 2;
+            const int dim = isA ? p.M : p.N;
+            int col = (isA ? m0 : n0) + (hh & 1) * 128 + lc * 8;
+            col = col + 8 <= dim ? col : dim - 8;
+            voff[hh * 4 + j] = (unsigned)(((long)krow * (isA ? p.lda : p.ldb) + col) * 2);
+        }
+    const sf_bf16* baseA = p.A + k0 * p.lda;
+    const sf_bf16* baseB = p.B + k0 * p.ldb;
+    const long incA = (long)TK * p.lda, incB = (long)TK * p.ldb;
+    auto dma = [&](int g, int kt) {  // g = hh*4 + j: piece 4*wave+j of half hh of K-tile kt
+        char* dst = smem + (kt & 1) * kBufBytes + (g >> 2) * kHalfBytes + (4 * wave + (g & 3)) * 1024;
+        const SfBufRaw b = sf_make_buf_raw(g < 8 ? baseA + (long)kt * incA : baseB + (long)kt * incB);
+        sf_buf_glds16_opaque(b, voff[g], 0u, dst);
+    };
+
+    // ---- fragment reads (transposed): lane constants of ds_read_b64_tr_b16 into the [64 k][256 B] image
+    const int fi = lane & 15, fg = lane >> 4;
+    const int fh = (fi >> 2) | ((fg & 1) << 2);
+    const int frag_lane = (8 * fg + (fi >> 2)) * 256 + ((fi >> 1) & 1) * 16 + (fi & 1) * 8;
+    const int a_half = wr * kHalfBytes, b_half = (2 + wc) * kHalfBytes;
+
+    sf_v4f acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
+    sf_v4s flo[2][16], fup[2][16];  // [set][0..7 = B n-tiles, 8..15 = A m-tiles]: k 0..3 / k 4..7 of each lane's 8-k group
+
+    auto read_half = [&](int set, int g, const char* buf, int ks, int half) {
+        const char* a = buf + (g < 8 ? b_half : a_half) + ks * (32 * 256) + frag_lane + ((((g & 7)) ^ fh) << 5);
+        if (half == 0) flo[set][g] = sf_ds_read_tr16(a);
+        else fup[set][g] = sf_ds_read_tr16(a + 4 * 256);
+    };
+    auto frag = [&](int set, int g) {
+        const sf_v4s lo = flo[set][g], up = fup[set][g];
+        return sf_v8s{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+    };
+
+    // ---- prologue
+#pragma unroll
+    for (int g = 0; g < 16; ++g) dma(g, 0);
+    if (nkt > 1) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dma(g, 1);
+    }
+    tn_wait_all();
+    tn_barrier();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) { read_half(0, g, smem, 0, 0); read_half(0, g, smem, 0, 1); }
+
+    auto tilep = [&](auto READ_NEXT, auto DO_DMA, int t) {
+        const char* cur = smem + (t & 1) * kBufBytes;
+        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
+        tn_static_for<0, 128>([&](auto I) SF_TN_LAMBDA {
+            constexpr int i = decltype(I)::value, idx = i & 63, mt = idx >> 3, nt = idx & 7, set = i >> 6;
+            sf_mfma16_acc(frag(set, nt), frag(set, 8 + mt), acc[mt][nt]);
+            tn_fence();
+            constexpr int r1 = tn_rd1_at<P>(i), r0 = tn_rd0_at<P>(i), gd = tn_dma_at<P>(i);
+            if constexpr (r1 >= 0) read_half(1, r1 >> 1, cur, 1, r1 & 1);
+            if constexpr (P::barB == i || P::barA == i) { tn_wait_lgkm(); tn_barrier(); }
+            if constexpr (decltype(DO_DMA)::value && gd >= 0) dma(gd, t + 2);
+            if constexpr (P::bar2 == i) {
+                if constexpr (decltype(DO_DMA)::value) tn_wait_vm16(); else tn_wait_vm0();
+                tn_barrier();
+            }
+            if constexpr (decltype(READ_NEXT)::value && r0 >= 0) read_half(0, r0 >> 1, nxt, 0, r0 & 1);
+            tn_fence();
+        });
+    };
+
+    int t = 0;
+    for (; t + 2 < nkt; ++t) tilep(std::true_type{}, std::true_type{}, t);
+    if (t + 1 < nkt) { tilep(std::true_type{}, std::false_type{}, t); ++t; }
+    tilep(std::false_type{}, std::false_type{}, t);
+
+    // ---- epilogue: lane owns C[m][n..n+3]
+    sf_mfma_drain();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            sf_gemm_store4<OUT_F32, 0>(p.e, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), v);
+        }
+}
+
 // C = alpha * sum_y ws[y] (+ beta * C): deterministic fixed-order reduction of the split-K partials
 template <int OUT_F32>
 SF_GLOBAL void tn_splitk_reduce_kernel(const float* ws, int ksplit, void* C, long ldc, int M, int N, float alpha, float beta) {
@@ -270,31 +438,38 @@ extern "C" int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void
                                           "number of 64-row K-tiles, and N % 4 == 0");
         if (fits && ksplit != 1 && (helps || ksplit == 2)) { p.ksplit = 2; p.ws = workspace; }
     }
-    if (p.ksplit > 1) {
-        SF_TN_SMEM((gemm_tn_256w4_kernel<1>));
-        SF_LAUNCH((gemm_tn_256w4_kernel<1>), dim3((unsigned)nblk, (unsigned)p.ksplit), dim3(256), 2 * kBufBytes, stream, p);
-        const long units = (long)M * (N / 4);
-        const int grid = (int)((units + 255) / 256 < 2048 ? (units + 255) / 256 : 2048);
-        if (c_dtype == SF_F32)
-            SF_LAUNCH((tn_splitk_reduce_kernel<1>), dim3(grid), dim3(256), 0, stream, (const float*)p.ws, p.ksplit, C, ldc, M, N, alpha, beta);
-        else
-            SF_LAUNCH((tn_splitk_reduce_kernel<0>), dim3(grid), dim3(256), 0, stream, (const float*)p.ws, p.ksplit, C, ldc, M, N, alpha, beta);
-        return sf_check_launch("sf_gemm_tn(split-K)");
-    }
+    // plan: which operand's LDS halves are released / re-staged first (0 = B, 1 = A); tools build: -1 = round-1 kernel
+    const int plan = sf_knob("SF_GEMM_TN_PLAN", 0);
+    const bool f32_main = p.ksplit > 1 || c_dtype == SF_F32;
+    const dim3 grid((unsigned)nblk, (unsigned)p.ksplit);
+#define SF_TN_CASE(F32, AF)                                                                                           \
+    if (f32_main == (F32 != 0) && plan == AF) {                                                                      \
+        SF_TN_SMEM((gemm_tn_256w4p_kernel<F32, AF>));                                                                \
+        SF_LAUNCH((gemm_tn_256w4p_kernel<F32, AF>), grid, dim3(256), 2 * kBufBytes, stream, p);                      \
+    } else
+    SF_TN_CASE(0, 0) SF_TN_CASE(1, 0) SF_TN_CASE(0, 1) SF_TN_CASE(1, 1)
+#undef SF_TN_CASE
+    {
 #ifdef SF_ABLATE
-    static const bool spread = sf_knob("SF_GEMM_TN_SPREAD", 0) == 1;
-    if (spread && c_dtype != SF_F32) {
-        SF_TN_SMEM((gemm_tn_256w4_kernel<0, 1>));
-        SF_LAUNCH((gemm_tn_256w4_kernel<0, 1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
-        return sf_check_launch("sf_gemm_tn(spread)");
-    }
+        if (f32_main) {
+            SF_TN_SMEM((gemm_tn_256w4_kernel<1>));
+            SF_LAUNCH((gemm_tn_256w4_kernel<1>), grid, dim3(256), 2 * kBufBytes, stream, p);
+        } else {
+            SF_TN_SMEM((gemm_tn_256w4_kernel<0>));
+            SF_LAUNCH((gemm_tn_256w4_kernel<0>), grid, dim3(256), 2 * kBufBytes, stream, p);
+        }
+#else
+        SF_CHECK_ARG(false, "sf_gemm_tn: no kernel for this configuration");
 #endif
-    if (c_dtype == SF_F32) {
-        SF_TN_SMEM((gemm_tn_256w4_kernel<1>));
-        SF_LAUNCH((gemm_tn_256w4_kernel<1>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
-    } else {
-        SF_TN_SMEM((gemm_tn_256w4_kernel<0>));
-        SF_LAUNCH((gemm_tn_256w4_kernel<0>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);
+    }
+    if (p.ksplit > 1) {
+        const long units = (long)M * (N / 4);
+        const int rgrid = (int)((units + 255) / 256 < 2048 ? (units + 255) / 256 : 2048);
+        if (c_dtype == SF_F32)
+            SF_LAUNCH((tn_splitk_reduce_kernel<1>), dim3(rgrid), dim3(256), 0, stream, (const float*)p.ws, p.ksplit, C, ldc, M, N, alpha, beta);
+        else
+            SF_LAUNCH((tn_splitk_reduce_kernel<0>), dim3(rgrid), dim3(256), 0, stream, (const float*)p.ws, p.ksplit, C, ldc, M, N, alpha, beta);
+        return sf_check_launch("sf_gemm_tn(split-K)");
     }
     return sf_check_launch("sf_gemm_tn");
 }

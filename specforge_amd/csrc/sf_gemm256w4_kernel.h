@@ -112,6 +112,11 @@ SF_DEVICE void w4_store4(const GemmW4Args& p, int m, int n, sf_v4f acc) {
 //   bar2   : vmcnt + s_barrier after this slot       (every wave's pieces of tile t+1 landed: it may be read)
 // compile-time loop: the body receives std::integral_constant<int, I> (a 128-trip `#pragma unroll` loop with nested
 // conditionals is not reliably unrolled, and runtime-indexed fragment / accumulator arrays would go to scratch)
+// slot -> filler lookups, evaluated by the constant evaluator (no template instantiation per candidate)
+template <class P> constexpr int w4_rd1_at(int i) { for (int r = 0; r < 16; ++r) if (P::rd1(r) == i) return r; return -1; }
+template <class P> constexpr int w4_rd0_at(int i) { for (int r = 0; r < 16; ++r) if (P::rd0(r) == i) return r; return -1; }
+template <class P> constexpr int w4_dma_at(int i) { for (int g = 0; g < 16; ++g) if (P::dma(g) == i) return g; return -1; }
+
 template <int I, int N, class F>
 SF_DEVICE void w4_static_for(F&& f) {
     if constexpr (I < N) {
@@ -262,32 +267,20 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
             if constexpr (i < 64) sf_mfma16_acc(f[0][nt], f[0][8 + mt], acc[mt][nt]);
             else sf_mfma16_acc(f[1][nt], f[1][8 + mt], acc[mt][nt]);
             w4_fence();
-            w4_static_for<0, 16>([&](auto R) SF_INLINE_LAMBDA {
-                constexpr int r = decltype(R)::value;
-                if constexpr (P::rd1(r) == i) read_frag(1, r, cur, 1);
-            });
+            constexpr int r1 = w4_rd1_at<P>(i), r0 = w4_rd0_at<P>(i), gd = w4_dma_at<P>(i);
+            if constexpr (r1 >= 0) read_frag(1, r1, cur, 1);
             if constexpr (P::bar1 == i && P::bar1 != P::bar2) { w4_wait_lgkm(); w4_barrier(); }
             if constexpr (w4_has_split<P>::value) {
                 if constexpr (w4_has_split<P>::barB(i) || w4_has_split<P>::barA(i)) { w4_wait_lgkm(); w4_barrier(); }
             }
-            if constexpr (decltype(DO_DMA)::value) {
-                w4_static_for<0, 16>([&](auto G) SF_INLINE_LAMBDA {
-                    constexpr int g = decltype(G)::value;
-                    if constexpr (P::dma(g) == i) dma(g, t + 2);
-                });
-            }
+            if constexpr (decltype(DO_DMA)::value && gd >= 0) dma(gd, t + 2);
             if constexpr (P::bar2 == i) {
                 if constexpr (P::bar1 == P::bar2) w4_wait_all();
                 else if constexpr (decltype(DO_DMA)::value && P::vm == 16) w4_wait_vm16();
                 else w4_wait_vm0();
                 w4_barrier();
             }
-            if constexpr (decltype(READ_NEXT)::value) {
-                w4_static_for<0, 16>([&](auto R) SF_INLINE_LAMBDA {
-                    constexpr int r = decltype(R)::value;
-                    if constexpr (P::rd0(r) == i) read_frag(0, r, nxt, 0);
-                });
-            }
+            if constexpr (decltype(READ_NEXT)::value && r0 >= 0) read_frag(0, r0, nxt, 0);
             w4_fence();
         });
     };

@@ -59,6 +59,12 @@ SF_DEVICE void sf_buf_glds16(SfBuf b, unsigned voff, unsigned soff, void* l) {
     static const char zero16[16] = {0};
     sfemu::global_load_lds16(voff + 16 <= b.bytes ? b.base + voff + soff : zero16, l);
 }
+// raw descriptor for the asm (compiler-opaque) buffer LDS-DMA: base may move by a scalar add per K-tile
+struct SfBufRaw { const char* base; };
+SF_DEVICE SfBufRaw sf_make_buf_raw(const void* base) { return SfBufRaw{(const char*)base}; }
+SF_DEVICE void sf_buf_glds16_opaque(SfBufRaw b, unsigned voff, unsigned soff, void* l) {
+    sfemu::global_load_lds16(b.base + voff + soff, l);
+}
 SF_DEVICE int sf_wave_id() { return sfemu::wave_index(); }
 SF_DEVICE sf_v4s sf_ds_read_tr16(const void* l) { return sfemu::ds_read_tr16_b64(l); }
 SF_DEVICE bool sf_all(bool pred) {
@@ -148,6 +154,22 @@ SF_DEVICE void sf_buf_glds16(SfBuf b, unsigned voff, unsigned soff, void* l) {
 SF_DEVICE void sf_glds16_opaque(const void* g, void* l) {
     const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds) : "memory", "m0");
+}
+// Buffer-descriptor LDS-DMA as inline asm (both properties at once: scalar K advance AND invisible to the compiler's
+// LDS ordering).  The descriptor is assembled by hand: {base[31:0], base[47:32] (stride 0), num_records = 2^31-1,
+// DST_SEL/format word 0x00020000}; every field must be wave-uniform.
+typedef int sf_v4i __attribute__((ext_vector_type(4)));
+struct SfBufRaw { sf_v4i w; };
+SF_DEVICE SfBufRaw sf_make_buf_raw(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    SfBufRaw b;
+    b.w = sf_v4i{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), 0x7fffffff, 0x00020000};
+    return b;
+}
+SF_DEVICE void sf_buf_glds16_opaque(SfBufRaw b, unsigned voff, unsigned soff, void* l) {
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 : : "v"(voff), "s"(b.w), "s"(soff), "s"(lds) : "memory", "m0");
 }
 // Workgroup-level arrive / wait on a monotonic LDS counter: a barrier whose "arrive" and "wait" halves are separate
 // program points (gfx950 has no split s_barrier).  arrive = release (everything this wave did to LDS is complete),
