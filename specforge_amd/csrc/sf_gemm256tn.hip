@@ -438,8 +438,10 @@ extern "C" int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void
                                           "number of 64-row K-tiles, and N % 4 == 0");
         if (fits && ksplit != 1 && (helps || ksplit == 2)) { p.ksplit = 2; p.ws = workspace; }
     }
-    // plan: which operand's LDS halves are released / re-staged first (0 = B, 1 = A); tools build: -1 = round-1 kernel
-    const int plan = sf_knob("SF_GEMM_TN_PLAN", 0);
+    // plan: which operand's LDS halves are released / re-staged first (0 = B, 1 = A).  Measured on the step's shapes
+    // (profiles/r2_gemm_tn_ab.jsonl): A first wins for the widest dY (lm_head, M = 32000) and for wide X (down, N = 14336),
+    // B first elsewhere; both beat the round-1 schedule (tools build: SF_GEMM_TN_PLAN=-1) by 3-8 %.
+    const int plan = sf_knob("SF_GEMM_TN_PLAN", (N > 8192 || M > 30000) ? 1 : 0);
     const bool f32_main = p.ksplit > 1 || c_dtype == SF_F32;
     const dim3 grid((unsigned)nblk, (unsigned)p.ksplit);
 #define SF_TN_CASE(F32, AF)                                                                                           \
