@@ -191,6 +191,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        out = None
         for i in range(nsteps):
             out = step(i)
         torch.cuda.synchronize()
