@@ -30,6 +30,7 @@ namespace {
 constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int kHalfBytes = 128 * TK * 2;     // 16 KiB: [64 k][256 B]
 constexpr int kBufBytes = 4 * kHalfBytes;    // A0 A1 B0 B1
+constexpr long kTnSyncFloats = 4096;         // 16 KiB of pace counters at the tail of the caller's workspace
 
 struct GemmTnArgs {
     const sf_bf16* A; long lda;   // [K, M]
@@ -40,6 +41,10 @@ struct GemmTnArgs {
     int gm;
     int ksplit;       // > 1: blockIdx.y contracts K-range [y*K/ksplit, (y+1)*K/ksplit) into fp32 partial y of `ws`
     float* ws;        // [ksplit][M][N] fp32 partials (split-K only)
+    // pace-keeping of the workgroups that share operand panels in one XCD's L2 (null = off): one zero-initialised
+    // counter per group of 32 consecutive tiles of an XCD, bumped every `sync_every` K-tiles
+    unsigned* sync;
+    int sync_every;   // power of two
 };
 
 #ifdef SF_EMU
@@ -201,6 +206,44 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4_kernel(GemmTnArgs p) {
 // (two ds_read_b64_tr_b16 per fragment), so the plan is denser: reads take one slot each.
 //   rd1(r), rd0(r): r = 2*fragment + half (fragments 0..7 = B n-tiles, 8..15 = A m-tiles; half 0 = k 0..3, 1 = k 4..7 of
 //   each 8-k group)
+// Pace group of a workgroup: the (up to) 32 workgroups with consecutive sequence numbers on one XCD run concurrently on
+// that XCD's 32 CUs and share 4 A panels and 8 B panels through its L2 -- as long as they stay within the ~10 K-tiles
+// the 4 MiB hold.  Nothing keeps them there: the DMA lead of this kernel hides exactly the latency differences that
+// would otherwise slow a runaway tile down, and over 1792 K-tiles (K = 114 688) the members drift apart until every
+// tile streams its own copy of the panels (measured: 39.6 GB of L2 misses per launch against 17.4 GB with perfect
+// sharing).  So every `sync_every` K-tiles the members meet at a counter in global memory: wave 0 ARRIVES 8 iterations
+// early (fire-and-forget atomic) and polls at the rendezvous iteration; the other waves are held by the loop's own
+// barriers.  No data passes through it -- it only aligns timing -- so there is no ordering requirement and a bounded
+// spin (then pacing is switched off for the rest of the tile) makes it deadlock-free whatever the placement.
+struct TnPace { unsigned* ctr; unsigned members; };
+SF_DEVICE TnPace tn_pace_group(unsigned* base, int bid, int y, int nblk, int ksplit) {
+    // groups follow the LINEAR dispatch order (y-major), 32 per XCD at a time = one "generation" of co-resident
+    // workgroups; with split-K the launcher enables pacing only when nblk % 8 == 0 (then block (x, y) sits on XCD x % 8)
+    const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7;
+    const int cnt = ksplit > 1 ? ksplit * q : q + (xcd < rem ? 1 : 0);
+    const int idx = y * q + (bid >> 3);
+    const int per_xcd = (ksplit * (q + 1) + 31) >> 5;      // groups per XCD (upper bound)
+    const int gl = idx >> 5;
+    const int left = cnt - (gl << 5);
+    TnPace g;
+    g.ctr = base + (xcd * per_xcd + gl);
+    g.members = (unsigned)(left < 32 ? left : 32);
+    return g;
+}
+#ifdef SF_EMU
+SF_DEVICE void tn_pace_arrive(TnPace) {}
+SF_DEVICE bool tn_pace_wait(TnPace, unsigned) { return true; }
+#else
+SF_DEVICE void tn_pace_arrive(TnPace g) { __hip_atomic_fetch_add(g.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SF_DEVICE bool tn_pace_wait(TnPace g, unsigned target) {   // false = gave up
+    for (int spin = 0; spin < 4096; ++spin) {              // <= ~1 ms
+        if (__hip_atomic_load(g.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+}
+#endif
+
 template <int AFIRST>
 struct TnPlan {
     static constexpr int barB = 21, barA = 51, bar2 = 92, vm = 16;
@@ -342,8 +385,21 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4p_kernel(GemmTnArgs p) {
         });
     };
 
+    bool pace = p.sync != nullptr && wave == 0;
+    const TnPace pg = tn_pace_group(p.sync, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, p.ksplit);
+    const int pmask = p.sync_every - 1;
     int t = 0;
-    for (; t + 2 < nkt; ++t) tilep(std::true_type{}, std::true_type{}, t);
+    for (; t + 2 < nkt; ++t) {
+        if (pace) {
+            if ((t & pmask) == pmask - 8 && lane == 0) tn_pace_arrive(pg);
+            if ((t & pmask) == pmask) {
+                bool ok = true;
+                if (lane == 0) ok = tn_pace_wait(pg, pg.members * (unsigned)((t >> __builtin_ctz((unsigned)p.sync_every)) + 1));
+                pace = sf_all(ok);
+            }
+        }
+        tilep(std::true_type{}, std::true_type{}, t);
+    }
     if (t + 1 < nkt) { tilep(std::true_type{}, std::false_type{}, t); ++t; }
     tilep(std::false_type{}, std::false_type{}, t);
 
@@ -438,10 +494,24 @@ extern "C" int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void
                                           "number of 64-row K-tiles, and N % 4 == 0");
         if (fits && ksplit != 1 && (helps || ksplit == 2)) { p.ksplit = 2; p.ws = workspace; }
     }
+    // pace-keeping counters: the last kTnSyncFloats floats of the workspace (when it is large enough), zeroed per launch
+    p.sync = nullptr;
+    p.sync_every = sf_knob("SF_GEMM_TN_SYNC", 128);
+#ifndef SF_EMU
+    {
+        const long need = (p.ksplit > 1 ? 2L * M * N : 0L) + kTnSyncFloats;
+        const bool pow2 = p.sync_every >= 16 && (p.sync_every & (p.sync_every - 1)) == 0;
+        if (workspace && workspace_floats >= need && pow2 && K / TK / p.ksplit >= 2 * p.sync_every && nblk >= 64 &&
+            (p.ksplit == 1 || nblk % 8 == 0)) {
+            p.sync = reinterpret_cast<unsigned*>(workspace + workspace_floats - kTnSyncFloats);
+            if (hipMemsetAsync(p.sync, 0, kTnSyncFloats * sizeof(float), (hipStream_t)stream) != hipSuccess) p.sync = nullptr;
+        }
+    }
+#endif
     // plan: which operand's LDS halves are released / re-staged first (0 = B, 1 = A).  Measured on the step's shapes
-    // (profiles/r2_gemm_tn_ab.jsonl): A first wins for the widest dY (lm_head, M = 32000) and for wide X (down, N = 14336),
-    // B first elsewhere; both beat the round-1 schedule (tools build: SF_GEMM_TN_PLAN=-1) by 3-8 %.
-    const int plan = sf_knob("SF_GEMM_TN_PLAN", (N > 8192 || M > 30000) ? 1 : 0);
+    // (profiles/r2_gemm_tn_ab.jsonl): A first wins for wide X (down-proj, N = 14336), B first elsewhere; both beat the
+    // round-1 schedule (tools build: SF_GEMM_TN_PLAN=-1) by 3-8 %.
+    const int plan = sf_knob("SF_GEMM_TN_PLAN", N > 8192 ? 1 : 0);
     const bool f32_main = p.ksplit > 1 || c_dtype == SF_F32;
     const dim3 grid((unsigned)nblk, (unsigned)p.ksplit);
 #define SF_TN_CASE(F32, AF)                                                                                           \

@@ -222,7 +222,8 @@ class Eagle3Engine:
         b["nws"] = cv("nws", ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)
         b["nws_e"] = cv("nws_e", ops.rmsnorm_bwd_workspace(Np, H), dtype=f32)
         # fp32 partials for the 2-way split-K of weight-gradient GEMMs whose tile count fills the CUs badly (down, q|k|v)
-        b["tn_ws"] = cv("tn_ws", 2 * max(H * I, self.QW * H), dtype=f32)
+        # (+ 4096 floats at the tail: pace-keeping counters of sf_gemm_tn)
+        b["tn_ws"] = cv("tn_ws", 2 * max(H * I, self.QW * H) + 4096, dtype=f32)
         return b
 
     def _refresh_weight_transposes(self):

@@ -43,7 +43,7 @@ for (M, N, Kk) in SHAPES:
     a = torch.randn(Kk, M, device=dev).to(torch.bfloat16)
     b = torch.randn(Kk, N, device=dev).to(torch.bfloat16)
     c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    ws = torch.empty(2 * M * N, device=dev)
+    ws = torch.empty(2 * M * N + 4096, device=dev)
     ref = None
     res = {v: [] for v in variants}
     for r in range(ROUNDS + 1):
