@@ -40,7 +40,7 @@ LLAMA3_8B = dict(hidden_size=4096, intermediate_size=14336, num_attention_heads=
 SMALL = dict(hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=2, vocab_size=4096,
              draft_vocab_size=1024, head_dim=128, target_hidden_size=512, max_position_embeddings=2048, rms_norm_eps=1e-5)
 PEAK_BF16_TFLOPS = 2500.0
-GEMM_KERNEL_NAME = "gemm_nt_256w4_kernel (bf16 MFMA GEMM, 256x256x64, 4 waves x 128x128, software-pipelined)"
+GEMM_KERNEL_NAME = "gemm_nt_256w4_kernel (bf16 MFMA GEMM, 256x256x64, 4 waves x 128x128, plan-scheduled: one filler per MFMA slot, counted vmcnt)"
 
 
 class GemmTimer:
