@@ -64,21 +64,41 @@ ce_fused_kernel(T* logits, long ld, int V, const float* target, int S, int Spad,
     // pass 1: online max / sum-exp / argmax over the draft vocabulary
     float m = SF_NEG_BIG, d = 0.f;
     ArgMax am{SF_NEG_BIG, 0x7fffffff};
-    for (int c = tid; c < V8; c += nt) {
+    auto chunk1 = [&](int c, const SfRaw8<T>& raw) {
         float v[8];
-        SfVec8<T>::ld(x + c * 8, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = raw.at(i);
         float cm = v[0];
 #pragma unroll
         for (int i = 1; i < 8; ++i) cm = fmaxf(cm, v[i]);
+        if (cm > am.v) {   // rare after the first chunks; same winner as an unconditional scan (strict >, ascending i)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (v[i] > am.v) { am.v = v[i]; am.i = c * 8 + i; }
+            for (int i = 0; i < 8; ++i)
+                if (v[i] > am.v) { am.v = v[i]; am.i = c * 8 + i; }
+        }
         float mn = fmaxf(m, cm);
-        float acc = (m == SF_NEG_BIG) ? 0.f : d * sf_exp(m - mn);
+        float acc = (m == SF_NEG_BIG) ? 0.f : d * sf_exp_fast(m - mn);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc += sf_exp(v[i] - mn);
+        for (int i = 0; i < 8; ++i) acc += sf_exp_fast(v[i] - mn);
         m = mn;
         d = acc;
+    };
+    // four 16-byte chunks in flight per lane (one per trip leaves the row latency-bound); folded in ascending order
+    constexpr int PU = 4;
+    {
+        int c = tid;
+        for (; c + (PU - 1) * nt < V8; c += PU * nt) {
+            SfRaw8<T> raw[PU];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) raw[u].ld(x + (c + u * nt) * 8);
+#pragma unroll
+            for (int u = 0; u < PU; ++u) chunk1(c + u * nt, raw[u]);
+        }
+        for (; c < V8; c += nt) {
+            SfRaw8<T> raw;
+            raw.ld(x + c * 8);
+            chunk1(c, raw);
+        }
     }
     for (int j = V8 * 8 + tid; j < V; j += nt) {  // tail (V % 8)
         float v = SfElem<T>::ld(x + j);
@@ -117,23 +137,41 @@ ce_fused_kernel(T* logits, long ld, int V, const float* target, int S, int Spad,
             sf_syncthreads();
         }
         const float gs = grad_scale * (float)pm;
-        for (int c = tid; c < V8; c += nt) {
-            float v[8], p[8], g[8];
-            SfVec8<T>::ld(x + c * 8, v);
-            SfVec8<float>::ld(tp + c * 8, p);
+        auto chunk2 = [&](int c, const SfRaw8<T>& raw, const SfRaw8<float>& praw) {
+            float g[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float lp = v[i] - lse;
-                float sm = sf_exp(lp);
-                loss -= p[i] * lp;
-                acc_min += fminf(p[i] * podc, sm);
-                g[i] = (sm * tsum - p[i]) * gs;
+                const float pi = praw.at(i);
+                float lp = raw.at(i) - lse;
+                float sm = sf_exp_fast(lp);
+                loss -= pi * lp;
+                acc_min += fminf(pi * podc, sm);
+                g[i] = (sm * tsum - pi) * gs;
             }
             if (write_grad) SfVec8<T>::st(x + c * 8, g);
+        };
+        int c = tid;
+        for (; c + (PU - 1) * nt < V8; c += PU * nt) {
+            SfRaw8<T> raw[PU];
+            SfRaw8<float> praw[PU];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                raw[u].ld(x + (c + u * nt) * 8);
+                praw[u].ld(tp + (c + u * nt) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < PU; ++u) chunk2(c + u * nt, raw[u], praw[u]);
+        }
+        for (; c < V8; c += nt) {
+            SfRaw8<T> raw;
+            SfRaw8<float> praw;
+            raw.ld(x + c * 8);
+            praw.ld(tp + c * 8);
+            chunk2(c, raw, praw);
         }
         for (int j = V8 * 8 + tid; j < V; j += nt) {
             float v = SfElem<T>::ld(x + j), p = tp[j];
-            float lp = v - lse, sm = sf_exp(lp);
+            float lp = v - lse, sm = sf_exp_fast(lp);
             loss -= p * lp;
             acc_min += fminf(p * podc, sm);
             if (write_grad) SfElem<T>::st(x + j, (sm * tsum - p) * gs);
@@ -274,35 +312,56 @@ teacher_reduce_kernel(const T* z, long ldz, int Vt, int Vd, const long long* d2t
     // mask), so that the gathered pass below can write normalised probabilities in ONE pass
     float m = SF_NEG_BIG, d = 0.f, md = SF_NEG_BIG, sdd = 0.f;
     ArgMax am{SF_NEG_BIG, 0x7fffffff};
-    for (int c = tid; c < V8; c += nt) {
+    auto chunk = [&](int c, const SfRaw8<T>& raw, unsigned long long mk) {
         float v[8];
-        SfVec8<T>::ld(x + c * 8, v);
-        const unsigned long long mk = *reinterpret_cast<const unsigned long long*>(t2d + c * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = raw.at(i);
         if (mk) {
             float cmd = SF_NEG_BIG;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 if ((mk >> (8 * i)) & 0xffull) cmd = fmaxf(cmd, v[i]);
             const float mdn = fmaxf(md, cmd);
-            float accd = (md == SF_NEG_BIG) ? 0.f : sdd * sf_exp(md - mdn);
+            float accd = (md == SF_NEG_BIG) ? 0.f : sdd * sf_exp_fast(md - mdn);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if ((mk >> (8 * i)) & 0xffull) accd += sf_exp(v[i] - mdn);
+                if ((mk >> (8 * i)) & 0xffull) accd += sf_exp_fast(v[i] - mdn);
             md = mdn;
             sdd = accd;
         }
         float cm = v[0];
 #pragma unroll
         for (int i = 1; i < 8; ++i) cm = fmaxf(cm, v[i]);
+        if (cm > am.v) {   // rare after the first chunks; same winner as an unconditional scan (strict >, ascending i)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (v[i] > am.v) { am.v = v[i]; am.i = c * 8 + i; }
+            for (int i = 0; i < 8; ++i)
+                if (v[i] > am.v) { am.v = v[i]; am.i = c * 8 + i; }
+        }
         float mn = fmaxf(m, cm);
-        float acc = (m == SF_NEG_BIG) ? 0.f : d * sf_exp(m - mn);
+        float acc = (m == SF_NEG_BIG) ? 0.f : d * sf_exp_fast(m - mn);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc += sf_exp(v[i] - mn);
+        for (int i = 0; i < 8; ++i) acc += sf_exp_fast(v[i] - mn);
         m = mn;
         d = acc;
+    };
+    // four chunks (and their t2d mask words) in flight per lane; chunks are folded in ascending order, as one at a time did
+    constexpr int PU = 4;
+    int c = tid;
+    for (; c + (PU - 1) * nt < V8; c += PU * nt) {
+        SfRaw8<T> raw[PU];
+        unsigned long long mk[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            raw[u].ld(x + (c + u * nt) * 8);
+            mk[u] = *reinterpret_cast<const unsigned long long*>(t2d + (c + u * nt) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) chunk(c + u * nt, raw[u], mk[u]);
+    }
+    for (; c < V8; c += nt) {
+        SfRaw8<T> raw;
+        raw.ld(x + c * 8);
+        chunk(c, raw, *reinterpret_cast<const unsigned long long*>(t2d + c * 8));
     }
     for (int j = V8 * 8 + tid; j < Vt; j += nt) {
         float v = SfElem<T>::ld(x + j);
@@ -342,8 +401,26 @@ teacher_reduce_kernel(const T* z, long ldz, int Vt, int Vd, const long long* d2t
     // draft sub-vocabulary: one gathered pass writes the normalised probabilities (torch.softmax: exp(x - max) / sum)
     float* tp = target_p_pad + pr * (long)Vd;
     float ts = 0.f;
-    for (int j = tid; j < Vd; j += nt) {
-        const float p = sf_exp(SfElem<T>::ld(x + j + d2t[j]) - md) * inv;
+    // the gather is two dependent loads per element (d2t[j], then the logit): batches of 8 keep 8 of each in flight per lane
+    // (one element per trip left the launch latency-bound at 1.2 TB/s); the per-lane summation order is unchanged
+    constexpr int GU = 8;
+    int j = tid;
+    for (; j + (GU - 1) * nt < Vd; j += GU * nt) {
+        long long o[GU];
+        float v[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) o[u] = d2t[j + u * nt];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) v[u] = SfElem<T>::ld(x + j + u * nt + o[u]);
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const float p = sf_exp_fast(v[u] - md) * inv;
+            tp[j + u * nt] = p;
+            ts += p;
+        }
+    }
+    for (; j < Vd; j += nt) {
+        const float p = sf_exp_fast(SfElem<T>::ld(x + j + d2t[j]) - md) * inv;
         tp[j] = p;
         ts += p;
     }

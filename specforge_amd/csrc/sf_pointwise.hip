@@ -61,24 +61,33 @@ rmsnorm_fwd_kernel(const T* x, long ldx, const long long* ids_pad, int S, int Sp
 
 // dx = rstd * (g - xhat * mean(g*xhat)), g = dy*w, xhat = round_T(x*rstd); dw_partial += dy*xhat.
 // dx (optional) gets `add` (optional residual-stream gradient) summed in.
-template <typename T>
+// A workgroup walks `rows_per_block` rows; the loads of row r+1 (x, dy, add) are issued BEFORE the block-wide sum of row r,
+// so the two HBM round trips of a row overlap the previous row's reduction and stores (one row at a time left the kernel
+// latency-bound at 2.6 TB/s).  NV = 16-byte vectors per thread (H <= 2048 * NV).
+template <typename T, int NV>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2)
 rmsnorm_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, const long long* ids_pad, int S, int Spad, int off,
                    const T* w, const float* rstd_in, int H, int R, int rows_per_block, const T* add, long ldadd, T* dx,
                    long lddx, float* dw_partial) {
     SF_SHARED float red[16];
     const int tid = (int)threadIdx.x;
-    float dwacc[kNormVecs][8];
-    float wv[kNormVecs][8];
+    float dwacc[NV][8];
+    float wv[NV][8];
+    int colc[NV];     // this thread's columns; threads past H shadow column 0 (loads stay unconditional) and store nothing
+    bool live[NV];
 #pragma unroll
-    for (int i = 0; i < kNormVecs; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int col = (tid + i * 256) * 8;
+        live[i] = col < H;
+        colc[i] = live[i] ? col : 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dwacc[i][j] = 0.f; wv[i][j] = 0.f; }
-        if (col < H) SfVec8<T>::ld(w + col, wv[i]);
+        if (live[i]) SfVec8<T>::ld(w + col, wv[i]);
     }
     const int r0 = (int)blockIdx.x * rows_per_block;
-    for (int r = r0; r < r0 + rows_per_block && r < R; ++r) {
+    const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    const bool has_add = add && dx;
+    auto load_row = [&](int r, SfRaw8<T> (&xo)[NV], SfRaw8<T> (&dvo)[NV], SfRaw8<T> (&ao)[NV], float& rs) {
         const T* xr;
         if (ids_pad) {
             const int b = r / S, s = r - b * S;
@@ -86,52 +95,61 @@ rmsnorm_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, const long long
         } else {
             xr = x + (long)r * ldx;
         }
-        const float rstd = rstd_in[r];
-        float g[kNormVecs][8], xh[kNormVecs][8];
+        rs = rstd_in[r];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            xo[i].ld(xr + colc[i]);
+            dvo[i].ld(dy + (long)r * lddy + colc[i]);
+            if (has_add) ao[i].ld(add + (long)r * ldadd + colc[i]);   // uniform branch
+        }
+    };
+    auto process = [&](int r, const SfRaw8<T> (&xc)[NV], const SfRaw8<T> (&dc)[NV], const SfRaw8<T> (&ac)[NV], float rs) {
+        float g[NV][8], xh[NV][8];
         float dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < kNormVecs; ++i) {
-            const int col = (tid + i * 256) * 8;
-            if (col < H) {
-                float xv[8], dv[8];
-                SfVec8<T>::ld(xr + col, xv);
-                SfVec8<T>::ld(dy + (long)r * lddy + col, dv);
+        for (int i = 0; i < NV; ++i) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    xh[i][j] = SfElem<T>::rnd(xv[j] * rstd);
-                    g[i][j] = dv[j] * wv[i][j];
-                    dot += g[i][j] * xh[i][j];
-                    dwacc[i][j] += dv[j] * xh[i][j];
-                }
+            for (int j = 0; j < 8; ++j) {
+                const float dvj = live[i] ? dc[i].at(j) : 0.f;
+                xh[i][j] = SfElem<T>::rnd(xc[i].at(j) * rs);
+                g[i][j] = dvj * wv[i][j];
+                dot += g[i][j] * xh[i][j];
+                dwacc[i][j] += dvj * xh[i][j];
             }
         }
         if (dx) {
             dot = sf_block_sum(dot, red);
             const float cmean = dot / (float)H;
 #pragma unroll
-            for (int i = 0; i < kNormVecs; ++i) {
-                const int col = (tid + i * 256) * 8;
-                if (col < H) {
-                    float o[8];
+            for (int i = 0; i < NV; ++i) {
+                float o[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - xh[i][j] * cmean);
-                    if (add) {
-                        float a[8];
-                        SfVec8<T>::ld(add + (long)r * ldadd + col, a);
+                for (int j = 0; j < 8; ++j) o[j] = rs * (g[i][j] - xh[i][j] * cmean);
+                if (has_add) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] += a[j];
-                    }
-                    SfVec8<T>::st(dx + (long)r * lddx + col, o);
+                    for (int j = 0; j < 8; ++j) o[j] += ac[i].at(j);
                 }
+                if (live[i]) SfVec8<T>::st(dx + (long)r * lddx + colc[i], o);
             }
         }
+    };
+    // groups of RG rows: all loads of a group are issued first, then the rows are reduced one after the other, so the
+    // HBM round trip is paid once per group and the later rows land under the earlier rows' reductions.  (Prefetching
+    // across loop trips does not work here: the compiler's wait-count insertion drains loop-carried loads with vmcnt(0).)
+    constexpr int RG = NV <= 2 ? 4 : 2;
+    for (int r = r0; r < r1; r += RG) {
+        SfRaw8<T> xg[RG][NV], dg[RG][NV], ag[RG][NV];
+        float rsg[RG];
+#pragma unroll
+        for (int u = 0; u < RG; ++u) load_row(r + u < r1 ? r + u : r1 - 1, xg[u], dg[u], ag[u], rsg[u]);
+#pragma unroll
+        for (int u = 0; u < RG; ++u)
+            if (r + u < r1) process(r + u, xg[u], dg[u], ag[u], rsg[u]);
     }
     if (dw_partial) {
 #pragma unroll
-        for (int i = 0; i < kNormVecs; ++i) {
-            const int col = (tid + i * 256) * 8;
-            if (col < H) SfVec8<float>::st(dw_partial + (long)blockIdx.x * H + col, dwacc[i]);
-        }
+        for (int i = 0; i < NV; ++i)
+            if (live[i]) SfVec8<float>::st(dw_partial + (long)blockIdx.x * H + colc[i], dwacc[i]);
     }
 }
 
@@ -380,9 +398,12 @@ extern "C" int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* 
     SF_CHECK_ARG(!dw_acc || workspace, "sf_rmsnorm_bwd: workspace required for dw");
     if (rows == 0) return 0;
     const int rpb = 16, nb = (rows + rpb - 1) / rpb;
-    SF_DISPATCH_T(dtype, SF_LAUNCH((rmsnorm_bwd_kernel<T>), dim3(nb), dim3(256), 0, stream, (const T*)dy, lddy, (const T*)x,
-                                   ldx, ids_pad, S, Spad, off, (const T*)w, rstd, H, rows, rpb, (const T*)add, ldadd,
-                                   (T*)dx, lddx, dw_acc ? workspace : (float*)nullptr));
+#define SF_NORM_BWD(NV)                                                                                                    \
+    SF_DISPATCH_T(dtype, SF_LAUNCH((rmsnorm_bwd_kernel<T, NV>), dim3(nb), dim3(256), 0, stream, (const T*)dy, lddy, (const T*)x, \
+                                   ldx, ids_pad, S, Spad, off, (const T*)w, rstd, H, rows, rpb, (const T*)add, ldadd,      \
+                                   (T*)dx, lddx, dw_acc ? workspace : (float*)nullptr))
+    if (H <= 2048) { SF_NORM_BWD(1); } else if (H <= 4096) { SF_NORM_BWD(2); } else { SF_NORM_BWD(kNormVecs); }
+#undef SF_NORM_BWD
     if (dw_acc)
         SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, nb, H, dw_acc,
                   dw_accumulate);

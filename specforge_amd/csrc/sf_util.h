@@ -35,6 +35,20 @@ template <> struct SfVec8<float> {
     }
 };
 
+// 8 elements as loaded (no conversion at the load site: a converted prefetch would make the compiler wait for the data
+// right where the load is issued)
+template <typename T> struct SfRaw8;
+template <> struct SfRaw8<sf_bf16> {
+    sf_v8s v;
+    SF_DEVICE void ld(const sf_bf16* p) { v = *reinterpret_cast<const sf_v8s*>(p); }
+    SF_DEVICE float at(int i) const { return sf_bf2f((sf_bf16)v[i]); }
+};
+template <> struct SfRaw8<float> {
+    sf_v4f a, b;
+    SF_DEVICE void ld(const float* p) { a = *reinterpret_cast<const sf_v4f*>(p); b = *reinterpret_cast<const sf_v4f*>(p + 4); }
+    SF_DEVICE float at(int i) const { return i < 4 ? a[i] : b[i - 4]; }
+};
+
 // Sum / max over a whole workgroup (blockDim.x multiple of 64, <= 1024).  `red` is LDS
 // scratch of >= 16 floats owned by the caller; result is returned to every thread.
 SF_DEVICE float sf_block_sum(float v, float* red) {

@@ -250,9 +250,10 @@ def test_add_bf16(backend):
 
 
 # ------------------------------------------------------------------ teacher
+@pytest.mark.parametrize("Vt,Vd", [(640, 256), (6008, 2600)])   # the second reaches the batched gather (Vd >= 8 x 256)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_teacher_reduce(backend, dtype):
-    B, S, T, Vt, Vd = 2, 12, 3, 640, 256
+def test_teacher_reduce(backend, dtype, Vt, Vd):
+    B, S, T = 2, 12, 3
     Spad = S + T
     g = torch.Generator().manual_seed(11)
     z = (torch.randn(B * S, Vt, generator=g) * 3).to(dtype)
@@ -280,7 +281,7 @@ def test_teacher_reduce(backend, dtype):
 
 # ------------------------------------------------------------------ RMSNorm
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("R,H", [(20, 128), (33, 896)])
+@pytest.mark.parametrize("R,H", [(20, 128), (33, 896), (19, 4096), (5, 7168)])   # 1 / 1 / 2 / 4 vectors per thread
 def test_rmsnorm_fwd_bwd(backend, dtype, tol, R, H):
     x = _rand((R, H), dtype, 1)
     w = (1 + 0.1 * _rand((H,), torch.float32, 2)).to(dtype)
