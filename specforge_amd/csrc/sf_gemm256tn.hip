@@ -190,6 +190,10 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4_kernel(GemmTnArgs p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
+        for (int j = 0; j < 8; ++j) sf_acc_touch(acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             sf_gemm_store4<OUT_F32, 0>(p.e, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), v);
@@ -267,6 +271,22 @@ template <class P> constexpr int tn_rd1_at(int i) { for (int r = 0; r < 32; ++r)
 template <class P> constexpr int tn_rd0_at(int i) { for (int r = 0; r < 32; ++r) if (P::rd0(r) == i) return r; return -1; }
 template <class P> constexpr int tn_dma_at(int i) { for (int g = 0; g < 16; ++g) if (P::dma(g) == i) return g; return -1; }
 
+// M0 (LDS destination) of piece g is written right after the PREVIOUS piece's DMA, in that piece's slot (the early group
+// has no empty slot between its DMAs); the first piece of an iteration gets the free slot 16.  The DMA itself is then one
+// instruction: no M0 write + s_nop in front of it (see sf_gemm256w4_kernel.h, same reasoning).
+template <class P> constexpr int tn_dma_prev_slot(int g) {
+    int best = -1;
+    for (int h = 0; h < 16; ++h) if (P::dma(h) < P::dma(g) && P::dma(h) > best) best = P::dma(h);
+    return best;
+}
+template <class P> constexpr int tn_m0_at(int i) {
+    for (int g = 0; g < 16; ++g) {
+        const int prev = tn_dma_prev_slot<P>(g);
+        if ((prev < 0 ? 16 : prev) == i) return g;
+    }
+    return -1;
+}
+
 template <int I, int N, class F>
 SF_DEVICE void tn_static_for(F&& f) {
     if constexpr (I < N) {
@@ -324,11 +344,23 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4p_kernel(GemmTnArgs p) {
     const sf_bf16* baseA = p.A + k0 * p.lda;
     const sf_bf16* baseB = p.B + k0 * p.ldb;
     const long incA = (long)TK * p.lda, incB = (long)TK * p.ldb;
-    auto dma = [&](int g, int kt) {  // g = hh*4 + j: piece 4*wave+j of half hh of K-tile kt
-        char* dst = smem + (kt & 1) * kBufBytes + (g >> 2) * kHalfBytes + (4 * wave + (g & 3)) * 1024;
-        const SfBufRaw b = sf_make_buf_raw(g < 8 ? baseA + (long)kt * incA : baseB + (long)kt * incB);
-        sf_buf_glds16_opaque(b, voff[g], 0u, dst);
+    auto dma_dst = [&](int g, int kt) -> char* {
+        return smem + (kt & 1) * kBufBytes + (g >> 2) * kHalfBytes + (4 * wave + (g & 3)) * 1024;
     };
+    auto dma = [&](int g, int kt) {  // g = hh*4 + j: piece 4*wave+j of half hh of K-tile kt
+        const SfBufRaw b = sf_make_buf_raw(g < 8 ? baseA + (long)kt * incA : baseB + (long)kt * incB);
+        sf_buf_glds16_opaque(b, voff[g], 0u, dma_dst(g, kt));
+    };
+#ifndef SF_EMU
+    // the loop's DMA: descriptors of K-tile t+2, advanced once per iteration (64-bit base: K * ld * 2 can pass 4 GiB, so
+    // the K advance cannot live in the 32-bit scalar offset), M0 written one slot ahead
+    SfBufRaw dscA = sf_make_buf_raw(baseA + 2 * incA), dscB = sf_make_buf_raw(baseB + 2 * incB);
+    auto dsc_advance = [&](SfBufRaw& d, long inc_elems) {
+        const unsigned long long a = (((unsigned long long)(unsigned)d.w[1] << 32) | (unsigned)d.w[0]) + (unsigned long long)inc_elems * 2;
+        d.w[0] = (int)(unsigned)a;
+        d.w[1] = (int)(unsigned)(a >> 32);   // bits 63:48 (stride / swizzle) stay zero: addresses are < 2^48
+    };
+#endif
 
     // ---- fragment reads (transposed): lane constants of ds_read_b64_tr_b16 into the [64 k][256 B] image
     const int fi = lane & 15, fg = lane >> 4;
@@ -375,7 +407,13 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4p_kernel(GemmTnArgs p) {
             constexpr int r1 = tn_rd1_at<P>(i), r0 = tn_rd0_at<P>(i), gd = tn_dma_at<P>(i);
             if constexpr (r1 >= 0) read_half(1, r1 >> 1, cur, 1, r1 & 1);
             if constexpr (P::barB == i || P::barA == i) { tn_wait_lgkm(); tn_barrier(); }
+#ifdef SF_EMU
             if constexpr (decltype(DO_DMA)::value && gd >= 0) dma(gd, t + 2);
+#else
+            if constexpr (decltype(DO_DMA)::value && gd >= 0) sf_buf_glds16_m0(gd < 8 ? dscA : dscB, voff[gd], 0u);
+            constexpr int gm0 = tn_m0_at<P>(i);
+            if constexpr (decltype(DO_DMA)::value && gm0 >= 0) sf_m0_set(dma_dst(gm0, t + 2));
+#endif
             if constexpr (P::bar2 == i) {
                 if constexpr (decltype(DO_DMA)::value) tn_wait_vm16(); else tn_wait_vm0();
                 tn_barrier();
@@ -383,6 +421,9 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4p_kernel(GemmTnArgs p) {
             if constexpr (decltype(READ_NEXT)::value && r0 >= 0) read_half(0, r0 >> 1, nxt, 0, r0 & 1);
             tn_fence();
         });
+#ifndef SF_EMU
+        if constexpr (decltype(DO_DMA)::value) { dsc_advance(dscA, incA); dsc_advance(dscB, incB); }
+#endif
     };
 
     bool pace = p.sync != nullptr && wave == 0;
@@ -405,6 +446,10 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4p_kernel(GemmTnArgs p) {
 
     // ---- epilogue: lane owns C[m][n..n+3]
     sf_mfma_drain();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sf_acc_touch(acc[i][j]);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll

@@ -30,6 +30,8 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
         return sf_check_launch("sf_gemm_nt(256w4 tools)");                                                               \
     }
 #ifdef SF_ABLATE   // A/B variants, tools only (tools/experiments/sf_gemm256w4_*.inc)
+    p.cyc = sf_knob("SF_GEMM_CYC", 0);
+    p.stagger = sf_knob("SF_GEMM_STAGGER", 0);
     {
         const int ks = sf_knob("SF_GEMM_SCHED", -1);
         if (ks >= 0) {
@@ -46,6 +48,16 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     }
         SF_ABL_CASE(1) SF_ABL_CASE(2) SF_ABL_CASE(3) SF_ABL_CASE(8) SF_ABL_CASE(16)
 #undef SF_ABL_CASE
+        // the same decomposition for the product plan (B first): SF_GEMM_ABL12 = 1 no reads | 2 no DMA | 4 no barriers | 8 no waits
+        const int abl12 = sf_knob("SF_GEMM_ABL12", 0);
+#define SF_ABL12_CASE(V)                                                                                                  \
+    if (abl12 == V) {                                                                                                    \
+        SF_W4_SMEM((gemm_nt_256w4_kernel<0, 0, 12, V>));                                                                 \
+        SF_LAUNCH((gemm_nt_256w4_kernel<0, 0, 12, V>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);       \
+        return sf_check_launch("abl12");                                                                                 \
+    }
+        SF_ABL12_CASE(1) SF_ABL12_CASE(2) SF_ABL12_CASE(4) SF_ABL12_CASE(8) SF_ABL12_CASE(12) SF_ABL12_CASE(14) SF_ABL12_CASE(15)
+#undef SF_ABL12_CASE
     }
     if (int st = sf_gemm_nt_256w4_variants_launch(p, nblk, c_dtype, stream); st != -1) return st;
 #endif

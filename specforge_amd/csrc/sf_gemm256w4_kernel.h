@@ -33,6 +33,9 @@
 #include <type_traits>
 
 #define SF_INLINE_LAMBDA __attribute__((always_inline))
+#ifndef SF_W4_FAST_EPI
+#define SF_W4_FAST_EPI 1
+#endif
 
 #ifdef SF_EMU
 #define SF_W4_SMEM(kernel)
@@ -57,6 +60,10 @@ struct GemmW4Args {
     int M, N, K;
     int tiles_m, tiles_n;
     int gm;
+#ifdef SF_ABLATE
+    int stagger;
+    int cyc;   // tools build: wave 0 of every workgroup overwrites C[m0][n0..n0+1] with its K-loop cycle count (fp32 bits)
+#endif
 };
 
 namespace {
@@ -131,6 +138,27 @@ template <class P> struct w4_has_split<P, std::void_t<decltype(P::barB)>> : std:
     static constexpr bool barA(int i) { return P::barA == i; }
 };
 
+// M0 (the LDS destination of a DMA piece) is written in a slot of its own, after the previous piece's slot and before the
+// piece's own: the first such slot that holds no other filler; when there is none it shares the previous DMA's slot
+// (issued after it).  hipBLASLt's loop does the same (buffer_load ... lds ; next gap: s_add m0): a DMA slot that also
+// carries the M0 write and the s_nop its hazard needs overflows the MFMA shadow (measured: ~10 cycles per piece).
+template <class P> constexpr bool w4_slot_busy(int i) {
+    if (w4_rd1_at<P>(i) >= 0 || w4_rd0_at<P>(i) >= 0 || w4_dma_at<P>(i) >= 0 || i == P::bar1 || i == P::bar2) return true;
+    if constexpr (w4_has_split<P>::value) { if (i == P::barB || i == P::barA) return true; }
+    return false;
+}
+template <class P> constexpr int w4_dma_prev_slot(int g) {
+    int best = -1;
+    for (int h = 0; h < 16; ++h) if (P::dma(h) < P::dma(g) && P::dma(h) > best) best = P::dma(h);
+    return best;
+}
+template <class P> constexpr int w4_m0_slot(int g) {
+    const int lo = w4_dma_prev_slot<P>(g);
+    for (int s = lo + 1; s < P::dma(g); ++s) if (!w4_slot_busy<P>(s)) return s;
+    return lo >= 0 ? lo : 0;
+}
+template <class P> constexpr int w4_m0_at(int i) { for (int g = 0; g < 16; ++g) if (w4_m0_slot<P>(g) == i) return g; return -1; }
+
 // Plan interface: the MFMA slot (0..127) after which each filler of iteration t is issued.
 //   rd1(r) : read of fragment r (0..7 = B n-tiles, 8..15 = A m-tiles) of (tile t, k-half 1)  -> register set 1
 //   dma(g) : LDS-DMA piece g (0..7 = A rows, 8..15 = B rows) of tile t+2                     -> buffer t&1
@@ -199,10 +227,17 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
         voff[j] = (unsigned)(((long)ra * p.lda + slc * 8) * 2);
         voff[8 + j] = (unsigned)(((long)rb * p.ldb + slc * 8) * 2);
     }
-    auto dma = [&](int g, int kt) {  // piece g (0..7 A, 8..15 B) of K-tile kt into buffer kt&1
-        char* dst = smem + (kt & 1) * kBufBytes + (g >> 3) * kOpBytes + (8 * wave + (g & 7)) * 1024;
-        sf_buf_glds16(g < 8 ? bufA : bufB, voff[g], (unsigned)kt * (TK * 2), dst);
+    auto dma_dst = [&](int g, int kt) -> char* {
+        return smem + (kt & 1) * kBufBytes + (g >> 3) * kOpBytes + (8 * wave + (g & 7)) * 1024;
     };
+    auto dma = [&](int g, int kt) {  // piece g (0..7 A, 8..15 B) of K-tile kt into buffer kt&1
+        sf_buf_glds16(g < 8 ? bufA : bufB, voff[g], (unsigned)kt * (TK * 2), dma_dst(g, kt));
+    };
+#ifndef SF_EMU
+    // the plan loop issues the same pieces in two halves (M0 write in an earlier slot, then the bare DMA instruction)
+    const SfBufRaw rawA = sf_make_buf_raw(p.A + (long)m0 * p.lda);
+    const SfBufRaw rawB = sf_make_buf_raw(p.B + (long)n0 * p.ldb);
+#endif
 
     // ---- fragment read offsets; (row & 7) == (lane & 7) for every fragment row
     const int frow = lane & 15;
@@ -238,6 +273,17 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
         }
     }
     sf_v8s f[2][16];  // [set][0..7 = B n-tiles, 8..15 = A m-tiles]
+#ifdef SF_ABLATE
+    float cyc_loop = 0.f;
+#ifndef SF_EMU
+    unsigned rt[4] = {(unsigned)__builtin_amdgcn_s_memrealtime(), 0u, 0u, 0u};   // 100 MHz: entry, loop begin, loop end, exit
+    if (p.stagger && blockIdx.x < 256u) {   // first-round workgroups start late by (rank in the stagger order) * stagger * 10 ns
+        const unsigned rank = p.stagger > 0 ? (blockIdx.x & 7u) : (blockIdx.x >> 3);   // > 0: by XCD; < 0: by slot within the XCD
+        const unsigned wait = rank * (unsigned)(p.stagger > 0 ? p.stagger : -p.stagger);
+        while ((unsigned)__builtin_amdgcn_s_memrealtime() - rt[0] < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+#endif
 
     auto read_frag = [&](int set, int g, const char* buf, int ks) {
         if (g < 8) f[set][g] = *reinterpret_cast<const sf_v8s*>(buf + b_off + g * 2048 + swz[ks]);
@@ -268,19 +314,36 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
             else sf_mfma16_acc(f[1][nt], f[1][8 + mt], acc[mt][nt]);
             w4_fence();
             constexpr int r1 = w4_rd1_at<P>(i), r0 = w4_rd0_at<P>(i), gd = w4_dma_at<P>(i);
-            if constexpr (r1 >= 0) read_frag(1, r1, cur, 1);
-            if constexpr (P::bar1 == i && P::bar1 != P::bar2) { w4_wait_lgkm(); w4_barrier(); }
+            // ABL (tools build, timing only, results are wrong): 1 = no fragment reads, 2 = no DMA, 4 = no barriers, 8 = no waits
+            constexpr bool kRd = !(ABL & 1), kDma = !(ABL & 2), kBar = !(ABL & 4), kWait = !(ABL & 8);
+            if constexpr (kRd && r1 >= 0) read_frag(1, r1, cur, 1);
+            if constexpr (P::bar1 == i && P::bar1 != P::bar2) {
+                if constexpr (kWait) w4_wait_lgkm();
+                if constexpr (kBar) w4_barrier();
+            }
             if constexpr (w4_has_split<P>::value) {
-                if constexpr (w4_has_split<P>::barB(i) || w4_has_split<P>::barA(i)) { w4_wait_lgkm(); w4_barrier(); }
+                if constexpr (w4_has_split<P>::barB(i) || w4_has_split<P>::barA(i)) {
+                    if constexpr (kWait) w4_wait_lgkm();
+                    if constexpr (kBar) w4_barrier();
+                }
             }
-            if constexpr (decltype(DO_DMA)::value && gd >= 0) dma(gd, t + 2);
+#ifdef SF_EMU
+            if constexpr (kDma && decltype(DO_DMA)::value && gd >= 0) dma(gd, t + 2);
+#else
+            if constexpr (kDma && decltype(DO_DMA)::value && gd >= 0)
+                sf_buf_glds16_m0(gd < 8 ? rawA : rawB, voff[gd], (unsigned)(t + 2) * (TK * 2));
+            constexpr int gm0 = w4_m0_at<P>(i);
+            if constexpr (kDma && decltype(DO_DMA)::value && gm0 >= 0) sf_m0_set(dma_dst(gm0, t + 2));
+#endif
             if constexpr (P::bar2 == i) {
-                if constexpr (P::bar1 == P::bar2) w4_wait_all();
-                else if constexpr (decltype(DO_DMA)::value && P::vm == 16) w4_wait_vm16();
-                else w4_wait_vm0();
-                w4_barrier();
+                if constexpr (kWait) {
+                    if constexpr (P::bar1 == P::bar2) w4_wait_all();
+                    else if constexpr (decltype(DO_DMA)::value && P::vm == 16) w4_wait_vm16();
+                    else w4_wait_vm0();
+                }
+                if constexpr (kBar) w4_barrier();
             }
-            if constexpr (decltype(READ_NEXT)::value && r0 >= 0) read_frag(0, r0, nxt, 0);
+            if constexpr (kRd && decltype(READ_NEXT)::value && r0 >= 0) read_frag(0, r0, nxt, 0);
             w4_fence();
         });
     };
@@ -293,18 +356,95 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     {
         using P = W4PlanFor<SCHED>;
         int t = 0;
+#if defined(SF_ABLATE) && !defined(SF_EMU)
+        const unsigned long long cyc0 = __builtin_readcyclecounter();
+        rt[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
         for (; t + 2 < nkt; ++t) tilep(P{}, std::true_type{}, std::true_type{}, t);
+#if defined(SF_ABLATE) && !defined(SF_EMU)
+        cyc_loop = (float)(__builtin_readcyclecounter() - cyc0);
+        rt[2] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
         if (t + 1 < nkt) { tilep(P{}, std::true_type{}, std::false_type{}, t); ++t; }
         tilep(P{}, std::false_type{}, std::false_type{}, t);
         sf_mfma_drain();   // asm MFMAs are invisible to the hazard recogniser: let the last ones retire before acc is read
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sf_acc_touch(acc[i][j]);
     }
 
     // ---- epilogue: lane owns C[m][n..n+3]
+    // Interior tiles without beta / residual (every launch of the training step) take a straight path: one row pointer
+    // per m-tile, the eight n-tiles at immediate offsets, hardware bf16 packing.  The general store below re-derives
+    // address, bounds and the beta / residual cases per 4 values -- ~7500 instructions, 11-13 us per tile, which was
+    // 12 % of a K = 4096 tile.
+#ifdef SF_ABLATE
+    if ((p.cyc & 4) || ((p.cyc & 8) && (blockIdx.x & 1))) {   // timing experiments: no stores at all / only every other workgroup stores
+    } else
+#endif
+    if (SF_W4_FAST_EPI && m0 + TM <= p.M && n0 + TN <= p.N && p.e.beta == 0.f && !p.e.R && (p.e.ldc & 7) == 0 &&
+        ((size_t)p.e.C & 15) == 0) {   // workgroup-uniform; 16-byte row segments need 16-byte aligned rows
+        const float alpha = p.e.alpha;
+        if constexpr (OUT_F32) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i) {
+                float* crow = (float*)p.e.C + (long)(m0 + wr * 128 + i * 16 + (lane & 15)) * p.e.ldc + n0 + wc * 128 + 4 * (lane >> 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            w4_store4<OUT_F32, 0>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<sf_v4f*>(crow + j * 16) = acc[i][j] * alpha;
+            }
+        } else {
+            // bf16: a lane's 4 values are 8 bytes, so a direct store instruction touches 16 rows x 32 B = 16 L2 requests; the
+            // CU issues about one request per 4 cycles and the 256 stores of a tile took ~10 us (measured per workgroup,
+            // independent of how many other workgroups were storing) -- 10 % of a K = 4096 tile.  The tile is transposed
+            // through the (now free) K-tile buffers instead: 8-byte LDS writes in the accumulator layout, 16-byte reads in
+            // row-major order, so every store instruction writes 4 rows x 256 B = 8 full 128-byte lines.
+            constexpr int kStRow = 272;                 // 256 B of a 128-column row + 16 B pad (bank spread of the 8-byte writes)
+            w4_wait_lgkm();
+            w4_barrier();                               // every wave's last fragment reads returned: the buffers are free
+            char* st = smem + wave * (64 * kStRow);     // wave-private staging of 64 rows at a time
+            const int r = lane & 15, q = lane >> 4;
+            sf_bf16* cbase = (sf_bf16*)p.e.C + (long)(m0 + wr * 128 + q) * p.e.ldc + n0 + wc * 128 + r * 8;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const sf_v4f v = acc[half * 4 + ii][j] * alpha;
+                        sf_v4s o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (short)sf_f2bf(v[e]);
+                        *reinterpret_cast<sf_v4s*>(st + (ii * 16 + r) * kStRow + j * 32 + q * 8) = o;
+                    }
+                sf_wave_lockstep();
+#pragma unroll
+                for (int s4 = 0; s4 < 16; ++s4) {        // rows 4*s4 + q of this half, 16 bytes at column 8*r
+                    const sf_v8s d = *reinterpret_cast<const sf_v8s*>(st + (4 * s4 + q) * kStRow + r * 16);
+                    *reinterpret_cast<sf_v8s*>(cbase + (long)(half * 64 + 4 * s4) * p.e.ldc) = d;
+                }
+                sf_wave_lockstep();
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                w4_store4<OUT_F32, 0>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
+    }
+#ifdef SF_ABLATE
+    if ((p.cyc & 3) == 1 && tid == 0) *reinterpret_cast<float*>((char*)p.e.C + ((long)m0 * p.e.ldc + n0) * (OUT_F32 ? 4 : 2)) = cyc_loop;
+#ifndef SF_EMU
+    if ((p.cyc & 3) == 2 && tid == 0) {   // timeline of this workgroup + where it ran: 6 words at the tile origin
+        rt[3] = (unsigned)__builtin_amdgcn_s_memrealtime();   // stores issued, not yet complete
+        unsigned* o = reinterpret_cast<unsigned*>((char*)p.e.C + ((long)m0 * p.e.ldc + n0) * (OUT_F32 ? 4 : 2));
+        o[0] = rt[0]; o[1] = rt[1]; o[2] = rt[2]; o[3] = rt[3];
+        o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+        o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    }
+#endif
+#endif
 }
 
 #ifdef SF_ABLATE

@@ -42,6 +42,10 @@ SF_DEVICE sf_v4f sf_mfma16(sf_v8s a, sf_v8s b, sf_v4f c) { return sfemu::mfma_16
 SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) { return sfemu::mfma_32x32x16_bf16(a, b, c); }
 SF_DEVICE void sf_mfma16_acc(sf_v8s a, sf_v8s b, sf_v4f& c) { c = sfemu::mfma_16x16x32_bf16(a, b, c); }
 SF_DEVICE void sf_mfma_drain() {}
+SF_DEVICE void sf_acc_touch(sf_v4f&) {}
+// a wave's lanes run in lockstep on the GPU; the interpreter's lanes are fibres and need an explicit rendezvous between
+// an LDS write and a read of another lane's data within the wave
+SF_DEVICE void sf_wave_lockstep() { sfemu::wave_sync(); }
 SF_DEVICE void sf_glds16(const void* g, void* l) { sfemu::global_load_lds16(g, l); }
 SF_DEVICE void sf_glds16_opaque(const void* g, void* l) { sfemu::global_load_lds16(g, l); }
 SF_DEVICE void sf_flag_arrive(unsigned* c) { if (sfemu::lane_id() == 0) sfemu::atomic_add(c, 1u); }
@@ -114,7 +118,19 @@ SF_DEVICE sf_v4f sf_mfma16(sf_v8s a, sf_v8s b, sf_v4f c) {
 SF_DEVICE void sf_mfma16_acc(sf_v8s a, sf_v8s b, sf_v4f& c) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
-SF_DEVICE void sf_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
+// Fenced on both sides for the instruction scheduler: an accumulator read (v_accvgpr_read) is a register-only
+// instruction that a "memory" clobber does not hold back -- the compiler hoisted such reads above the nops (seen with a
+// short epilogue: wrong, run-to-run different results).
+SF_DEVICE void sf_mfma_drain() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// "This accumulator is (re)defined here, in an AGPR": placed after sf_mfma_drain() it pins every later use of the value
+// behind the drain.  Without it the register allocator may copy an asm MFMA's result to a VGPR right after the MFMA that
+// produced it (a v_accvgpr_read one instruction later reads the old value: the hazard recogniser cannot see the asm).
+SF_DEVICE void sf_acc_touch(sf_v4f& c) { asm volatile("" : "+a"(c)); }
+SF_DEVICE void sf_wave_lockstep() {}   // lanes of a wave execute LDS instructions in order, in lockstep
 SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -171,6 +187,17 @@ SF_DEVICE void sf_buf_glds16_opaque(SfBufRaw b, unsigned voff, unsigned soff, vo
     const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                  : : "v"(voff), "s"(b.w), "s"(soff), "s"(lds) : "memory", "m0");
+}
+// The two halves of that DMA as separate program points, the way hand-scheduled kernels issue it: M0 (the LDS
+// destination) is written in an EARLIER instruction slot, so the DMA itself is a single instruction with no `s_nop`
+// for the M0 write -> LDS-DMA hazard.  Between sf_m0_set and sf_buf_glds16_m0 the compiler must have no reason to touch
+// M0 (no LDS-DMA builtins, no indirect register indexing): the plan-scheduled GEMM loop satisfies that.
+SF_DEVICE void sf_m0_set(void* l) {
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
+    asm volatile("s_mov_b32 m0, %0" : : "s"(lds) : "m0");
+}
+SF_DEVICE void sf_buf_glds16_m0(SfBufRaw b, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(b.w), "s"(soff) : "memory");
 }
 // Workgroup-level arrive / wait on a monotonic LDS counter: a barrier whose "arrive" and "wait" halves are separate
 // program points (gfx950 has no split s_barrier).  arrive = release (everything this wave did to LDS is complete),

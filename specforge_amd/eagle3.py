@@ -36,16 +36,34 @@ class _TTTStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_plosses):
         eng: Eagle3Engine = ctx.engine
-        gp = grad_plosses.detach().float().cpu().tolist()  # one host sync per micro-step
-        g = gp[0]
-        # The decay weights are baked into the fused CE gradients; the caller must use the same ones.
-        for k, v in enumerate(gp):
-            want = g * (eng.decay ** k)
-            if abs(v - want) > 1e-6 * max(1.0, abs(want)):
-                raise RuntimeError(
-                    f"ploss weights seen in backward ({gp}) are not g*ploss_decay^k with ploss_decay={eng.decay}; "
-                    "construct OnlineEagle3Model(ploss_decay=...) with the strategy's value")
-        eng.backward(g)
+        # The upstream gradient lives on the device.  It is only needed as the alpha of the weight-gradient GEMMs at the
+        # end of the sweep, so it is copied to pinned memory asynchronously and read back THERE: the host queues the whole
+        # data-gradient sweep first and the read-back waits behind ~half a step of queued GPU work instead of stalling
+        # the launch of the backward behind the forward.
+        gp_dev = grad_plosses.detach().float()
+        if gp_dev.is_cuda:
+            host = torch.empty(gp_dev.shape, dtype=torch.float32, pin_memory=True)
+            host.copy_(gp_dev, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record()
+        else:
+            host, ready = gp_dev, None
+
+        def resolve():
+            if ready is not None:
+                ready.synchronize()
+            gp = host.tolist()
+            g = gp[0]
+            # The decay weights are baked into the fused CE gradients; the caller must use the same ones.
+            for k, v in enumerate(gp):
+                want = g * (eng.decay ** k)
+                if abs(v - want) > 1e-6 * max(1.0, abs(want)):
+                    raise RuntimeError(
+                        f"ploss weights seen in backward ({gp}) are not g*ploss_decay^k with ploss_decay={eng.decay}; "
+                        "construct OnlineEagle3Model(ploss_decay=...) with the strategy's value")
+            return g
+
+        eng.backward(resolve)
         return None, None, None
 
 

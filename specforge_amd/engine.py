@@ -401,9 +401,14 @@ class Eagle3Engine:
 
     # ----------------------------------------------------------------- backward
     @torch.no_grad()
-    def backward(self, g: float = 1.0):
+    def backward(self, g=1.0):
         """Backward sweep of the last ``forward(train=True)``; accumulates g * dLoss/dW into
-        ``flat.grad`` (overwrites on the first micro-step of an accumulation window)."""
+        ``flat.grad`` (overwrites on the first micro-step of an accumulation window).
+
+        ``g`` is a float or a zero-argument callable returning one.  It enters only as the alpha of the weight-gradient
+        GEMMs at the END of the sweep, so a callable is resolved there: when it has to wait for a device value (the
+        autograd upstream gradient), the whole data-gradient sweep is already queued behind the forward and the wait
+        costs no GPU time."""
         if self._fwd_state is None:
             raise RuntimeError("Eagle3Engine.backward called without a training forward")
         B, S = self._fwd_state
@@ -496,6 +501,8 @@ class Eagle3Engine:
 
         # ---- deferred weight gradients: dW = dY^T . X over all T*N token rows of the natural-layout stashes
         # (sf_gemm_tn), bf16 straight into flat.grad in all-reduce bucket order
+        if callable(g):
+            g = float(g())
         beta = 0.0 if self.micro_in_window == 0 else 1.0
         ln_s = b["ln_s"] if c.norm_output else b["h_s"]
         jobs = [

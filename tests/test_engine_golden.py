@@ -124,6 +124,21 @@ def test_accumulation_window_and_eval_mode(backend, golden_dir):
     torch.testing.assert_close(torch.stack(out.metrics["plosses"]).float().cpu(), blob["plosses"], rtol=2e-2, atol=2e-2)
 
 
+def test_foreign_ploss_weights_are_refused(backend, golden_dir):
+    """the decay weights are baked into the fused CE gradients at forward time; a loss that combines the per-step losses
+    with other weights must fail loudly (the check runs where the upstream gradient is read back: the end of the sweep)"""
+    blob = torch.load(os.path.join(golden_dir, "eagle3_tiny_bf16.pt"), weights_only=False)
+    cfg, model, eagle, strat = _build(blob, backend)
+    eagle.train()
+    t = _batch(blob, backend).tensors
+    ids, th, lm = TargetHead.preprocess(t["input_ids"], t["target"], t["loss_mask"])
+    plosses = eagle(input_ids=ids, attention_mask=t["attention_mask"], loss_mask=lm, target=None, hidden_states=t["hidden_state"],
+                    target_hidden_for_compact=th, target_head_weight=strat.target_head.fc.weight.data)[0]
+    wrong = sum((0.5 ** k) * p for k, p in enumerate(plosses))      # the model was built with ploss_decay 0.8
+    with pytest.raises(RuntimeError, match="ploss weights"):
+        wrong.backward()
+
+
 def test_logits_teacher_path_equals_hidden_state_path(backend, golden_dir):
     """target_repr == logits: online capture has ALREADY shifted logits and input ids, so the strategy uses them exactly
     as delivered (_prepare_eagle_target, strategies/base.py:95-121).  Feeding the head's own bf16 logits of the shifted
