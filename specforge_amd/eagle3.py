@@ -42,7 +42,9 @@ class _TTTStep(torch.autograd.Function):
         # the launch of the backward behind the forward.
         gp_dev = grad_plosses.detach().float()
         if gp_dev.is_cuda:
-            host = torch.empty(gp_dev.shape, dtype=torch.float32, pin_memory=True)
+            host = getattr(eng, "_upstream_host", None)      # one pinned buffer for the engine's lifetime: allocating
+            if host is None or host.shape != gp_dev.shape:   # pinned memory per step costs milliseconds of idle GPU
+                host = eng._upstream_host = torch.empty(gp_dev.shape, dtype=torch.float32, pin_memory=True)
             host.copy_(gp_dev, non_blocking=True)
             ready = torch.cuda.Event()
             ready.record()

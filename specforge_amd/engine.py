@@ -394,7 +394,8 @@ class Eagle3Engine:
             out["acces"].append(met[k, 1] / denom)
             out["acceptance_rates"].append(met[k, 2] / pden)
             out["metric_losses"].append(ploss.clone())
-            out["metric_loss_denoms"].append(torch.tensor(float(N), device=self.dev))
+            out["metric_loss_denoms"].append(torch.full((), float(N), device=self.dev))   # device-side fill: torch.tensor(x,
+            # device=...) is a pageable host-to-device copy, which blocks the host until the whole forward has run
         out["target_token_ids"] = b["tids"][:, :S]
         out["position_mask"] = b["pm"][:, :S]
         return out
