@@ -287,6 +287,21 @@ template <class P> constexpr int tn_m0_at(int i) {
     return -1;
 }
 
+// The fragment read addresses (one register per fragment: the XOR swizzle term differs per fragment, so they cannot
+// share a base + immediate) are moved to the other K-tile buffer ONCE per iteration, in slots of their own between the
+// last read of tile t (slot 45) and the first read of tile t+1 (slot 94); re-deriving them next to every pair of reads
+// (what the compiler does with a loop-invariant base + per-fragment offset) put a VALU add into 32 read slots.
+template <class P> constexpr bool tn_mid_busy(int i) { return tn_dma_at<P>(i) >= 0 || i == P::barA || i == P::barB || i == P::bar2; }
+template <class P> constexpr int tn_tog_at(int i) {
+    int g = 0;
+    for (int s = 46; s < 94 && g < 16; ++s) {
+        if (tn_mid_busy<P>(s)) continue;
+        if (s == i) return g;
+        ++g;
+    }
+    return -1;
+}
+
 template <int I, int N, class F>
 SF_DEVICE void tn_static_for(F&& f) {
     if constexpr (I < N) {
@@ -375,10 +390,15 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4p_kernel(GemmTnArgs p) {
         for (int j = 0; j < 8; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
     sf_v4s flo[2][16], fup[2][16];  // [set][0..7 = B n-tiles, 8..15 = A m-tiles]: k 0..3 / k 4..7 of each lane's 8-k group
 
-    auto read_half = [&](int set, int g, const char* buf, int ks, int half) {
-        const char* a = buf + (g < 8 ? b_half : a_half) + ks * (32 * 256) + frag_lane + ((((g & 7)) ^ fh) << 5);
+    // ra[g]: address of fragment g's piece in the buffer the NEXT reads use: buffer t&1 at the start of
+    // iteration t (k-half 1 of tile t), moved to buffer (t+1)&1 in the middle of the iteration (k-half 0 of tile t+1)
+    const char* ra[16];   // (pointers, not offsets: the dynamic-LDS base is a link-time constant the compiler re-adds per use)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) ra[g] = smem + (g < 8 ? b_half : a_half) + frag_lane + ((((g & 7)) ^ fh) << 5);
+    auto read_half = [&](int set, int g, int ks, int half) {
+        const char* a = ra[g] + ks * (32 * 256) + half * (4 * 256);
         if (half == 0) flo[set][g] = sf_ds_read_tr16(a);
-        else fup[set][g] = sf_ds_read_tr16(a + 4 * 256);
+        else fup[set][g] = sf_ds_read_tr16(a);
     };
     auto frag = [&](int set, int g) {
         const sf_v4s lo = flo[set][g], up = fup[set][g];
@@ -395,17 +415,18 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4p_kernel(GemmTnArgs p) {
     tn_wait_all();
     tn_barrier();
 #pragma unroll
-    for (int g = 0; g < 16; ++g) { read_half(0, g, smem, 0, 0); read_half(0, g, smem, 0, 1); }
+    for (int g = 0; g < 16; ++g) { read_half(0, g, 0, 0); read_half(0, g, 0, 1); }
 
     auto tilep = [&](auto READ_NEXT, auto DO_DMA, int t) {
-        const char* cur = smem + (t & 1) * kBufBytes;
-        const char* nxt = smem + ((t + 1) & 1) * kBufBytes;
+        const int flip = (t & 1) ? -kBufBytes : kBufBytes;
         tn_static_for<0, 128>([&](auto I) SF_TN_LAMBDA {
             constexpr int i = decltype(I)::value, idx = i & 63, mt = idx >> 3, nt = idx & 7, set = i >> 6;
             sf_mfma16_acc(frag(set, nt), frag(set, 8 + mt), acc[mt][nt]);
             tn_fence();
             constexpr int r1 = tn_rd1_at<P>(i), r0 = tn_rd0_at<P>(i), gd = tn_dma_at<P>(i);
-            if constexpr (r1 >= 0) read_half(1, r1 >> 1, cur, 1, r1 & 1);
+            if constexpr (r1 >= 0) read_half(1, r1 >> 1, 1, r1 & 1);
+            constexpr int gt = tn_tog_at<P>(i);
+            if constexpr (gt >= 0) ra[gt] += flip;
             if constexpr (P::barB == i || P::barA == i) { tn_wait_lgkm(); tn_barrier(); }
 #ifdef SF_EMU
             if constexpr (decltype(DO_DMA)::value && gd >= 0) dma(gd, t + 2);
@@ -418,7 +439,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_tn_256w4p_kernel(GemmTnArgs p) {
                 if constexpr (decltype(DO_DMA)::value) tn_wait_vm16(); else tn_wait_vm0();
                 tn_barrier();
             }
-            if constexpr (decltype(READ_NEXT)::value && r0 >= 0) read_half(0, r0 >> 1, nxt, 0, r0 & 1);
+            if constexpr (decltype(READ_NEXT)::value && r0 >= 0) read_half(0, r0 >> 1, 0, r0 & 1);
             tn_fence();
         });
 #ifndef SF_EMU
