@@ -26,7 +26,7 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
 #define SF_W4_LOCAL(F32, ADD, SCHED)                                                                                      \
     if (f32 == F32 && add == ADD && sched == SCHED) {                                                                    \
         SF_W4_SMEM((gemm_nt_256w4_kernel<F32, ADD, SCHED>));                                                             \
-        SF_LAUNCH((gemm_nt_256w4_kernel<F32, ADD, SCHED>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);   \
+        SF_LAUNCH((gemm_nt_256w4_kernel<F32, ADD, SCHED>), dim3(sf_w4_grid(nblk, ADD)), dim3(256), kW4SmemBytes, stream, p);   \
         return sf_check_launch("sf_gemm_nt(256w4 tools)");                                                               \
     }
 #ifdef SF_ABLATE   // A/B variants, tools only (tools/experiments/sf_gemm256w4_*.inc)
@@ -43,7 +43,7 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
 #define SF_ABL_CASE(V)                                                                                                    \
     if (abl == V) {                                                                                                      \
         SF_W4_SMEM((gemm_nt_256w4_kernel<0, 0, 0, V>));                                                                  \
-        SF_LAUNCH((gemm_nt_256w4_kernel<0, 0, 0, V>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);        \
+        SF_LAUNCH((gemm_nt_256w4_kernel<0, 0, 0, V>), dim3(sf_w4_grid(nblk)), dim3(256), kW4SmemBytes, stream, p);        \
         return sf_check_launch("abl");                                                                                   \
     }
         SF_ABL_CASE(1) SF_ABL_CASE(2) SF_ABL_CASE(3) SF_ABL_CASE(8) SF_ABL_CASE(16)
@@ -53,7 +53,7 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
 #define SF_ABL12_CASE(V)                                                                                                  \
     if (abl12 == V) {                                                                                                    \
         SF_W4_SMEM((gemm_nt_256w4_kernel<0, 0, 12, V>));                                                                 \
-        SF_LAUNCH((gemm_nt_256w4_kernel<0, 0, 12, V>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p);       \
+        SF_LAUNCH((gemm_nt_256w4_kernel<0, 0, 12, V>), dim3(sf_w4_grid(nblk)), dim3(256), kW4SmemBytes, stream, p);       \
         return sf_check_launch("abl12");                                                                                 \
     }
         SF_ABL12_CASE(1) SF_ABL12_CASE(2) SF_ABL12_CASE(4) SF_ABL12_CASE(8) SF_ABL12_CASE(12) SF_ABL12_CASE(14) SF_ABL12_CASE(15)

@@ -44,7 +44,7 @@
     do {                                                                                                         \
         static bool done_ = false;                                                                               \
         if (!done_) {                                                                                            \
-            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBufBytes); \
+            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kW4SmemBytes); \
             (void)hipGetLastError();                                                                             \
             done_ = true;                                                                                        \
         }                                                                                                        \
@@ -71,6 +71,9 @@ namespace {
 constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int kOpBytes = 256 * TK * 2;       // 32 KiB: one operand's K-tile
 constexpr int kBufBytes = 2 * kOpBytes;      // A + B
+constexpr int kStageRow = 272;               // epilogue staging: 256 B of a 128-column bf16 row + 16 B pad (bank spread)
+constexpr int kStageBytes = 4 * 16 * kStageRow;  // 4 waves x 16 rows
+constexpr int kW4SmemBytes = 2 * kBufBytes + kStageBytes;   // two K-tile buffers + the staging area = 145 KiB of the CU's 160
 
 
 #ifdef SF_EMU
@@ -79,6 +82,8 @@ SF_DEVICE void w4_wait_all() {}
 SF_DEVICE void w4_wait_lgkm() {}
 SF_DEVICE void w4_wait_vm16() {}
 SF_DEVICE void w4_wait_vm13() {}
+SF_DEVICE void w4_wait_vm32() {}
+SF_DEVICE void w4_wait_vm63() {}
 SF_DEVICE void w4_wait_vm0() {}
 SF_DEVICE void w4_fence() {}
 #else
@@ -87,6 +92,8 @@ SF_DEVICE void w4_wait_all() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: 
 SF_DEVICE void w4_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 SF_DEVICE void w4_wait_vm16() { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }   // all but the newest 16 LDS-DMA pieces
 SF_DEVICE void w4_wait_vm13() { asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
+SF_DEVICE void w4_wait_vm32() { asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); }
+SF_DEVICE void w4_wait_vm63() { asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); }
 SF_DEVICE void w4_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 SF_DEVICE void w4_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
@@ -205,9 +212,13 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     SF_DYN_SMEM(smem);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id();
     const int wr = wave >> 1, wc = wave & 1;
-    int tm, tn;
-    w4_tile_coords((int)blockIdx.x, (int)gridDim.x, p.tiles_m, p.tiles_n, p.gm, tm, tn);
-    const int m0 = tm * TM, n0 = tn * TN;
+    // PERSISTENT over tiles: workgroup w computes tiles w, w + gridDim.x, ... (the launcher starts one workgroup per CU
+    // when there are more tiles than CUs; gridDim.x is a multiple of 8 then, so a tile keeps its XCD).  The next tile's
+    // first two K-tiles are put in flight BEFORE the epilogue of the finished one: its DMA latency, the per-tile set-up and
+    // the workgroup hand-over (~3 us of a ~98 us tile at K = 4096) disappear behind the epilogue's stores.
+    const int nblk = p.tiles_m * p.tiles_n;
+    int tile = (int)blockIdx.x;
+    int m0 = 0, n0 = 0;
     const int nkt = p.K / TK;
 
     // ---- DMA sources: this wave stages pieces 8*wave .. 8*wave+7 (8 rows x 128 B each) of A and of B through raw
@@ -216,28 +227,47 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     // accumulators that are never stored.
     const int srow = lane >> 3;
     const int slc = (lane & 7) ^ (srow & 7);  // logical 16-byte chunk fetched into physical chunk lane&7
-    const SfBuf bufA = sf_make_buf(p.A + (long)m0 * p.lda, 0x7fffffffu);
-    const SfBuf bufB = sf_make_buf(p.B + (long)n0 * p.ldb, 0x7fffffffu);
+    SfBuf bufA, bufB;
+#ifndef SF_EMU
+    SfBufRaw rawA, rawB;   // the same descriptors for the asm (compiler-opaque) DMA forms
+#endif
     unsigned voff[16];
+    auto setup_tile = [&](int t) {   // tile origin, descriptors and per-lane source offsets of tile t
+        int tm, tn;
+        w4_tile_coords(t, nblk, p.tiles_m, p.tiles_n, p.gm, tm, tn);
+        m0 = tm * TM;
+        n0 = tn * TN;
+        bufA = sf_make_buf(p.A + (long)m0 * p.lda, 0x7fffffffu);
+        bufB = sf_make_buf(p.B + (long)n0 * p.ldb, 0x7fffffffu);
+#ifndef SF_EMU
+        rawA = sf_make_buf_raw(p.A + (long)m0 * p.lda);
+        rawB = sf_make_buf_raw(p.B + (long)n0 * p.ldb);
+#endif
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        int ra = (8 * wave + j) * 8 + srow, rb = ra;
-        ra = m0 + ra < p.M ? ra : p.M - 1 - m0;
-        rb = n0 + rb < p.N ? rb : p.N - 1 - n0;
-        voff[j] = (unsigned)(((long)ra * p.lda + slc * 8) * 2);
-        voff[8 + j] = (unsigned)(((long)rb * p.ldb + slc * 8) * 2);
-    }
+        for (int j = 0; j < 8; ++j) {
+            int ra = (8 * wave + j) * 8 + srow, rb = ra;
+            ra = m0 + ra < p.M ? ra : p.M - 1 - m0;
+            rb = n0 + rb < p.N ? rb : p.N - 1 - n0;
+            voff[j] = (unsigned)(((long)ra * p.lda + slc * 8) * 2);
+            voff[8 + j] = (unsigned)(((long)rb * p.ldb + slc * 8) * 2);
+        }
+    };
+    setup_tile(tile);
     auto dma_dst = [&](int g, int kt) -> char* {
         return smem + (kt & 1) * kBufBytes + (g >> 3) * kOpBytes + (8 * wave + (g & 7)) * 1024;
     };
     auto dma = [&](int g, int kt) {  // piece g (0..7 A, 8..15 B) of K-tile kt into buffer kt&1
         sf_buf_glds16(g < 8 ? bufA : bufB, voff[g], (unsigned)kt * (TK * 2), dma_dst(g, kt));
     };
-#ifndef SF_EMU
-    // the plan loop issues the same pieces in two halves (M0 write in an earlier slot, then the bare DMA instruction)
-    const SfBufRaw rawA = sf_make_buf_raw(p.A + (long)m0 * p.lda);
-    const SfBufRaw rawB = sf_make_buf_raw(p.B + (long)n0 * p.ldb);
+    // between tiles: invisible to the compiler like the loop's DMAs (a builtin DMA would make it wait for vmcnt(0) before
+    // the epilogue's staging reads, which it cannot tell apart from the K-tile buffers)
+    auto dma_next = [&](int g, int kt) {
+#ifdef SF_EMU
+        dma(g, kt);
+#else
+        sf_buf_glds16_opaque(g < 8 ? rawA : rawB, voff[g], (unsigned)kt * (TK * 2), dma_dst(g, kt));
 #endif
+    };
 
     // ---- fragment read offsets; (row & 7) == (lane & 7) for every fragment row
     const int frow = lane & 15;
@@ -248,6 +278,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     const int b_off = kOpBytes + (wc * 128 + frow) * 128;
 
     sf_v4f acc[8][8];
+    auto acc_init = [&]() SF_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -272,6 +303,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
             }
         }
     }
+    };
+    acc_init();
     sf_v8s f[2][16];  // [set][0..7 = B n-tiles, 8..15 = A m-tiles]
 #ifdef SF_ABLATE
     float cyc_loop = 0.f;
@@ -348,6 +381,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
         });
     };
 
+    for (;;) {   // ---- tiles of this workgroup
 #ifdef SF_ABLATE
     if constexpr (SCHED == 0) {
 #include "../../tools/experiments/sf_gemm256w4_sched0.inc"
@@ -374,65 +408,92 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
             for (int j = 0; j < 8; ++j) sf_acc_touch(acc[i][j]);
     }
 
-    // ---- epilogue: lane owns C[m][n..n+3]
-    // Interior tiles without beta / residual (every launch of the training step) take a straight path: one row pointer
-    // per m-tile, the eight n-tiles at immediate offsets, hardware bf16 packing.  The general store below re-derives
-    // address, bounds and the beta / residual cases per 4 values -- ~7500 instructions, 11-13 us per tile, which was
-    // 12 % of a K = 4096 tile.
+    // ---- hand-over: the finished tile's coordinates, then the next tile's first two K-tiles go in flight
+    const int mc = m0, nc = n0;
+    const int next = tile + (int)gridDim.x;
+    const bool has_next = next < nblk;
+    w4_wait_lgkm();
+    w4_barrier();                 // every wave's last fragment reads returned: both K-tile buffers are free
+    if (has_next) {
+        setup_tile(next);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) dma_next(g, 0);
+        if (nkt > 1) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) dma_next(g, 1);
+        }
+    }
+
+    // ---- epilogue of tile (mc, nc): lane owns C[m][n..n+3]
+    // Interior tiles without beta / residual (every launch of the training step) take a straight path; the general store
+    // below re-derives address, bounds and the beta / residual cases per 4 values (~7500 instructions).
+    int newer = 0;   // vector-memory instructions this wave issues AFTER the next tile's DMAs (lower bound; 0 = unknown)
 #ifdef SF_ABLATE
     if ((p.cyc & 4) || ((p.cyc & 8) && (blockIdx.x & 1))) {   // timing experiments: no stores at all / only every other workgroup stores
     } else
 #endif
-    if (SF_W4_FAST_EPI && m0 + TM <= p.M && n0 + TN <= p.N && p.e.beta == 0.f && !p.e.R && (p.e.ldc & 7) == 0 &&
+    if (SF_W4_FAST_EPI && mc + TM <= p.M && nc + TN <= p.N && p.e.beta == 0.f && !p.e.R && (p.e.ldc & 7) == 0 &&
         ((size_t)p.e.C & 15) == 0) {   // workgroup-uniform; 16-byte row segments need 16-byte aligned rows
         const float alpha = p.e.alpha;
         if constexpr (OUT_F32) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float* crow = (float*)p.e.C + (long)(m0 + wr * 128 + i * 16 + (lane & 15)) * p.e.ldc + n0 + wc * 128 + 4 * (lane >> 4);
+                float* crow = (float*)p.e.C + (long)(mc + wr * 128 + i * 16 + (lane & 15)) * p.e.ldc + nc + wc * 128 + 4 * (lane >> 4);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) *reinterpret_cast<sf_v4f*>(crow + j * 16) = acc[i][j] * alpha;
             }
+            newer = 64;
         } else {
             // bf16: a lane's 4 values are 8 bytes, so a direct store instruction touches 16 rows x 32 B = 16 L2 requests; the
             // CU issues about one request per 4 cycles and the 256 stores of a tile took ~10 us (measured per workgroup,
             // independent of how many other workgroups were storing) -- 10 % of a K = 4096 tile.  The tile is transposed
-            // through the (now free) K-tile buffers instead: 8-byte LDS writes in the accumulator layout, 16-byte reads in
-            // row-major order, so every store instruction writes 4 rows x 256 B = 8 full 128-byte lines.
-            constexpr int kStRow = 272;                 // 256 B of a 128-column row + 16 B pad (bank spread of the 8-byte writes)
-            w4_wait_lgkm();
-            w4_barrier();                               // every wave's last fragment reads returned: the buffers are free
-            char* st = smem + wave * (64 * kStRow);     // wave-private staging of 64 rows at a time
+            // through LDS instead (a staging area behind the K-tile buffers, 16 rows per wave at a time): 8-byte writes in
+            // the accumulator layout, 16-byte reads in row-major order, so every store instruction writes 4 rows x 256 B =
+            // 8 full 128-byte lines (~5 us: the CU's 16 B/clk store path).
+            char* st = smem + 2 * kBufBytes + wave * (16 * kStageRow);     // wave-private
             const int r = lane & 15, q = lane >> 4;
-            sf_bf16* cbase = (sf_bf16*)p.e.C + (long)(m0 + wr * 128 + q) * p.e.ldc + n0 + wc * 128 + r * 8;
+            sf_bf16* cbase = (sf_bf16*)p.e.C + (long)(mc + wr * 128 + q) * p.e.ldc + nc + wc * 128 + r * 8;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int i = 0; i < 8; ++i) {
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
+                for (int j = 0; j < 8; ++j) {
+                    const sf_v4f v = acc[i][j] * alpha;
+                    sf_v4s o;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const sf_v4f v = acc[half * 4 + ii][j] * alpha;
-                        sf_v4s o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (short)sf_f2bf(v[e]);
-                        *reinterpret_cast<sf_v4s*>(st + (ii * 16 + r) * kStRow + j * 32 + q * 8) = o;
-                    }
+                    for (int e = 0; e < 4; ++e) o[e] = (short)sf_f2bf(v[e]);
+                    *reinterpret_cast<sf_v4s*>(st + r * kStageRow + j * 32 + q * 8) = o;
+                }
                 sf_wave_lockstep();
 #pragma unroll
-                for (int s4 = 0; s4 < 16; ++s4) {        // rows 4*s4 + q of this half, 16 bytes at column 8*r
-                    const sf_v8s d = *reinterpret_cast<const sf_v8s*>(st + (4 * s4 + q) * kStRow + r * 16);
-                    *reinterpret_cast<sf_v8s*>(cbase + (long)(half * 64 + 4 * s4) * p.e.ldc) = d;
+                for (int s4 = 0; s4 < 4; ++s4) {         // rows 4*s4 + q of this m-tile, 16 bytes at column 8*r
+                    const sf_v8s d = *reinterpret_cast<const sf_v8s*>(st + (4 * s4 + q) * kStageRow + r * 16);
+                    *reinterpret_cast<sf_v8s*>(cbase + (long)(i * 16 + 4 * s4) * p.e.ldc) = d;
                 }
                 sf_wave_lockstep();
             }
+            newer = 32;
         }
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                w4_store4<OUT_F32, 0>(p, m0 + wr * 128 + i * 16 + (lane & 15), n0 + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
+                w4_store4<OUT_F32, 0>(p, mc + wr * 128 + i * 16 + (lane & 15), nc + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
     }
+    if (!has_next) break;
+
+    // ---- the next tile: accumulators, then its K-tiles 0 and 1 (in flight since before the epilogue) must have landed.
+    // vmcnt retires in order, so "all but the `newer` youngest" covers the DMAs without waiting for the epilogue's stores.
+    tile = next;
+    acc_init();
+    if (ADD) newer += 64;
+    if (newer >= 63) w4_wait_vm63();
+    else if (newer >= 32) w4_wait_vm32();
+    else w4_wait_all();
+    w4_barrier();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) read_frag(0, g, smem, 0);
+    }   // tiles
 #ifdef SF_ABLATE
     if ((p.cyc & 3) == 1 && tid == 0) *reinterpret_cast<float*>((char*)p.e.C + ((long)m0 * p.e.ldc + n0) * (OUT_F32 ? 4 : 2)) = cyc_loop;
 #ifndef SF_EMU
@@ -453,13 +514,33 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
 
 }  // namespace
 
+// Grid of the persistent kernel: one workgroup per CU once there are more tiles than CUs (256 on MI355X; a multiple of 8,
+// so tile t and tile t + grid sit on the same XCD).  SF_GEMM_PERSIST=0 (tools build) gives one workgroup per tile.
+static inline unsigned sf_w4_grid(long nblk, int add = 0) {
+    static const int persist = sf_knob("SF_GEMM_PERSIST", 1);
+    static const int cus = [] {
+        int dev = 0, n = 0;
+#ifndef SF_EMU
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+#endif
+#ifdef SF_EMU
+        return 8 + 0 * (dev + n);   // interpreter: 8 "CUs", so the multi-tile path runs at test sizes
+#else
+        return n >= 8 ? n / 8 * 8 : 256;
+#endif
+    }();
+    // the row-addend form stays one workgroup per tile: its accumulators START from a 256 KB fp32 tile, a load that
+    // overlaps the first K-tiles' DMA at workgroup start but would sit between epilogue and K loop in the persistent form
+    return (unsigned)((persist && !add && nblk > cus) ? cus : nblk);
+}
+
 // one launch function per instantiation; each lives in its own translation unit (sf_gemm256w4_i*.hip) so that the
 // eight 128-slot kernels compile in parallel (~25 s each; together in one unit they took > 10 minutes)
 #define SF_W4_DECLARE(F32, ADD, SCHED) int sf_w4_launch_##F32##_##ADD##_##SCHED(const GemmW4Args& p, long nblk, void* stream)
 #define SF_W4_DEFINE(F32, ADD, SCHED)                                                                                  \
     SF_W4_DECLARE(F32, ADD, SCHED) {                                                                                   \
         SF_W4_SMEM((gemm_nt_256w4_kernel<F32, ADD, SCHED>));                                                           \
-        SF_LAUNCH((gemm_nt_256w4_kernel<F32, ADD, SCHED>), dim3((unsigned)nblk), dim3(256), 2 * kBufBytes, stream, p); \
+        SF_LAUNCH((gemm_nt_256w4_kernel<F32, ADD, SCHED>), dim3(sf_w4_grid(nblk, ADD)), dim3(256), kW4SmemBytes, stream, p); \
         return sf_check_launch("sf_gemm_nt(256w4)");                                                                   \
     }
 SF_W4_DECLARE(0, 0, 12); SF_W4_DECLARE(0, 0, 13); SF_W4_DECLARE(1, 0, 12); SF_W4_DECLARE(1, 0, 13);

@@ -276,10 +276,11 @@ ce_lk_grad_kernel(T* logits, long ld, int V, const float* target, int S, int Spa
     }
 }
 
-// deterministic sum of n floats (fixed order, double accumulation): out[0] = sum
-SF_GLOBAL void reduce_sum_kernel(const float* in, long n, float* out, float scale) {
+// deterministic sum of n floats (fixed order, double accumulation): workgroup b sums segment b, out[b] = sum
+SF_GLOBAL void reduce_sum_kernel(const float* in_all, long n, float* out, float scale) {
     SF_SHARED double part[256];
     const int tid = (int)threadIdx.x;
+    const float* in = in_all + (long)blockIdx.x * n;
     double acc = 0.0;
     for (long i = tid; i < n; i += 256) acc += (double)in[i];
     part[tid] = acc;
@@ -479,8 +480,7 @@ extern "C" int sf_ce_lk_grad(void* logits, int dtype, long ld, int rows, int V, 
 extern "C" int sf_reduce_sum(const float* in, long n, int nsegments, float* out, float scale, void* stream) {
     SF_CHECK_ARG(n >= 0 && nsegments >= 1, "sf_reduce_sum: bad shape");
     // segment i sums in[i*n : (i+1)*n]
-    for (int i = 0; i < nsegments; ++i)
-        SF_LAUNCH(reduce_sum_kernel, dim3(1), dim3(256), 0, stream, in + (long)i * n, n, out + i, scale);
+    SF_LAUNCH(reduce_sum_kernel, dim3((unsigned)nsegments), dim3(256), 0, stream, in, n, out, scale);
     return sf_check_launch("sf_reduce_sum");
 }
 

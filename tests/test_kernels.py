@@ -30,7 +30,8 @@ def _rand(shape, dtype, seed, scale=1.0):
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (64, 48, 288), (257, 384, 512), (256, 256, 64),
                                    (520, 264, 192), (300, 200, 128), (300, 260, 640), (256, 512, 64 * 11),
-                                   (200, 8456, 512)])   # N > 8192: the A-first plan of the 4-wave kernel
+                                   (200, 8456, 512),   # N > 8192: the A-first plan of the 4-wave kernel
+                                   (1100, 608, 512)])  # 5 x 3 tiles: workgroups of the persistent kernel take 2 tiles (interior + edge)
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_nt(backend, M, N, K, out_dtype):
     a = _rand((M, K), torch.bfloat16, 1)
