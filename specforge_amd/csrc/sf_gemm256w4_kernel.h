@@ -411,7 +411,9 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     // ---- hand-over: the finished tile's coordinates, then the next tile's first two K-tiles go in flight
     const int mc = m0, nc = n0;
     const int next = tile + (int)gridDim.x;
-    const bool has_next = next < nblk;
+    // (the row-addend form is launched one workgroup per tile -- sf_w4_grid -- and compiles without the second tile:
+    //  a second call site of its 256-register accumulator load made the compiler spill 152 registers)
+    const bool has_next = !ADD && next < nblk;
     w4_wait_lgkm();
     w4_barrier();                 // every wave's last fragment reads returned: both K-tile buffers are free
     if (has_next) {
@@ -481,12 +483,12 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                 w4_store4<OUT_F32, 0>(p, mc + wr * 128 + i * 16 + (lane & 15), nc + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
     }
     if (!has_next) break;
+    if constexpr (ADD != 0) break;
 
     // ---- the next tile: accumulators, then its K-tiles 0 and 1 (in flight since before the epilogue) must have landed.
     // vmcnt retires in order, so "all but the `newer` youngest" covers the DMAs without waiting for the epilogue's stores.
     tile = next;
     acc_init();
-    if (ADD) newer += 64;
     if (newer >= 63) w4_wait_vm63();
     else if (newer >= 32) w4_wait_vm32();
     else w4_wait_all();

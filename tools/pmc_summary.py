@@ -18,15 +18,20 @@ def family(name):
 
 
 def main(d, out):
-    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    # one csv per rocprofv3 run; several runs of the same command (one counter group each) may sit under `d`
     agg = defaultdict(lambda: defaultdict(float))
-    launches = defaultdict(set)
-    for r in csv.DictReader(open(f)):
-        fam = family(r["Kernel_Name"])
-        if fam is None:
-            continue
-        agg[fam][r["Counter_Name"]] += float(r["Counter_Value"])
-        launches[fam].add(r.get("Dispatch_Id") or r.get("Correlation_Id"))
+    nlaunch = defaultdict(int)
+    for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
+        per_file = defaultdict(set)
+        for r in csv.DictReader(open(f)):
+            fam = family(r["Kernel_Name"])
+            if fam is None:
+                continue
+            agg[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+            per_file[fam].add(r.get("Dispatch_Id") or r.get("Correlation_Id"))
+        for fam, ids in per_file.items():
+            nlaunch[fam] = max(nlaunch[fam], len(ids))
+    launches = {fam: range(n) for fam, n in nlaunch.items()}
     res = {}
     for fam, c in agg.items():
         e = {"launches": len(launches[fam])}
