@@ -5,7 +5,9 @@
 //     (256 accumulator registers pinned to AGPRs; one wave per SIMD with the full 512-entry register file).
 //   * LDS = 2 K-tile buffers x {A 256 rows, B 256 rows} x 128 B, XOR-swizzled 16-byte chunks = 128 KiB, filled by
 //     LDS-DMA (buffer_load ... lds through raw buffer descriptors: the K advance is a scalar offset, no vector
-//     arithmetic in the loop).
+//     arithmetic in the loop), + 17 KiB staging for the bf16 epilogue (the tile leaves as whole 128-byte lines).
+//   * persistent over tiles: one workgroup per CU walks tiles w, w + grid, ...; the next tile's first two K-tiles are
+//     put in flight before the finished tile's epilogue (see the hand-over section of the kernel).
 //   * a K-tile = 128 MFMAs = two k-halves of 64; fragments are double-buffered in registers (set 0 = k-half 0,
 //     set 1 = k-half 1).
 //   * Schedule of iteration t (round 2; measured against hipBLASLt's hand-scheduled kernel of the same geometry, whose
@@ -14,7 +16,9 @@
 //       slot   21 / 51 : lgkmcnt(0) + s_barrier -> that OPERAND's half of buffer t&1 is free (released separately,
 //                        so its re-staging starts after 1/6 of the iteration instead of 1/2)
 //       slots  22..95  : the 16 LDS-DMA pieces of tile t+2, never two fillers in one slot (an LDS-DMA issue costs
-//                        60-180 cycles when bunched with ds_reads; a burst of one per 2 MFMAs measured -7 %)
+//                        60-180 cycles when bunched with ds_reads; a burst of one per 2 MFMAs measured -7 %); the
+//                        LDS destination (M0) of each piece is written in an EARLIER free slot, so the piece itself
+//                        is one instruction (s_mov m0 + s_nop + buffer_load in one gap: ~10 cycles per piece)
 //       slot  108      : s_waitcnt vmcnt(16) + s_barrier -> tile t+1 (issued during iteration t-1) is visible; this
 //                        iteration's 16 pieces stay in flight.  DMA lead: 1.1 .. 1.7 iterations (2400 .. 3700 cycles).
 //       slots 110..126 : the 16 fragment reads of (t+1, k-half 0)
@@ -24,6 +28,8 @@
 //     only after (own reads returned: lgkmcnt(0)) + barrier; its k-half-0 fragments were read in iteration t-1.
 //   * round-1 schedule (one barrier per K-tile, groups of 4 MFMAs + 2 reads, DMA in the second half-step, vmcnt(0)):
 //     30 % more cycles than hipBLASLt on the same shape; this one 10 % (SQ_WAVE_CYCLES, profiles/r2_gemm_pmc.txt).
+//     Cycles per K-tile read inside the kernel (tools build, SF_GEMM_CYC): MFMAs alone 2083, this loop 2251
+//     (profiles/r2_gemm_cycles.jsonl).
 //     It and the intermediate plans live in tools/experiments/sf_gemm256w4_sched.inc (tools build only).
 #pragma once
 #include "sf_api_internal.h"

@@ -44,7 +44,8 @@ def test_gemm_nt(backend, M, N, K, out_dtype):
     torch.testing.assert_close(out.float().cpu(), ref, rtol=tol, atol=tol * math.sqrt(K))
 
 
-@pytest.mark.parametrize("M,N,K,S,T", [(64, 48, 64, 16, 3), (512, 264, 128, 64, 2), (256, 200, 576, 32, 2)])
+@pytest.mark.parametrize("M,N,K,S,T", [(64, 48, 64, 16, 3), (512, 264, 128, 64, 2), (256, 200, 576, 32, 2),
+                                       (768, 520, 512, 64, 2)])   # 3 x 3 tiles of the 4-wave kernel, interior + edge
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_nt_rowadd(backend, M, N, K, S, T, out_dtype):
     """fp32 row-mapped addend joins the accumulator before the single rounding (embedding half of the TTT QKV)"""
