@@ -37,7 +37,9 @@ def _check(out, ref, K, out_dtype, what):
     assert rel_max < (2e-4 if out_dtype == torch.float32 else 8e-3), rel_max
 
 
-@pytest.mark.parametrize("M,N,K", [(16384, 32000, 4096), (16384, 4096, 14336), (16384, 28672, 4096)])
+@pytest.mark.parametrize("M,N,K", [(16384, 32000, 4096), (16384, 4096, 14336), (16384, 28672, 4096),
+                                   (16448, 6144, 4096),    # the embedding half: 65 x 24 tiles, a row of EDGE tiles inside the persistent walk
+                                   (16390, 8456, 1024)])   # ragged M and N (N % 8 == 0), A-first plan, 65 x 34 tiles
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_nt_headline_shapes(M, N, K, out_dtype):
     a, b = _randn((M, K), 1), _randn((N, K), 2)
