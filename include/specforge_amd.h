@@ -29,7 +29,7 @@ extern "C" {
 #define SF_BF16 0
 #define SF_F32 1
 
-#define SF_ABI_VERSION 2
+#define SF_ABI_VERSION 3
 
 int sf_abi_version(void);
 /* 1 if this library is the SIMT-emulator test build, 0 for the gfx950 product build */
@@ -126,6 +126,13 @@ int sf_rope(void* x, int dtype, long ld, int rows, int nheads, int hd, const voi
 int sf_swiglu_fwd(const void* gu, int dtype, long ldgu, long rows, int I, void* act, long ldact, void* stream);
 int sf_swiglu_bwd(const void* dact, int dtype, long lddact, const void* gu, long ldgu, long rows, int I, void* dgu,
                   long lddgu, void* stream);
+
+/* The down-projection input gradient fused with d(SwiGLU) (llama3_eagle.py:1518-1549 under autograd: d(act) = dY . W_down,
+ * then d(gate), d(up) from the saved gate / up): A [M, K] = dY, B [I, K] = W_down^T image, gu [M, 2I] saved gate|up,
+ * dgu [M, 2I] out.  d(act) [M, I] is never written when the chip-filling kernel can fuse the two (whole 256 x 256 tiles);
+ * `dact` [M, I] is the scratch the two-step form of every other shape goes through.  Same bits either way (ABI 3). */
+int sf_gemm_nt_swiglu_bwd(const void* A, long lda, const void* B, long ldb, int M, int I, int K, const void* gu, long ldgu,
+                          void* dgu, long lddgu, void* dact, long lddact, void* stream);
 
 /* out[b1][b2][c][r] = in[b1][b2][r][c]: operand transposes for dgrad/wgrad and the K^T/V^T/Q^T/dO^T
  * images of the attention kernels (no reference equivalent: autograd transposes are views). */

@@ -189,6 +189,34 @@ extern "C" int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void
     return sf_gemm_dispatch(A, lda, B, ldb, K, e, c_dtype, stream);
 }
 
+// d(act) = A . B^T fused with d(SwiGLU): dgu[:, :I] = d(gate), dgu[:, I:] = d(up) from gu [M, 2I] (see SfGemmEpi).  The fused
+// epilogue exists in the 4-wave kernel for whole tiles only; every other shape runs the two steps through `dact`.
+extern "C" int sf_gemm_nt_swiglu_bwd(const void* A, long lda, const void* B, long ldb, int M, int I, int K, const void* gu,
+                                     long ldgu, void* dgu, long lddgu, void* dact, long lddact, void* stream) {
+    if (int st = sf_gemm_check(lda, ldb, lddact, 0, M, I, K, SF_BF16, nullptr)) return st;
+    SF_CHECK_ARG(gu && dgu && dact && ldgu % 8 == 0 && lddgu % 8 == 0 && lddact % 8 == 0 && I % 8 == 0,
+                 "sf_gemm_nt_swiglu_bwd: gu / dgu / dact rows must be 16-byte aligned");
+    if (M == 0 || I == 0) return 0;
+    SfGemmEpi e;
+    e.C = dact; e.ldc = lddact; e.R = nullptr; e.ldr = 0;
+    e.Cadd = nullptr; e.ldadd = 0; e.add_S = 1; e.add_Spad = 1; e.add_off = 0;
+    e.M = M; e.N = I; e.alpha = 1.f; e.beta = 0.f;
+#ifdef SF_EMU
+    const bool big = K >= 512;
+#else
+    const bool big = (long)(M / 256) * (I / 256) >= 256 && K >= 512;
+#endif
+    static const int fuse = sf_knob("SF_GEMM_SWIGLU_FUSE", 1);
+    const bool aligned = ((size_t)gu & 15) == 0 && ((size_t)dgu & 15) == 0 && ((size_t)dact & 15) == 0;
+    if (fuse && big && aligned && M % 256 == 0 && I % 256 == 0 && K % 64 == 0 && sf_gemm_use_256()) {
+        e.sw_gu = (const sf_bf16*)gu; e.sw_ldgu = ldgu;
+        e.sw_dgu = (sf_bf16*)dgu; e.sw_lddgu = lddgu;
+        return sf_gemm_nt_256w4_launch(A, lda, B, ldb, K, e, SF_BF16, stream);
+    }
+    if (int st = sf_gemm_dispatch(A, lda, B, ldb, K, e, SF_BF16, stream)) return st;
+    return sf_swiglu_bwd(dact, SF_BF16, lddact, gu, ldgu, M, I, dgu, lddgu, stream);
+}
+
 extern "C" int sf_gemm_nt_rowadd(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M,
                                  int N, int K, float alpha, const float* Cadd, long ldadd, int S, int Spad, int off,
                                  void* stream) {

@@ -472,14 +472,45 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                     *reinterpret_cast<sf_v4s*>(st + r * kStageRow + j * 32 + q * 8) = o;
                 }
                 sf_wave_lockstep();
+                if (p.e.sw_gu) {
+                    // fused d(SwiGLU): this row segment of d(act) never goes to memory.  gate / up of the same 8 positions
+                    // come in (the loads of all four segments first), d(gate) / d(up) go out -- the arithmetic and its
+                    // bf16 roundings are those of swiglu_bwd_kernel on the stored d(act)
+                    const long row0 = mc + wr * 128 + i * 16 + q;
+                    const int col = nc + wc * 128 + r * 8;
+                    sf_v8s gq[4], uq[4];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {         // rows 4*s4 + q of this m-tile, 16 bytes at column 8*r
-                    const sf_v8s d = *reinterpret_cast<const sf_v8s*>(st + (4 * s4 + q) * kStageRow + r * 16);
-                    *reinterpret_cast<sf_v8s*>(cbase + (long)(i * 16 + 4 * s4) * p.e.ldc) = d;
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const sf_bf16* gp = p.e.sw_gu + (row0 + 4 * s4) * p.e.sw_ldgu + col;
+                        gq[s4] = *reinterpret_cast<const sf_v8s*>(gp);
+                        uq[s4] = *reinterpret_cast<const sf_v8s*>(gp + p.N);
+                    }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const sf_v8s d = *reinterpret_cast<const sf_v8s*>(st + (4 * s4 + q) * kStageRow + r * 16);
+                        sf_v8s og, ou;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float dg, du;
+                            sf_swiglu_bwd_elem<sf_bf16>(sf_bf2f((sf_bf16)gq[s4][e]), sf_bf2f((sf_bf16)uq[s4][e]),
+                                                        sf_bf2f((sf_bf16)d[e]), dg, du);
+                            og[e] = (short)sf_f2bf(dg);
+                            ou[e] = (short)sf_f2bf(du);
+                        }
+                        sf_bf16* op = p.e.sw_dgu + (row0 + 4 * s4) * p.e.sw_lddgu + col;
+                        *reinterpret_cast<sf_v8s*>(op) = og;
+                        *reinterpret_cast<sf_v8s*>(op + p.N) = ou;
+                    }
+                } else {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {         // rows 4*s4 + q of this m-tile, 16 bytes at column 8*r
+                        const sf_v8s d = *reinterpret_cast<const sf_v8s*>(st + (4 * s4 + q) * kStageRow + r * 16);
+                        *reinterpret_cast<sf_v8s*>(cbase + (long)(i * 16 + 4 * s4) * p.e.ldc) = d;
+                    }
                 }
                 sf_wave_lockstep();
             }
-            newer = 32;
+            newer = 32;   // (the fused form issues 64 stores + 64 loads: more, which is the safe direction)
         }
     } else {
 #pragma unroll

@@ -15,6 +15,11 @@ struct SfGemmEpi {
     int add_S, add_Spad, add_off;
     int M, N;
     float alpha, beta;
+    // fused d(SwiGLU) (4-wave kernel, interior bf16 tiles only; the launcher guarantees it): the GEMM's result is d(act)
+    // [M, N = I]; instead of storing it, every 8-value row segment reads gate / up at the same position of gu [M, 2I] and
+    // writes d(gate) / d(up) to dgu [M, 2I].  Null = plain store.
+    const sf_bf16* sw_gu = nullptr; long sw_ldgu = 0;
+    sf_bf16* sw_dgu = nullptr; long sw_lddgu = 0;
 };
 
 // ADD = 0 compiles the addend out (the 4-wave kernel's register allocation is sensitive to epilogue code, so its

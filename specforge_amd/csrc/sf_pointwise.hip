@@ -242,12 +242,7 @@ SF_GLOBAL void swiglu_bwd_kernel(const T* dact, long lddact, const T* gu, long l
         SfVec8<T>::ld(gu + r * ldgu + I + j, up);
         SfVec8<T>::ld(dact + r * lddact + j, da);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float sg = 1.0f / (1.0f + sf_exp(-g[i]));
-            float silu = g[i] * sg;
-            dg[i] = da[i] * up[i] * (sg * (1.0f + g[i] * (1.0f - sg)));
-            du[i] = da[i] * SfElem<T>::rnd(silu);
-        }
+        for (int i = 0; i < 8; ++i) sf_swiglu_bwd_elem<T>(g[i], up[i], da[i], dg[i], du[i]);
         SfVec8<T>::st(dgu + r * lddgu + j, dg);
         SfVec8<T>::st(dgu + r * lddgu + I + j, du);
     }

@@ -49,6 +49,16 @@ template <> struct SfRaw8<float> {
     SF_DEVICE float at(int i) const { return i < 4 ? a[i] : b[i - 4]; }
 };
 
+// d(SwiGLU): act = round_T(silu(g)) * u  ->  dg = da * u * silu'(g), du = da * round_T(silu(g)); one definition for the
+// standalone kernel and the fused GEMM epilogue, so the two produce the same bits
+template <typename T>
+SF_DEVICE void sf_swiglu_bwd_elem(float g, float up, float da, float& dg, float& du) {
+    const float sg = 1.0f / (1.0f + sf_exp(-g));
+    const float silu = g * sg;
+    dg = da * up * (sg * (1.0f + g * (1.0f - sg)));
+    du = da * SfElem<T>::rnd(silu);
+}
+
 // Sum / max over a whole workgroup (blockDim.x multiple of 64, <= 1024).  `red` is LDS
 // scratch of >= 16 floats owned by the caller; result is returned to every thread.
 SF_DEVICE float sf_block_sum(float v, float* red) {

@@ -447,8 +447,7 @@ class Eagle3Engine:
             else:
                 ops.add_bf16(b["dln"][k], dh_next, dh)
             # MLP
-            ops.gemm_nt(dh, self.wdT, b["dact"])
-            ops.swiglu_bwd(b["dact"], b["gu"][k], dgu)
+            ops.gemm_nt_swiglu_bwd(dh, self.wdT, b["gu"][k], dgu, b["dact"])   # down dgrad + d(SwiGLU) in its epilogue
             ops.gemm_nt(dgu, self.wguT, b["dpn"])
             acc, a = nacc("midlayer.post_attention_layernorm.weight")
             ops.rmsnorm_bwd(b["dpn"], b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"), b["rstd_p"][k],

@@ -174,6 +174,18 @@ def swiglu_fwd(gu: torch.Tensor, act: torch.Tensor):
     return act
 
 
+def gemm_nt_swiglu_bwd(a: torch.Tensor, b: torch.Tensor, gu: torch.Tensor, dgu: torch.Tensor, dact: torch.Tensor):
+    """dgu = d(SwiGLU)(a @ b.T, gu): the down-projection input gradient with the activation's backward in its epilogue
+    (one launch for chip-filling shapes; gemm_nt + swiglu_bwd through `dact` otherwise)"""
+    L = _lib.lib()
+    M, K = a.shape
+    I = b.shape[0]
+    assert b.shape[1] == K and gu.shape == (M, 2 * I) and dgu.shape == (M, 2 * I) and dact.shape == (M, I)
+    assert a.dtype == b.dtype == gu.dtype == dgu.dtype == dact.dtype == torch.bfloat16
+    _lib.check(L.sf_gemm_nt_swiglu_bwd(_p(a), _rowmajor(a), _p(b), _rowmajor(b), M, I, K, _p(gu), _rowmajor(gu), _p(dgu),
+                                       _rowmajor(dgu), _p(dact), _rowmajor(dact), _stream()), "sf_gemm_nt_swiglu_bwd")
+
+
 def swiglu_bwd(dact: torch.Tensor, gu: torch.Tensor, dgu: torch.Tensor):
     L = _lib.lib()
     rows, I = dact.shape

@@ -365,6 +365,25 @@ def test_swiglu(backend, dtype, tol):
     torch.testing.assert_close(dgu.float().cpu(), gr.grad.float(), rtol=tol, atol=tol * float(gr.grad.abs().max()))
 
 
+@pytest.mark.parametrize("M,I,K", [(512, 768, 512),    # whole 256 x 256 tiles, long K: the fused epilogue of the 4-wave kernel (interpreter)
+                                   (300, 264, 128)])   # everything else: gemm_nt + swiglu_bwd through the scratch
+def test_gemm_nt_swiglu_bwd_equals_the_two_steps(backend, M, I, K):
+    """d(act) = dY . W_down with d(SwiGLU) in the GEMM epilogue == the same GEMM followed by swiglu_bwd (same roundings)"""
+    dy, w = _rand((M, K), torch.bfloat16, 1), _rand((I, K), torch.bfloat16, 2)
+    gu = _rand((M, 2 * I), torch.bfloat16, 3)
+    d = lambda t: t.to(backend)
+    dact = torch.empty((M, I), dtype=torch.bfloat16, device=backend)
+    ref = torch.empty((M, 2 * I), dtype=torch.bfloat16, device=backend)
+    ops.gemm_nt(d(dy), d(w), dact)
+    ops.swiglu_bwd(dact, d(gu), ref)
+    out = torch.full((M, 2 * I), 7.0, dtype=torch.bfloat16, device=backend)
+    scratch = torch.empty((M, I), dtype=torch.bfloat16, device=backend)
+    ops.gemm_nt_swiglu_bwd(d(dy), d(w), d(gu), out, scratch)
+    same = float((out == ref).float().mean())
+    assert same >= 0.999, same                       # fp contraction may differ between the two call sites: <= 1 bf16 ulp, rarely
+    torch.testing.assert_close(out.float().cpu(), ref.float().cpu(), rtol=2 ** -6, atol=1e-30)
+
+
 def test_transpose_and_cast(backend):
     x = _rand((72, 200), torch.bfloat16, 1)
     out = torch.empty((200, 72), dtype=torch.bfloat16, device=backend)

@@ -53,6 +53,26 @@ def test_gemm_nt_headline_shapes(M, N, K, out_dtype):
         torch.testing.assert_close(out.float(), (ref.to(torch.bfloat16) + res).float(), rtol=2e-2, atol=2e-2 * math.sqrt(K))
 
 
+def test_gemm_nt_swiglu_bwd_headline_shape():
+    """the down-projection input gradient with d(SwiGLU) fused (16384 x 14336 x 4096: 64 x 56 whole tiles, persistent walk)
+    against gemm_nt + swiglu_bwd on the same operands"""
+    M, I, K = 16384, 14336, 4096
+    dy, w = _randn((M, K), 1), _randn((I, K), 2)
+    gu = _randn((M, 2 * I), 3, scale=2.0)
+    dact = torch.empty((M, I), dtype=torch.bfloat16, device=DEV)
+    ref = torch.empty((M, 2 * I), dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(dy, w, dact)
+    ops.swiglu_bwd(dact, gu, ref)
+    out = torch.full((M, 2 * I), 7.0, dtype=torch.bfloat16, device=DEV)
+    scratch = torch.full((M, I), 5.0, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt_swiglu_bwd(dy, w, gu, out, scratch)
+    assert float((scratch == 5.0).float().mean()) == 1.0          # fused: d(act) is never written
+    same = float((out == ref).float().mean())
+    print(f"\n[swiglu-fused dgrad] identical elements {same:.6f}")
+    assert same >= 0.999, same
+    torch.testing.assert_close(out.float(), ref.float(), rtol=2 ** -6, atol=1e-30)
+
+
 def test_gemm_nt_rowadd_headline_shape():
     M, N, K, S, T = 16384, 6144, 4096, 2048, 7
     B, Spad = M // S, S + T
