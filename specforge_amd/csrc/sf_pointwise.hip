@@ -225,7 +225,7 @@ SF_GLOBAL void swiglu_fwd_kernel(const T* gu, long ldgu, int I, long rows, T* ac
         SfVec8<T>::ld(gu + r * ldgu + I + j, up);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float sg = 1.0f / (1.0f + sf_exp(-g[i]));
+            float sg = 1.0f / (1.0f + sf_exp_fast(-g[i]));
             o[i] = SfElem<T>::rnd(g[i] * sg) * up[i];
         }
         SfVec8<T>::st(act + r * ldact + j, o);
