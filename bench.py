@@ -47,7 +47,8 @@ class GemmTimer:
     """HIP events around every sf_gemm_nt launch on the current stream (the launch stream)."""
 
     def __init__(self):
-        self.records = []
+        self.records = []   # sf_gemm_nt: the plain instantiations of the dominant kernel (roofline object)
+        self.fused = []     # sf_gemm_nt_swiglu_bwd: the same main loop with d(SwiGLU) in its epilogue (its own kernel symbol)
 
     def wrap(self, ops):
         orig = ops.gemm_nt
@@ -61,12 +62,27 @@ class GemmTimer:
             return r
 
         ops.gemm_nt = timed
+        orig_sw = ops.gemm_nt_swiglu_bwd
+
+        def timed_sw(a, b, gu, dgu, dact):   # the down-projection dgrad with d(SwiGLU) in its epilogue: same kernel, same flops
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig_sw(a, b, gu, dgu, dact)
+            e.record()
+            self.fused.append((2.0 * a.shape[0] * b.shape[0] * a.shape[1], s, e))
+            return r
+
+        ops.gemm_nt_swiglu_bwd = timed_sw
+        self._orig_sw = orig_sw
         return orig
 
     def summary(self):
         fl = sum(r[0] for r in self.records)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
         return fl, ms, len(self.records)
+
+    def fused_summary(self):
+        return (sum(r[0] for r in self.fused), sum(r[1].elapsed_time(r[2]) for r in self.fused), len(self.fused))
 
 
 def make_batch(cfg, B, S, dev, seed):
@@ -200,6 +216,7 @@ def main():
         elapsed = time.perf_counter() - t0
         if orig is not None:
             ops.gemm_nt = orig
+            ops.gemm_nt_swiglu_bwd = timer._orig_sw
         if world > 1:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -273,6 +290,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": GEMM_KERNEL_NAME, "achieved": ach,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "traffic_source": traffic_src, "launches_per_step": nlaunch / max(1, args.steps),
+                         "fused_swiglu_dgrad": {"launches_per_step": timer.fused_summary()[2] / max(1, args.steps),
+                                                "ms_per_step": timer.fused_summary()[1] / max(1, args.steps),
+                                                "gemm_tflops": (timer.fused_summary()[0] / max(timer.fused_summary()[1], 1e-9)) / 1e9},
                          "gemm_ms_per_step": gemm_ms / max(1, args.steps)},
             "final_loss": loss,
             "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 1e9,

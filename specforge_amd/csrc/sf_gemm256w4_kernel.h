@@ -213,6 +213,8 @@ template <int SCHED> using W4PlanFor = std::conditional_t<SCHED == 13, W4PlanAFi
 // SCHED: 12 = W4PlanBFirst, 13 = W4PlanAFirst (product); 0 and 2..11 exist in the tools build only.
 // ABL (tools build, timing ablations of the round-1 schedule only, results are wrong): bit0 = no ds_reads after the first
 // tile, bit1 = no DMA in the loop, ...
+// ADD: 0 = plain, 1 = accumulators start from the fp32 row-mapped addend (sf_gemm_nt_rowadd), 2 = d(SwiGLU) in the bf16 epilogue
+// (sf_gemm_nt_swiglu_bwd; whole tiles only -- its launcher guarantees it)
 template <int OUT_F32, int ADD = 0, int SCHED = 12, int ABL = 0>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     SF_DYN_SMEM(smem);
@@ -289,7 +291,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
-    if (ADD) {
+    if (ADD == 1) {
         // row-mapped fp32 addend: START the accumulators from it (alpha == 1 is enforced by the launcher), so the
         // K loop and the epilogue are exactly the plain kernel's -- the loads overlap the staging of K-tiles 0 and 1
 #pragma unroll
@@ -419,7 +421,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     const int next = tile + (int)gridDim.x;
     // (the row-addend form is launched one workgroup per tile -- sf_w4_grid -- and compiles without the second tile:
     //  a second call site of its 256-register accumulator load made the compiler spill 152 registers)
-    const bool has_next = !ADD && next < nblk;
+    const bool has_next = ADD != 1 && next < nblk;
     w4_wait_lgkm();
     w4_barrier();                 // every wave's last fragment reads returned: both K-tile buffers are free
     if (has_next) {
@@ -472,7 +474,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                     *reinterpret_cast<sf_v4s*>(st + r * kStageRow + j * 32 + q * 8) = o;
                 }
                 sf_wave_lockstep();
-                if (p.e.sw_gu) {
+                if constexpr (ADD == 2) {   // its own instantiation: a different operator with its own line in a kernel trace
                     // fused d(SwiGLU): this row segment of d(act) never goes to memory.  gate / up of the same 8 positions
                     // come in (the loads of all four segments first), d(gate) / d(up) go out -- the arithmetic and its
                     // bf16 roundings are those of swiglu_bwd_kernel on the stored d(act)
@@ -520,7 +522,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                 w4_store4<OUT_F32, 0>(p, mc + wr * 128 + i * 16 + (lane & 15), nc + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
     }
     if (!has_next) break;
-    if constexpr (ADD != 0) break;
+    if constexpr (ADD == 1) break;
 
     // ---- the next tile: accumulators, then its K-tiles 0 and 1 (in flight since before the epilogue) must have landed.
     // vmcnt retires in order, so "all but the `newer` youngest" covers the DMAs without waiting for the epilogue's stores.
@@ -579,8 +581,9 @@ static inline unsigned sf_w4_grid(long nblk, int add = 0) {
 #define SF_W4_DEFINE(F32, ADD, SCHED)                                                                                  \
     SF_W4_DECLARE(F32, ADD, SCHED) {                                                                                   \
         SF_W4_SMEM((gemm_nt_256w4_kernel<F32, ADD, SCHED>));                                                           \
-        SF_LAUNCH((gemm_nt_256w4_kernel<F32, ADD, SCHED>), dim3(sf_w4_grid(nblk, ADD)), dim3(256), kW4SmemBytes, stream, p); \
+        SF_LAUNCH((gemm_nt_256w4_kernel<F32, ADD, SCHED>), dim3(sf_w4_grid(nblk, ADD == 1)), dim3(256), kW4SmemBytes, stream, p); \
         return sf_check_launch("sf_gemm_nt(256w4)");                                                                   \
     }
 SF_W4_DECLARE(0, 0, 12); SF_W4_DECLARE(0, 0, 13); SF_W4_DECLARE(1, 0, 12); SF_W4_DECLARE(1, 0, 13);
 SF_W4_DECLARE(0, 1, 12); SF_W4_DECLARE(0, 1, 13); SF_W4_DECLARE(1, 1, 12); SF_W4_DECLARE(1, 1, 13);
+SF_W4_DECLARE(0, 2, 12); SF_W4_DECLARE(0, 2, 13);
