@@ -47,6 +47,12 @@ def _run(cmd):
     return r.stdout
 
 
+# per-file extra flags.  sf_attn.hip: without -fno-honor-nans every fmaxf on an MFMA result is preceded by a canonicalising
+# v_max_f32 x, x (the compiler cannot prove the accumulator is not a signalling NaN): 32 extra VALU per 64-key tile in the
+# online softmax.  Infinities keep their meaning (the causal mask is -inf).
+EXTRA_FLAGS = {"sf_attn.hip": ["-fno-honor-nans"]}
+
+
 def _build(lib, objdir, compile_cmd, link_cmd, force=False):
     os.makedirs(objdir, exist_ok=True)
     deps = _deps()
@@ -57,7 +63,7 @@ def _build(lib, objdir, compile_cmd, link_cmd, force=False):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + deps):
-            jobs.append(compile_cmd + ["-c", src, "-o", obj])
+            jobs.append(compile_cmd + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(_run, jobs))

@@ -25,12 +25,6 @@
 
 namespace {
 
-#ifdef SF_EMU
-static const sf_bf16 sf_zero16a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#else
-__device__ const sf_bf16 sf_zero16a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-
 #ifdef SF_ABLATE   // profiling experiments of the tools build: 1 = stage tile 0 only, 2 = skip the MFMA / softmax work
 #define SF_ATTN_DBG(p, bit) ((p).dbg & (bit))
 #else
@@ -41,6 +35,22 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kNegBig = -1.0e30f;
 constexpr int kMaxDiag = 8;
+
+// ---- L2-aware work order ----------------------------------------------------
+// Workgroup ids are handed to the 8 XCDs round-robin (block b runs on XCD b % 8: observed, relied on for speed only) and
+// each XCD has its own 4 MiB L2.  The tiles a workgroup streams (K/V of one (batch, kv head) for fwd / dQ; Q and dO of
+// the group's query heads for dK/dV) are shared by every workgroup of that (batch, kv head) "pair" -- 1 MiB of K + V at
+// S = 2048, hd = 128.  Dispatching the heaviest blocks of ALL pairs first spread 32 different pairs over the 64
+// workgroups resident on one XCD, so nearly every tile load missed L2: rocprofv3 showed 3.3 GB of fabric reads per
+// forward launch against 0.34 GB of algorithmic bytes, i.e. the kernel ran at the fabric's 6.6 TB/s, not at the MFMA
+// rate.  The work list is therefore ordered pair-major (heaviest block first INSIDE a pair) and cut into 8 contiguous
+// ranges, one per XCD: the workgroups resident on an XCD at any time belong to one or two pairs.
+SF_DEVICE int attn_work_index(int bid, int total, int l2_map) {
+    if (!l2_map) return bid;
+    const int per_xcd = (total + 7) >> 3;
+    return (bid & 7) * per_xcd + (bid >> 3);   // >= total: no work for this workgroup
+}
+static inline unsigned attn_grid(long total, int l2_map) { return (unsigned)(l2_map ? 8 * ((total + 7) / 8) : total); }
 
 struct AttnFwdArgs {
     const sf_bf16* q; long ldq;        // [B*S, nh*hd] view, row stride ldq
@@ -54,6 +64,7 @@ struct AttnFwdArgs {
     float* lse;                        // [B, nh, S] natural-log lse over all S+k columns
     int B, S, nh, nkv;
     float scale;
+    int l2_map;  // pair-major work order (attn_work_index); 0 only in the tools build's A/B
     int dbg;  // profiling experiments only (SF_ATTN_DBG): 1 = stage tile 0 only, 2 = skip the MFMA/softmax work
 };
 
@@ -68,22 +79,43 @@ SF_DEVICE int swz(int r) {
 }
 
 // ---- LDS tile staging -------------------------------------------------------
-// natural tile: 64 rows (keys / queries) x HD, row-major, 16-byte chunks XOR-swizzled by row&7
-template <int HD, int NW>
-SF_DEVICE void stage_rows64(char* lds, const sf_bf16* base, long ld, int row0, int nrows_valid, int wave, int lane) {
-    constexpr int CPR = HD / 8;            // chunks per row
-    constexpr int RPI = 64 / CPR;          // rows per wave-instruction (1 KiB)
-    constexpr int NP = 64 / RPI;           // 1 KiB pieces per tile
-    constexpr int NI = (NP + NW - 1) / NW; // instructions per wave
+// A tile of R rows x HD (row-major in LDS, 16-byte chunks XOR-swizzled by swz<HD>(row)) arrives as R*HD*2/1024 pieces
+// of 1 KiB, one LDS-DMA wave-instruction each, through a BOUNDED buffer descriptor: rows at or past the end of the
+// sequence read as zeros without a select or a branch.  `off[t]` = byte offset of this lane's 16-byte chunk of piece t
+// relative to the tile's first row; a tile is staged with one add + one DMA per piece (the pointer form this replaces
+// compiled to ~10 instructions per piece, exec-masked).
+// Nothing in a tile loop may be a compiler-visible VMEM load: vmcnt is ONE in-order counter, so any wait the compiler
+// inserts for a load of its own also drains the DMA prefetch of the next tile (which it cannot see).  Round 2's kernels
+// had exactly that: the Q / K fragments loaded ahead of the loop were waited for at their first use INSIDE the loop
+// (vmcnt(7)..vmcnt(0) in front of the QK^T MFMAs, every iteration), and the dK/dV kernel staged lse / delta through
+// registers (global_load; vmcnt(0); ds_write) right behind the DMA issue -- the prefetch never overlapped anything.
+template <int HD, int ROWS, int NW>
+struct TileStage {
+    static constexpr int CPR = HD / 8, RPI = 64 / CPR, NP = ROWS / RPI, NI = (NP + NW - 1) / NW;
+    unsigned off[NI];
+    int piece0;
+    SF_DEVICE void init(long ld, int wave, int lane) {
+        piece0 = wave * NI;
 #pragma unroll
-    for (int t = 0; t < NI; ++t) {
-        if (NP % NW != 0 && wave * NI + t >= NP) break;  // wave-uniform
-        const int rr = (wave * NI + t) * RPI + lane / CPR;
-        const int pc = lane % CPR;
-        const int lc = pc ^ swz<HD>(rr);
-        const sf_bf16* src = (row0 + rr < nrows_valid) ? base + (long)(row0 + rr) * ld + lc * 8 : sf_zero16a;
-        sf_glds16_opaque(src, lds + (wave * NI + t) * 1024);  // uniform base; lane i lands at +16*i
+        for (int t = 0; t < NI; ++t) {
+            const int rr = (piece0 + t) * RPI + lane / CPR;
+            const int lc = (lane % CPR) ^ swz<HD>(rr);
+            off[t] = (unsigned)(((long)rr * ld + lc * 8) * 2);
+        }
     }
+    // `row_bytes` = first row of the tile * ld * 2 (wave-uniform); `lds` = tile base (wave-uniform)
+    SF_DEVICE void issue(SfBufB buf, unsigned row_bytes, char* lds) const {
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+            if (NP % NW != 0 && piece0 + t >= NP) break;  // wave-uniform
+            sf_bufb_glds16(buf, off[t] + row_bytes, lds + (piece0 + t) * 1024);
+        }
+    }
+};
+// descriptor over the rows [0, S) of one (batch, head) slice: base = first row, row stride ld elements
+template <int HD>
+SF_DEVICE SfBufB rows_buf(const sf_bf16* base, long ld, int S) {
+    return sf_make_bufb(base, (unsigned)((((long)S - 1) * ld + HD) * 2));
 }
 // Per-lane LDS byte offsets of the MFMA fragments, computed once per kernel so the tile loops issue
 // ds_reads with (register + immediate) addresses only.  Tile row blocks start at multiples of 32
@@ -139,6 +171,13 @@ SF_DEVICE float dot8(sf_v8s a, sf_v8s b) {
 }
 
 // ------------------------------------------------------------------ forward
+// -inf where the tile-relative key index `c` is past `rel` (= last visible key - first key of the block - 4 * hi)
+SF_DEVICE void mask_scores(sf_v16f& s, int rel) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if ((r & 3) + 8 * (r >> 2) > rel) s[r] = -INFINITY;
+}
+
 template <int HD, int NW>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
     constexpr int KS = HD / 16, DB = HD / 32, QB = NW * 32, TILE = 128 * HD * 2;
@@ -147,10 +186,20 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
     // 1-D grid, heaviest work first: the causal key range grows with the query block, so the LAST query blocks are
     // dispatched first (longest-processing-time order keeps the tail of the launch short)
     const int nqb = (p.S + QB - 1) / QB, per_qb = p.nh * p.B;
-    const int bid = (int)blockIdx.x;
-    const int qbi = nqb - 1 - bid / per_qb, hb = bid % per_qb;
-    const int qb0 = qbi * QB, h = hb % p.nh, b = hb / p.nh;
-    const int g = h / (p.nh / p.nkv);
+    int qbi, h, b, g;
+    if (p.l2_map) {   // pair-major: (batch, kv head) -> query block (last = heaviest first) -> query head of the group
+        const int nrep = p.nh / p.nkv, W = nrep * nqb;
+        const int v = attn_work_index((int)blockIdx.x, W * p.nkv * p.B, 1);
+        if (v >= W * p.nkv * p.B) return;
+        const int pr = v / W, w = v - pr * W;
+        b = pr / p.nkv; g = pr - b * p.nkv;
+        qbi = nqb - 1 - w / nrep; h = g * nrep + w % nrep;
+    } else {
+        const int bid = (int)blockIdx.x, hb = bid % per_qb;
+        qbi = nqb - 1 - bid / per_qb; h = hb % p.nh; b = hb / p.nh;
+        g = h / (p.nh / p.nkv);
+    }
+    const int qb0 = qbi * QB;
     const int S = p.S;
     const int kvlen = p.kv_len ? p.kv_len[b] : S;
     const int qw0 = qb0 + wave * 32;
@@ -158,6 +207,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
     const bool qok = qi < S;
     const long qrow = (long)b * S + (qok ? qi : S - 1);
     const float sc = p.scale * kLog2e;
+    const int lim = qi < kvlen - 1 ? qi : kvlen - 1;   // last key this query attends to in block 0
     FragOff<HD> fo;
     fo.init(lane);
 
@@ -173,23 +223,28 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
         for (int r = 0; r < 16; ++r) acc_o[d][r] = 0.f;
     float m = kNegBig, lpart = 0.f;
 
-    const sf_bf16* kbase = p.k0 + (long)b * S * p.ldk + g * HD;
-    const sf_bf16* vbase = p.v0 + (long)b * S * p.ldk + g * HD;
+    const SfBufB kbuf = rows_buf<HD>(p.k0 + (long)b * S * p.ldk + g * HD, p.ldk, S);
+    const SfBufB vbuf = rows_buf<HD>(p.v0 + (long)b * S * p.ldk + g * HD, p.ldk, S);
+    const unsigned tile_bytes = (unsigned)(64 * p.ldk * 2);
+    TileStage<HD, 64, NW> st;
+    st.init(p.ldk, wave, lane);
     int kend = qb0 + QB < S ? qb0 + QB : S;  // causal upper bound for this block
     if (kvlen < kend) kend = kvlen;
     const int ntiles = (kend + 63) / 64;
     if (ntiles > 0) {
-        stage_rows64<HD, NW>(smem, kbase, p.ldk, 0, S, wave, lane);
-        stage_rows64<HD, NW>(smem + 64 * HD * 2, vbase, p.ldk, 0, S, wave, lane);
+        st.issue(kbuf, 0, smem);
+        st.issue(vbuf, 0, smem + 64 * HD * 2);
     }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) sf_pin(qf[ks]);   // the Q loads are complete HERE, not at their first use in the loop
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 64;
         sf_wait_vm0();
         sf_syncthreads();  // tile kt landed for everyone; buffer (kt+1)&1 is no longer being read
         if (kt + 1 < ntiles && !SF_ATTN_DBG(p, 1)) {
             char* nb = smem + ((kt + 1) & 1) * TILE;
-            stage_rows64<HD, NW>(nb, kbase, p.ldk, key0 + 64, S, wave, lane);
-            stage_rows64<HD, NW>(nb + 64 * HD * 2, vbase, p.ldk, key0 + 64, S, wave, lane);
+            st.issue(kbuf, (unsigned)(kt + 1) * tile_bytes, nb);
+            st.issue(vbuf, (unsigned)(kt + 1) * tile_bytes, nb + 64 * HD * 2);
         }
         const char* lds_k = smem + (kt & 1) * TILE;
         const char* lds_v = lds_k + 64 * HD * 2;
@@ -207,20 +262,16 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) s[kb] = sf_mfma32(frag_rows<HD>(lds_k, kb * 32, ks, fo), qf[ks], s[kb]);
-        // scores stay unscaled in the accumulators; only diagonal / padded tiles pay for masking
+        // scores stay unscaled in the accumulators; only diagonal / padded tiles pay for masking (2 VALU per score)
         if (need_mask) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kk = key0 + kb * 32 + crow(r, hi);
-                    if (kk > qi || kk >= kvlen) s[kb][r] = -INFINITY;
-                }
+            const int rel = lim - key0 - 4 * hi;
+            mask_scores(s[0], rel);
+            mask_scores(s[1], rel - 32);
         }
         float mt = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s[0][r], s[1][r]));
-        mt = fmaxf(mt, sf_shfl_xor(mt, 32));
+        mt = sf_pair_max(mt);
         const float mts = mt * sc;  // running max m lives in the scaled log2 domain
         // deferred rescale: O and l are rescaled only when some row's max grew by more than 2^8
         if (!sf_all(mts - m <= 8.0f)) {
@@ -253,62 +304,64 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
                     acc_o[d] = sf_mfma32(frag_tr<HD>(lds_v, d, kb * 32 + 16 * jp, fo), pf, acc_o[d]);
             }
     }
-    float l = lpart + sf_shfl_xor(lpart, 32);
+    float l = sf_pair_sum(lpart);
 
-    // diagonal branch terms: one extra key per later TTT step at the query's own position
-    for (int i = 0; i < p.ndiag; ++i) {
-        sf_v8s kk[KS];
-        sf_v4s vv4[DB * 4];
-        if (NW == 4) {
-            // the block's 128 K_i / V_i rows go through LDS (coalesced LDS-DMA into the two free tile buffers) and every
-            // lane picks its own query's row from there; per-lane global reads of 32 different rows cost ~2x the
-            // whole main loop at 6 branches
-            sf_syncthreads();
-            const sf_bf16* kdb = p.kd[i] + (long)b * S * p.ldk + g * HD;
-            const sf_bf16* vdb = p.vd[i] + (long)b * S * p.ldk + g * HD;
-            stage_rows64<HD, NW>(smem, kdb, p.ldk, qb0, S, wave, lane);
-            stage_rows64<HD, NW>(smem + 64 * HD * 2, kdb, p.ldk, qb0 + 64, S, wave, lane);
-            stage_rows64<HD, NW>(smem + 128 * HD * 2, vdb, p.ldk, qb0, S, wave, lane);
-            stage_rows64<HD, NW>(smem + 192 * HD * 2, vdb, p.ldk, qb0 + 64, S, wave, lane);
+    // diagonal branch terms: one extra key per later TTT step at the query's own position.  A wave only ever needs the
+    // K_i / V_i rows of its OWN 32 queries, so each wave stages them into a private slice of the (now free) tile
+    // buffers -- no workgroup barrier per branch -- and the next branch's rows are in flight while this one is applied
+    // (round 2: four cooperative 16 KiB stagings, two barriers and an exposed wait per branch).
+    if (p.ndiag > 0) {
+        constexpr int PRIV = 2 * TILE / NW;             // bytes of LDS per wave: K_i rows | V_i rows
+        static_assert(PRIV >= 2 * 32 * HD * 2, "a wave's slice of the tile buffers holds 32 rows of K_i and of V_i");
+        char* mine = smem + wave * PRIV;
+        TileStage<HD, 32, 1> ds;
+        ds.init(p.ldk, 0, lane);
+        const unsigned my_rows = (unsigned)((long)qw0 * p.ldk * 2);
+        sf_syncthreads();                               // every wave is done with the last K/V tile
+        auto stage_diag = [&](int i) {
+            const long slice = (long)b * S * p.ldk + g * HD;
+            ds.issue(rows_buf<HD>(p.kd[i] + slice, p.ldk, S), my_rows, mine);
+            ds.issue(rows_buf<HD>(p.vd[i] + slice, p.ldk, S), my_rows, mine + 32 * HD * 2);
+        };
+        stage_diag(0);
+        for (int i = 0; i < p.ndiag; ++i) {
             sf_wait_vm0();
-            sf_syncthreads();
+            sf_wave_lockstep();   // (interpreter only: the other lanes' pieces of this wave's DMA have been copied)
+            sf_v8s kk[KS];
+            sf_v4s vv4[DB * 4];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kk[ks] = frag_rows<HD>(smem, wave * 32, ks, fo);
-            const char* vrow = smem + 128 * HD * 2 + (wave * 32 + c) * (HD * 2) + 8 * hi;
+            for (int ks = 0; ks < KS; ++ks) kk[ks] = frag_rows<HD>(mine, 0, ks, fo);
+            const char* vrow = mine + 32 * HD * 2 + c * (HD * 2) + 8 * hi;
 #pragma unroll
             for (int d = 0; d < DB; ++d)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     vv4[d * 4 + j] = *reinterpret_cast<const sf_v4s*>(vrow + (((4 * d + j) ^ swz<HD>(c)) << 4));
-        } else {
-            const sf_bf16* kr = p.kd[i] + qrow * p.ldk + g * HD;
-            const sf_bf16* vr = p.vd[i] + qrow * p.ldk + g * HD;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kk[ks] = *reinterpret_cast<const sf_v8s*>(kr + 16 * ks + 8 * hi);
+            for (int ks = 0; ks < KS; ++ks) sf_pin(kk[ks]);      // the reads have returned: the slice may be overwritten
+#pragma unroll
+            for (int j = 0; j < DB * 4; ++j) sf_pin(vv4[j]);
+            if (i + 1 < p.ndiag) stage_diag(i + 1);
+            float dp = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) dp += dot8(qf[ks], kk[ks]);
+            dp = sf_pair_sum(dp);
+            const float s2 = dp * sc;
+            const float mn = fmaxf(m, s2);
+            const float alpha = sf_exp2(m - mn);
+            const float e = sf_exp2(s2 - mn);
+            m = mn;
+            l = l * alpha + e;
 #pragma unroll
             for (int d = 0; d < DB; ++d)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) vv4[d * 4 + j] = *reinterpret_cast<const sf_v4s*>(vr + d * 32 + 8 * j + 4 * hi);
+                for (int j = 0; j < 4; ++j) {
+                    const sf_v4s vv = vv4[d * 4 + j];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc_o[d][4 * j + t] = acc_o[d][4 * j + t] * alpha + e * sf_bf2f((sf_bf16)vv[t]);
+                }
         }
-        float dp = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) dp += dot8(qf[ks], kk[ks]);
-        dp += sf_shfl_xor(dp, 32);
-        const float s2 = dp * sc;
-        const float mn = fmaxf(m, s2);
-        const float alpha = sf_exp2(m - mn);
-        const float e = sf_exp2(s2 - mn);
-        m = mn;
-        l = l * alpha + e;
-#pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const sf_v4s vv = vv4[d * 4 + j];
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc_o[d][4 * j + t] = acc_o[d][4 * j + t] * alpha + e * sf_bf2f((sf_bf16)vv[t]);
-            }
     }
     if (!qok) return;
     const float inv = l > 0.f ? 1.0f / l : 0.f;
@@ -462,6 +515,7 @@ struct AttnBwdArgs {
     float* dk; float* dv; long lddk; // fp32 accumulators (+=) [B*S, nkv*hd]  (dkv kernel)
     int B, S, nh, nkv;
     float scale;
+    int l2_map;
 };
 
 template <int HD, int NW>
@@ -472,10 +526,20 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     // 1-D grid, heaviest work first: the causal key range grows with the query block, so the LAST query blocks are
     // dispatched first (longest-processing-time order keeps the tail of the launch short)
     const int nqb = (p.S + QB - 1) / QB, per_qb = p.nh * p.B;
-    const int bid = (int)blockIdx.x;
-    const int qbi = nqb - 1 - bid / per_qb, hb = bid % per_qb;
-    const int qb0 = qbi * QB, h = hb % p.nh, b = hb / p.nh;
-    const int g = h / (p.nh / p.nkv);
+    int qbi, h, b, g;
+    if (p.l2_map) {   // pair-major: (batch, kv head) -> query block (last = heaviest first) -> query head of the group
+        const int nrep = p.nh / p.nkv, W = nrep * nqb;
+        const int v = attn_work_index((int)blockIdx.x, W * p.nkv * p.B, 1);
+        if (v >= W * p.nkv * p.B) return;
+        const int pr = v / W, w = v - pr * W;
+        b = pr / p.nkv; g = pr - b * p.nkv;
+        qbi = nqb - 1 - w / nrep; h = g * nrep + w % nrep;
+    } else {
+        const int bid = (int)blockIdx.x, hb = bid % per_qb;
+        qbi = nqb - 1 - bid / per_qb; h = hb % p.nh; b = hb / p.nh;
+        g = h / (p.nh / p.nkv);
+    }
+    const int qb0 = qbi * QB;
     const int S = p.S;
     const int kvlen = p.kv_len ? p.kv_len[b] : S;
     const int qw0 = qb0 + wave * 32;
@@ -483,11 +547,12 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const bool qok = qi < S;
     const long qrow = (long)b * S + (qok ? qi : S - 1);
     const float sc = p.scale * kLog2e;
+    const int lim = qi < kvlen - 1 ? qi : kvlen - 1;
     FragOff<HD> fo;
     fo.init(lane);
     const long li = ((long)b * p.nh + h) * S + (qok ? qi : S - 1);
-    const float lse2 = p.lse[li] * kLog2e;
-    const float dlt = p.delta[li];
+    float lse2 = p.lse[li] * kLog2e;
+    float dlt = p.delta[li];
 
     sf_v8s qf[KS], dof[KS];
 #pragma unroll
@@ -501,21 +566,33 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
-    const sf_bf16* kbase = p.k0 + (long)b * S * p.ldk + g * HD;
-    const sf_bf16* vbase = p.v0 + (long)b * S * p.ldv + g * HD;
+    const SfBufB kbuf = rows_buf<HD>(p.k0 + (long)b * S * p.ldk + g * HD, p.ldk, S);
+    const SfBufB vbuf = rows_buf<HD>(p.v0 + (long)b * S * p.ldv + g * HD, p.ldv, S);
+    const unsigned ktile = (unsigned)(64 * p.ldk * 2), vtile = (unsigned)(64 * p.ldv * 2);
+    TileStage<HD, 64, NW> stk, stv;
+    stk.init(p.ldk, wave, lane);
+    stv.init(p.ldv, wave, lane);
     int kend = qb0 + QB < S ? qb0 + QB : S;
     if (kvlen < kend) kend = kvlen;
     const int ntiles = (kend + 63) / 64;
-    auto stage = [&](char* dst, int key0) {
-        stage_rows64<HD, NW>(dst, kbase, p.ldk, key0, S, wave, lane);
-        stage_rows64<HD, NW>(dst + 64 * HD * 2, vbase, p.ldv, key0, S, wave, lane);
-    };
-    if (ntiles > 0) stage(smem, 0);
+    if (ntiles > 0) {
+        stk.issue(kbuf, 0, smem);
+        stv.issue(vbuf, 0, smem + 64 * HD * 2);
+    }
+    // every value loaded ahead of the loop is complete HERE (see TileStage): no compiler-placed vmcnt inside the loop
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { sf_pin(qf[ks]); sf_pin(dof[ks]); }
+    sf_pin(lse2);
+    sf_pin(dlt);
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 64;
         sf_wait_vm0();
         sf_syncthreads();
-        if (kt + 1 < ntiles) stage(smem + ((kt + 1) & 1) * TILE, key0 + 64);
+        if (kt + 1 < ntiles) {
+            char* nb = smem + ((kt + 1) & 1) * TILE;
+            stk.issue(kbuf, (unsigned)(kt + 1) * ktile, nb);
+            stv.issue(vbuf, (unsigned)(kt + 1) * vtile, nb + 64 * HD * 2);
+        }
         const char* lds_k = smem + (kt & 1) * TILE;
         const char* lds_v = lds_k + 64 * HD * 2;
         if (key0 > qw0 + 31) continue;
@@ -532,15 +609,16 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
                 dp[kb] = sf_mfma32(frag_rows<HD>(lds_v, kb * 32, ks, fo), dof[ks], dp[kb]);
             }
         const bool need_mask = (key0 + 63 > qw0) || (key0 + 63 >= kvlen);  // wave-uniform
+        if (need_mask) {
+            const int rel = lim - key0 - 4 * hi;
+            mask_scores(s[0], rel);          // exp2(-inf) == 0: masked keys carry no probability, hence no dS
+            mask_scores(s[1], rel - 32);
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pv = sf_exp2_raw(fmaf(s[kb][r], sc, -lse2));
-                if (need_mask) {
-                    const int kk = key0 + kb * 32 + crow(r, hi);
-                    if (kk > qi || kk >= kvlen) pv = 0.f;
-                }
+                const float pv = sf_exp2_raw(fmaf(s[kb][r], sc, -lse2));
                 s[kb][r] = pv * (dp[kb][r] - dlt);  // dS^T
             }
 #pragma unroll
@@ -555,20 +633,27 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     }
     if (!qok) return;
     sf_bf16* orow = p.dq + qrow * p.lddq + h * HD;
-    const float* irow = p.dq_init ? p.dq_init + qrow * ((long)p.nh * HD) + h * HD : nullptr;
+    // the diagonal branches' share of dQ (attn_bwd_pre): all 16 vector loads in flight at once (a per-element
+    // `if (init) v += init[i]` compiled to 64 dependent dword loads, each behind its own vmcnt(0))
+    sf_v4f init[DB * 4];
+    if (p.dq_init) {
+        const float* irow = p.dq_init + qrow * ((long)p.nh * HD) + h * HD;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) init[d * 4 + j] = *reinterpret_cast<const sf_v4f*>(irow + d * 32 + 8 * j + 4 * hi);
+    } else {
+#pragma unroll
+        for (int j = 0; j < DB * 4; ++j) init[j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int col = d * 32 + 8 * j + 4 * hi;
             sf_v4s ov;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float v = acc[d][4 * j + t] * p.scale;
-                if (irow) v += irow[col + t];
-                ov[t] = (short)sf_f2bf(v);
-            }
-            *reinterpret_cast<sf_v4s*>(orow + col) = ov;
+            for (int t = 0; t < 4; ++t) ov[t] = (short)sf_f2bf(acc[d][4 * j + t] * p.scale + init[d * 4 + j][t]);
+            *reinterpret_cast<sf_v4s*>(orow + d * 32 + 8 * j + 4 * hi) = ov;
         }
 }
 
@@ -588,9 +673,18 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dkv_kernel(AttnBwdArgs p) {
     const int sub = wave - role * NSUB;
     // 1-D grid, heaviest first: key block 0 sees every query tile, the last one only the final tiles
     const int per_kb = p.nkv * p.B;
-    const int bid = (int)blockIdx.x;
-    const int kbi = bid / per_kb, gb = bid % per_kb;
-    const int kb0 = kbi * KB, g = gb % p.nkv, b = gb / p.nkv;
+    int kbi, g, b;
+    if (p.l2_map) {   // pair-major: the key blocks of one (batch, kv head) stream the same Q / dO tiles
+        const int nkb = (p.S + KB - 1) / KB;
+        const int v = attn_work_index((int)blockIdx.x, nkb * per_kb, 1);
+        if (v >= nkb * per_kb) return;
+        const int pr = v / nkb;
+        kbi = v - pr * nkb; b = pr / p.nkv; g = pr - b * p.nkv;
+    } else {
+        const int bid = (int)blockIdx.x, gb = bid % per_kb;
+        kbi = bid / per_kb; g = gb % p.nkv; b = gb / p.nkv;
+    }
+    const int kb0 = kbi * KB;
     const int S = p.S, nrep = p.nh / p.nkv;
     const int kvlen = p.kv_len ? p.kv_len[b] : S;
     const int kw0 = kb0 + sub * 32;
@@ -617,37 +711,45 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dkv_kernel(AttnBwdArgs p) {
     const bool block_live = kb0 < kvlen;  // keys at/after kv_len never receive probability mass
     const int qt_first = kb0 / 64;
     const int nqt = (S + 63) / 64;
+    // a query q of the tile is visible to this lane's key iff  ki <= q < S  (and the key itself is valid): with
+    // q = q0 + 4*hi + C (C a compile-time constant per register) that is  lo <= C < up  for two per-tile values
+    const int key_lo = ki < kvlen ? ki : 0x3fffffff;
+    TileStage<HD, 64, NW> stq, stdo;
+    stq.init(p.ldq, wave, lane);
+    stdo.init(p.lddo, wave, lane);
+    const unsigned qtile = (unsigned)(64 * p.ldq * 2), dotile = (unsigned)(64 * p.lddo * 2);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { sf_pin(kf[ks]); sf_pin(vf[ks]); }   // complete HERE (see TileStage)
     int it = 0;
     if (block_live)
         for (int hh = 0; hh < nrep; ++hh) {
             const int h = g * nrep + hh;
-            const sf_bf16* qbase = p.q + (long)b * S * p.ldq + h * HD;
-            const sf_bf16* dobase = p.dout + (long)b * S * p.lddo + h * HD;
-            const float* lsebase = p.lse + ((long)b * p.nh + h) * S;
-            const float* dltbase = p.delta + ((long)b * p.nh + h) * S;
-            auto stage = [&](char* dst, int q0) {
-                stage_rows64<HD, NW>(dst, qbase, p.ldq, q0, S, wave, lane);
-                stage_rows64<HD, NW>(dst + 64 * HD * 2, dobase, p.lddo, q0, S, wave, lane);
-                if (tid < 64) {
-                    float* sl = reinterpret_cast<float*>(dst + 128 * HD * 2);
-                    const int qq = q0 + tid;
-                    sl[tid] = qq < S ? lsebase[qq] * kLog2e : 0.f;
-                    sl[64 + tid] = qq < S ? dltbase[qq] : 0.f;
-                }
+            const SfBufB qbuf = rows_buf<HD>(p.q + (long)b * S * p.ldq + h * HD, p.ldq, S);
+            const SfBufB dobuf = rows_buf<HD>(p.dout + (long)b * S * p.lddo + h * HD, p.lddo, S);
+            const SfBufB lsebuf = sf_make_bufb(p.lse + ((long)b * p.nh + h) * S, (unsigned)S * 4u);
+            const SfBufB dltbuf = sf_make_bufb(p.delta + ((long)b * p.nh + h) * S, (unsigned)S * 4u);
+            // lse / delta of the tile's 64 queries ride the same LDS-DMA path (one 4-byte-per-lane piece each, issued by
+            // waves 0 and 1): nothing in this loop is a load the compiler counts
+            auto stage = [&](char* dst, int qt) {
+                stq.issue(qbuf, (unsigned)qt * qtile, dst);
+                stdo.issue(dobuf, (unsigned)qt * dotile, dst + 64 * HD * 2);
+                if (wave == 0) sf_bufb_glds4(lsebuf, (unsigned)(qt * 64 + lane) * 4u, dst + 128 * HD * 2);
+                if (wave == 1 % NW) sf_bufb_glds4(dltbuf, (unsigned)(qt * 64 + lane) * 4u, dst + 128 * HD * 2 + 256);
             };
             // the buffer parity continues across the heads of the group: `it` counts tiles globally
-            if (qt_first < nqt) stage(smem + (it & 1) * TILE, qt_first * 64);
+            if (qt_first < nqt) stage(smem + (it & 1) * TILE, qt_first);
             for (int qt = qt_first; qt < nqt; ++qt, ++it) {
                 const int q0 = qt * 64;
                 sf_wait_vm0();
                 sf_syncthreads();
-                if (qt + 1 < nqt) stage(smem + ((it + 1) & 1) * TILE, q0 + 64);
+                if (qt + 1 < nqt) stage(smem + ((it + 1) & 1) * TILE, qt + 1);
                 const char* lds_q = smem + (it & 1) * TILE;
                 const char* lds_do = lds_q + 64 * HD * 2;
                 const char* lds_x = role == 0 ? lds_do : lds_q;  // dV^T += dO^T.P   |   dK^T += Q^T.dS
                 const float* lds_lse = reinterpret_cast<const float*>(lds_q + 128 * HD * 2);
                 const float* lds_dlt = lds_lse + 64;
                 if (q0 + 63 < kw0) continue;  // every query of the tile is before this wave's keys
+                const int lo = key_lo - q0 - 4 * hi, up = S - q0 - 4 * hi;
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     sf_v16f s, dp;
@@ -670,10 +772,10 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dkv_kernel(AttnBwdArgs p) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             const int r = 4 * j + t;
-                            float pv = sf_exp2_raw(fmaf(s[r], sc, -l4[t]));
+                            float pv = sf_exp2_raw(fmaf(s[r], sc, -kLog2e * l4[t]));
                             if (need_mask) {
-                                const int qq = q0 + ql0 + t;
-                                if (ki > qq || ki >= kvlen || qq >= S) pv = 0.f;
+                                const int C = qb * 32 + 8 * j + t;
+                                if (C < lo || C >= up) pv = 0.f;
                             }
                             s[r] = role == 0 ? pv : pv * (dp[r] - d4[t]);  // P (dV waves) | dS (dK waves)
                         }
@@ -712,16 +814,10 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dkv_kernel(AttnBwdArgs p) {
         else SF_CHECK_ARG(false, "head_dim must be 64 or 128");   \
     } while (0)
 
-constexpr int kAttnWaves = 8;  // waves per workgroup of the three MFMA attention kernels
-
-// fwd / dq run as 4-wave workgroups by default: two independent workgroups share a CU, so one's barrier
-// skew is covered by the other's MFMAs (measured 0.89 -> 0.77 ms fwd, 0.90 -> 0.79 ms dq at cfg 2 vs 8 waves).
-// SF_ATTN_WAVES=8 pins the 8-wave form.
-static int sf_attn_waves() {
-    static int v = -1;
-    if (v < 0) v = sf_knob("SF_ATTN_WAVES", 4);
-    return v;
-}
+constexpr int kAttnWaves = 8;   // waves per workgroup of the dK/dV kernel (4 key sub-blocks x 2 roles)
+// fwd / dQ run as 4-wave workgroups, two per CU: one's barrier skew is covered by the other's MFMAs (measured in round 1:
+// 0.89 -> 0.77 ms fwd, 0.90 -> 0.79 ms dQ at cfg 2 against one 8-wave workgroup)
+constexpr int kAttnFwdWaves = 4;
 
 #ifdef SF_EMU
 #define SF_ALLOW_SMEM(kernel, bytes)
@@ -754,15 +850,10 @@ extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, co
     p.o = (sf_bf16*)o; p.ldo = ldo; p.lse = lse;
     p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.scale = scale;
     p.dbg = sf_knob("SF_ATTN_DBG", 0);
-    if (sf_attn_waves() == 4) {
-        constexpr int NW = 4;
-        dim3 grid((unsigned)(((S + NW * 32 - 1) / (NW * 32)) * nh * B));
-        SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_fwd_kernel<HD, NW>), 2 * 128 * HD * 2);
-                       SF_LAUNCH((attn_fwd_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
-        return sf_check_launch("sf_attn_fwd");
-    }
-    constexpr int NW = kAttnWaves;
-    dim3 grid((unsigned)(((S + NW * 32 - 1) / (NW * 32)) * nh * B));
+    p.l2_map = sf_knob("SF_ATTN_L2MAP", 1);
+    SF_CHECK_ARG((long)S * ldk * 2 < (1L << 31), "sf_attn_fwd: S * ldk exceeds the 2 GiB range of a buffer descriptor");
+    constexpr int NW = kAttnFwdWaves;
+    dim3 grid(attn_grid((long)((S + NW * 32 - 1) / (NW * 32)) * nh * B, p.l2_map));
     SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_fwd_kernel<HD, NW>), 2 * 128 * HD * 2);
                    SF_LAUNCH((attn_fwd_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
     return sf_check_launch("sf_attn_fwd");
@@ -812,6 +903,7 @@ static int fill_bwd_args(AttnBwdArgs& p, const void* q, long ldq, const void* do
     p.dq = (sf_bf16*)dq; p.lddq = lddq;
     p.dk = dk; p.dv = dv; p.lddk = lddk;
     p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.scale = scale;
+    p.l2_map = sf_knob("SF_ATTN_L2MAP", 1);
     return 0;
 }
 
@@ -825,15 +917,10 @@ extern "C" int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long ld
     AttnBwdArgs p;
     fill_bwd_args(p, q, ldq, dout, lddo, k0, ldk, v0, ldv, kv_len, lse, delta, dq_init, dq, lddq,
                   nullptr, nullptr, 0, B, S, nh, nkv, scale);
-    if (sf_attn_waves() == 4) {
-        constexpr int NW = 4;
-        dim3 grid((unsigned)(((S + NW * 32 - 1) / (NW * 32)) * nh * B));
-        SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dq_kernel<HD, NW>), 2 * 128 * HD * 2);
-                       SF_LAUNCH((attn_bwd_dq_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
-        return sf_check_launch("sf_attn_bwd_dq");
-    }
-    constexpr int NW = kAttnWaves;
-    dim3 grid((unsigned)(((S + NW * 32 - 1) / (NW * 32)) * nh * B));
+    SF_CHECK_ARG((long)S * ldk * 2 < (1L << 31) && (long)S * ldv * 2 < (1L << 31),
+                 "sf_attn_bwd_dq: S * ld exceeds the 2 GiB range of a buffer descriptor");
+    constexpr int NW = kAttnFwdWaves;
+    dim3 grid(attn_grid((long)((S + NW * 32 - 1) / (NW * 32)) * nh * B, p.l2_map));
     SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dq_kernel<HD, NW>), 2 * 128 * HD * 2);
                    SF_LAUNCH((attn_bwd_dq_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
     return sf_check_launch("sf_attn_bwd_dq");
@@ -849,16 +936,11 @@ extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long l
     AttnBwdArgs p;
     fill_bwd_args(p, q, ldq, dout, lddo, k0, ldk, v0, ldv, kv_len, lse, delta, nullptr, nullptr, 0, dk,
                   dv, lddk, B, S, nh, nkv, scale);
-    static const int dkv_waves = sf_knob("SF_ATTN_DKV_WAVES", kAttnWaves);
-    if (dkv_waves == 4) {
-        constexpr int NW = 4;
-        dim3 grid((unsigned)(((S + NW * 16 - 1) / (NW * 16)) * nkv * B));
-        SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, NW>), 2 * (128 * HD * 2 + 512));
-                       SF_LAUNCH((attn_bwd_dkv_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (128 * HD * 2 + 512), stream, p));
-        return sf_check_launch("sf_attn_bwd_dkv");
-    }
+    SF_CHECK_ARG((long)S * ldq * 2 < (1L << 31) && (long)S * lddo * 2 < (1L << 31),
+                 "sf_attn_bwd_dkv: S * ld exceeds the 2 GiB range of a buffer descriptor");
+    p.l2_map = sf_knob("SF_ATTN_DKV_L2MAP", 0);   // heaviest-first over ALL pairs wins here (measured: pair-major +20 %)
     constexpr int NW = kAttnWaves;
-    dim3 grid((unsigned)(((S + NW * 16 - 1) / (NW * 16)) * nkv * B));  // NW/2 key sub-blocks of 32 keys per workgroup
+    dim3 grid(attn_grid((long)((S + NW * 16 - 1) / (NW * 16)) * nkv * B, p.l2_map));  // NW/2 key sub-blocks of 32 keys per workgroup
     SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD, NW>), 2 * (128 * HD * 2 + 512));
                    SF_LAUNCH((attn_bwd_dkv_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (128 * HD * 2 + 512), stream, p));
     return sf_check_launch("sf_attn_bwd_dkv");

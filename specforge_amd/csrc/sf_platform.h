@@ -69,6 +69,20 @@ SF_DEVICE SfBufRaw sf_make_buf_raw(const void* base) { return SfBufRaw{(const ch
 SF_DEVICE void sf_buf_glds16_opaque(SfBufRaw b, unsigned voff, unsigned soff, void* l) {
     sfemu::global_load_lds16(b.base + voff + soff, l);
 }
+// bounded raw buffer for LDS-DMA (zeros past `bytes`), 16 B / 4 B per lane
+struct SfBufB { const char* base; unsigned bytes; };
+SF_DEVICE SfBufB sf_make_bufb(const void* base, unsigned bytes) { return SfBufB{(const char*)base, bytes}; }
+SF_DEVICE void sf_bufb_glds16(SfBufB b, unsigned voff, void* l) {
+    static const char zero16[16] = {0};
+    sfemu::global_load_lds16(voff + 16 <= b.bytes ? b.base + voff : zero16, l);
+}
+SF_DEVICE void sf_bufb_glds4(SfBufB b, unsigned voff, void* l) {
+    static const char zero4[4] = {0};
+    sfemu::global_load_lds4(voff + 4 <= b.bytes ? b.base + voff : zero4, l);
+}
+template <typename T> SF_DEVICE void sf_pin(T&) {}
+SF_DEVICE float sf_pair_max(float v) { return fmaxf(v, sfemu::shfl_xor(v, 32)); }
+SF_DEVICE float sf_pair_sum(float v) { return v + sfemu::shfl_xor(v, 32); }
 SF_DEVICE int sf_wave_id() { return sfemu::wave_index(); }
 SF_DEVICE sf_v4s sf_ds_read_tr16(const void* l) { return sfemu::ds_read_tr16_b64(l); }
 SF_DEVICE bool sf_all(bool pred) {
@@ -198,6 +212,46 @@ SF_DEVICE void sf_m0_set(void* l) {
 }
 SF_DEVICE void sf_buf_glds16_m0(SfBufRaw b, unsigned voff, unsigned soff) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(b.w), "s"(soff) : "memory");
+}
+// Bounded raw-buffer LDS-DMA from inline asm: {base, stride 0, num_records = bytes, raw format}.  The hardware range-checks
+// the per-lane voffset against num_records and delivers zeros past it, so a ragged last tile needs neither a source
+// select nor an exec-masked branch (the pointer form compiled to ~10 instructions per 1-KiB piece); the DMA is
+// invisible to the compiler's vmcnt bookkeeping -- the kernel's own counted waits are the only ordering.
+// Every descriptor field must be wave-uniform.  16 B per lane (lane i lands at M0 + 16 i) / 4 B per lane (M0 + 4 i).
+struct SfBufB { sf_v4i w; };
+SF_DEVICE SfBufB sf_make_bufb(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    SfBufB b;
+    b.w = sf_v4i{__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+                 __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+    return b;
+}
+SF_DEVICE void sf_bufb_glds16(SfBufB b, unsigned voff, void* l) {
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                 : : "v"(voff), "s"(b.w), "s"(lds) : "memory", "m0");
+}
+SF_DEVICE void sf_bufb_glds4(SfBufB b, unsigned voff, void* l) {
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, 0 offen lds"
+                 : : "v"(voff), "s"(b.w), "s"(lds) : "memory", "m0");
+}
+// "this value is complete here": an empty asm that reads and re-defines the register(s).  The compiler has to place the
+// wait for whatever load produces the value BEFORE it.  Used on fragments loaded ahead of a software-pipelined loop:
+// left alone, the waitcnt pass puts a vmcnt(N) at the first use INSIDE the loop, and since vmcnt is one in-order counter
+// that wait also drains the LDS-DMA prefetch of the next tile (which the compiler cannot see) on every iteration.
+template <typename T> SF_DEVICE void sf_pin(T& v) { asm volatile("" : "+v"(v)); }
+// all-reduce over the lane pair (l, l ^ 32): v_permlane32_swap exchanges the upper half of one register with the lower
+// half of the other, so {a, b} = swap(v, v) holds {v[l], v[l ^ 32]} in some order in every lane -- no select, no LDS
+SF_DEVICE float sf_pair_max(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+SF_DEVICE float sf_pair_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 // Workgroup-level arrive / wait on a monotonic LDS counter: a barrier whose "arrive" and "wait" halves are separate
 // program points (gfx950 has no split s_barrier).  arrive = release (everything this wave did to LDS is complete),

@@ -366,6 +366,23 @@ inline void global_load_lds16(const void* gsrc, void* lds_base) {
     memcpy((char*)lds_base + 16 * lane_id(), gsrc, 16);
 }
 
+inline void global_load_lds4(const void* gsrc, void* lds_base) {
+    struct P {
+        void* l;
+    } p{lds_base};
+    SlotRow* s = wave_exchange(&p, sizeof(P));
+    const int n = wave_lanes();
+    for (int i = 0; i < n; ++i) {
+        P o;
+        memcpy(&o, s[i], sizeof(P));
+        if (o.l != lds_base) {
+            fprintf(stderr, "[sfemu] global_load_lds4: LDS base is not wave-uniform (lane %d vs %d)\n", lane_id(), i);
+            abort();
+        }
+    }
+    memcpy((char*)lds_base + 4 * lane_id(), gsrc, 4);
+}
+
 // ds_read_b64_tr_b16 (transpose read): see sf_platform.h::sf_ds_read_tr16
 typedef short v4s __attribute__((ext_vector_type(4)));
 inline v4s ds_read_tr16_b64(const void* lds_ptr) {
