@@ -1,0 +1,380 @@
+// TTT attention backward: dK and dV of the step-0 keys / values (reference blueprint: _FlashCachedMergeFunc.backward,
+// specforge/modeling/draft/llama3_eagle.py:1080-1151; semantics as in sf_attn.hip).
+//
+// One workgroup = 4 waves = 128 keys of one (batch, kv head); ONE wave per SIMD with the whole 512-entry register file
+// (__launch_bounds__(256, 1)).  A wave owns 32 keys and BOTH gradients of those keys; it loops over the group's query
+// heads and the 64-query tiles at / after its keys.  Per tile and wave, for the two 32-query blocks qb = 0, 1:
+//     A(qb): S = Q.K^T, dP = dO.V^T                      16 MFMAs (32x32x16 bf16), A fragments = rows of the Q / dO tile
+//     P(qb): P = exp2(S sc - lse log2e), dS = P (dP - delta), both packed to bf16          ~100 VALU
+//     G(qb): dV^T += dO^T.P, dK^T += Q^T.dS              16 MFMAs, A fragments by transpose read of the same tiles
+// i.e. 64 MFMAs, each product once.  (Round 2 gave the two gradients to two waves of a SIMD, each recomputing S: 80 MFMAs
+// per tile where 64 do, the lighter role idle a third of the time, 0.23 of the MFMA peak.)
+//
+// What hipcc made of the obvious C++ for this structure decided the shape of this file.  With builtin MFMAs and 128
+// accumulator registers per wave the register allocator kept the accumulators in architectural VGPRs, spilled fragment
+// addresses to AGPRs and copied ~290 registers through v_accvgpr_read / _write per tile, and the pre-RA scheduler --
+// pressure-bound -- serialised every fragment read (ds_read; s_waitcnt lgkmcnt(0); v_mfma; ds_read; ...).  So:
+//   * the wave's long-lived MFMA state lives in asm-owned AGPRs the compiler never sees: dV^T a[0:16 DB), dK^T next,
+//     then the K and V fragments (B operands of S / dP).  Every MFMA is an asm statement naming those registers; the
+//     compiler allocates only what VALU touches (S, dP, P, dS, addresses) and the A fragments in flight -- about 200
+//     registers, no spills, no copies (tests/test_isa_invariants.py audits the ISA: no compiler v_accvgpr_*, no scratch);
+//   * the tile body is ONE instruction stream in source order, a slot plan like the GEMMs': 64 MFMA slots, each followed by
+//     its fillers (fragment reads 8 slots ahead of their use, the next-but-one tile's LDS-DMA pieces, one piece of the
+//     P / dS arithmetic) and a scheduling barrier, so the stream the hardware sees is the stream written here.  The
+//     arithmetic of block 0 sits beside the S / dP MFMAs of block 1, that of block 1 beside the gradient MFMAs of block 0;
+//   * hazards the compiler cannot see into asm for are satisfied by distance, not nops: S / dP of a block are first read
+//     by VALU three MFMAs after their last MFMA; a packed P / dS fragment is first consumed >= 6 slots after its cvt.
+// Q / dO / lse / delta tiles arrive through a 3-deep LDS ring, two tiles ahead, behind a COUNTED vmcnt (nothing in the
+// loop is a load the compiler counts: see TileStage in sf_attn_common.h).
+#include "sf_attn_common.h"
+
+using namespace sfattn;
+
+namespace {
+
+#ifdef SF_EMU
+#define SF_SCHED_FENCE()
+#else
+#define SF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#define SF_LAMBDA_INLINE __attribute__((always_inline))
+
+// ---- the wave's asm-owned register bank -----------------------------------------------------------------------------
+// AGPR map (HD = 128): a[0:63] dV^T (4 x 16), a[64:127] dK^T, a[128:159] K fragments (8 x 4), a[160:191] V fragments.
+template <int HD>
+struct DkvBank {
+    static constexpr int KS = HD / 16, DB = HD / 32;
+    static constexpr int kAccV = 0, kAccK = 16 * DB, kKf = 32 * DB, kVf = 32 * DB + 4 * KS, kEnd = 32 * DB + 8 * KS;
+#ifdef SF_EMU
+    sf_v16f accv[DB], acck[DB];
+    sf_v8s kf[KS], vf[KS];
+    SF_DEVICE void init() {
+        for (int d = 0; d < DB; ++d)
+            for (int r = 0; r < 16; ++r) { accv[d][r] = 0.f; acck[d][r] = 0.f; }
+    }
+    template <int I> SF_DEVICE void set_k(sf_v8s v) { kf[I] = v; }
+    template <int I> SF_DEVICE void set_v(sf_v8s v) { vf[I] = v; }
+    template <int I, bool FIRST> SF_DEVICE void mfma_s(sf_v16f& s, sf_v8s a) {
+        if (FIRST) for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        s = sf_mfma32(a, kf[I], s);
+    }
+    template <int I, bool FIRST> SF_DEVICE void mfma_dp(sf_v16f& s, sf_v8s a) {
+        if (FIRST) for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        s = sf_mfma32(a, vf[I], s);
+    }
+    template <int D> SF_DEVICE void mfma_dv(sf_v8s a, sf_v8s b) { accv[D] = sf_mfma32(a, b, accv[D]); }
+    template <int D> SF_DEVICE void mfma_dk(sf_v8s a, sf_v8s b) { acck[D] = sf_mfma32(a, b, acck[D]); }
+    template <int D> SF_DEVICE sf_v16f get_dv() { return accv[D]; }
+    template <int D> SF_DEVICE sf_v16f get_dk() { return acck[D]; }
+    SF_DEVICE void drain() {}
+#else
+    // (the clobber makes the kernel descriptor allocate the bank; nothing the compiler emits may touch these registers)
+    SF_DEVICE void init() {
+        if constexpr (HD == 128) asm volatile("" ::: "a191"); else asm volatile("" ::: "a95");
+        static_for<0, 32 * DB>([&](auto I) SF_LAMBDA_INLINE { asm volatile("v_accvgpr_write_b32 a[%c0], 0" : : "i"(decltype(I)::value)); });
+    }
+    template <int BASE> SF_DEVICE void put4(sf_v8s v) {
+        typedef int v4i_ __attribute__((ext_vector_type(4)));
+        const v4i_ w = __builtin_bit_cast(v4i_, v);
+        asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\t"
+                     "v_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+                     : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
+    }
+    template <int I> SF_DEVICE void set_k(sf_v8s v) { put4<kKf + 4 * I>(v); }
+    template <int I> SF_DEVICE void set_v(sf_v8s v) { put4<kVf + 4 * I>(v); }
+    // S / dP accumulate in compiler-owned VGPRs (VALU reads them); B operand = the K / V fragment in the bank
+    template <int BASE, bool FIRST> SF_DEVICE void mfma_b(sf_v16f& s, sf_v8s a) {
+        if (FIRST)
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(s) : "v"(a), "i"(BASE), "i"(BASE + 3));
+        else
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(a), "i"(BASE), "i"(BASE + 3));
+    }
+    template <int I, bool FIRST> SF_DEVICE void mfma_s(sf_v16f& s, sf_v8s a) { mfma_b<kKf + 4 * I, FIRST>(s, a); }
+    template <int I, bool FIRST> SF_DEVICE void mfma_dp(sf_v16f& s, sf_v8s a) { mfma_b<kVf + 4 * I, FIRST>(s, a); }
+    template <int BASE> SF_DEVICE void mfma_acc(sf_v8s a, sf_v8s b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(a), "v"(b), "i"(BASE), "i"(BASE + 15));
+    }
+    template <int D> SF_DEVICE void mfma_dv(sf_v8s a, sf_v8s b) { mfma_acc<kAccV + 16 * D>(a, b); }
+    template <int D> SF_DEVICE void mfma_dk(sf_v8s a, sf_v8s b) { mfma_acc<kAccK + 16 * D>(a, b); }
+    template <int BASE> SF_DEVICE sf_v16f get16() {
+        sf_v16f r;
+        static_for<0, 16>([&](auto I) SF_LAMBDA_INLINE {
+            constexpr int i = decltype(I)::value;
+            float v;
+            asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(BASE + i));
+            r[i] = v;
+        });
+        return r;
+    }
+    template <int D> SF_DEVICE sf_v16f get_dv() { return get16<kAccV + 16 * D>(); }
+    template <int D> SF_DEVICE sf_v16f get_dk() { return get16<kAccK + 16 * D>(); }
+    SF_DEVICE void drain() { sf_mfma_drain(); }   // MFMA results in the bank are read only behind this
+#endif
+};
+
+// ---- one 64-query tile ----------------------------------------------------------------------------------------------
+// Slot s of 64 = one MFMA + its fillers.  A fragment consumed in slot s is read in slot s - kAhead (slots < kAhead: in the
+// burst in front of slot 0).
+//   slots  0..15  A(0): even = S (k-step s/2), odd = dP            16..31  A(1)
+//   slots 32..47  G(0): (jp, d): even = dV, odd = dK               48..63  G(1)
+//   fillers: DMA pieces of tile it+2 in slots 1..NDMA;  lse / delta reads of block 0 in slots 8..15, of block 1 in 24..31;
+//            P(0) element e in slot 18 + e * 14 / 16 (18..31), P(1) in 34..47; each element = 5 VALU (+3 when masked)
+template <int HD, bool MASK>
+struct DkvTile {
+    static constexpr int KS = HD / 16, DB = HD / 32, NA = 2 * KS, NG = 4 * DB, NSLOT = 2 * NA + 2 * NG, kAhead = 8;
+    static constexpr int P0 = NA + 2, P1 = 2 * NA + 2, PSPAN = NG - 2 < NA - 2 ? NG - 2 : NA - 2;
+    static_assert(NA == NG, "the plan assumes the score and gradient phases have the same number of MFMAs");
+
+    const char* lds_q;
+    const char* lds_do;
+    const float* lds_lse;
+    const float* lds_dlt;
+    const FragOff<HD>& fo;
+    int hi;
+    float sc;
+    int lo, up;
+    sf_v16f s[2], dp[2];
+    sf_v4f l4[2][4], d4[2][4];
+    sf_v8s pf[2][2], df[2][2];
+    sf_v8s fr[kAhead];          // A fragments in flight: slot s uses fr[s % kAhead]
+
+    // A fragment of slot S (compile-time)
+    template <int S> SF_DEVICE sf_v8s load_frag() const {
+        if constexpr (S < 2 * NA) {
+            constexpr int qb = S / NA, i = S % NA, ks = i / 2;
+            return frag_rows<HD>((i & 1) ? lds_do : lds_q, qb * 32, ks, fo);
+        } else {
+            constexpr int g = S - 2 * NA, qb = g / NG, i = g % NG, jp = i / (2 * DB), d = (i / 2) % DB;
+            return frag_tr<HD>((i & 1) ? lds_q : lds_do, d, qb * 32 + 16 * jp, fo);   // dV: dO^T | dK: Q^T
+        }
+    }
+    template <int E> SF_DEVICE void element(int qb) {   // element E = 4 j + t of block qb
+        constexpr int j = E / 4, t = E % 4;
+        float pv = sf_exp2_raw(fmaf(s[qb][E], sc, -kLog2e * l4[qb][j][t]));
+        if (MASK) {   // arithmetic select: a conditional assignment compiles to an exec-masked branch per element
+            const int C = qb * 32 + 8 * j + t;
+            pv *= (C >= lo && C < up) ? 1.0f : 0.0f;
+        }
+        s[qb][E] = pv;
+        dp[qb][E] = pv * (dp[qb][E] - d4[qb][j][t]);
+        if constexpr (E % 8 == 7) {
+            pf[qb][E / 8] = pack_bf16x8(s[qb], E - 7);
+            df[qb][E / 8] = pack_bf16x8(dp[qb], E - 7);
+        }
+    }
+    template <class Bank, class Dma>
+    SF_DEVICE void run(Bank& bank, Dma&& dma_piece) {
+        // burst: the first kAhead fragments
+        static_for<0, kAhead>([&](auto I) SF_LAMBDA_INLINE { fr[decltype(I)::value] = load_frag<decltype(I)::value>(); });
+        SF_SCHED_FENCE();
+        static_for<0, NSLOT>([&](auto I) SF_LAMBDA_INLINE {
+            constexpr int S = decltype(I)::value;
+            const sf_v8s a = fr[S % kAhead];
+            if constexpr (S < 2 * NA) {
+                constexpr int qb = S / NA, i = S % NA, ks = i / 2;
+                if constexpr (i & 1) bank.template mfma_dp<ks, ks == 0>(dp[qb], a);
+                else bank.template mfma_s<ks, ks == 0>(s[qb], a);
+            } else {
+                constexpr int g = S - 2 * NA, qb = g / NG, i = g % NG, jp = i / (2 * DB), d = (i / 2) % DB;
+                if constexpr (i & 1) bank.template mfma_dk<d>(a, df[qb][jp]);
+                else bank.template mfma_dv<d>(a, pf[qb][jp]);
+            }
+            // ---- fillers of this slot
+            if constexpr (S + kAhead < NSLOT) fr[S % kAhead] = load_frag<S + kAhead>();
+            dma_piece(std::integral_constant<int, S>{});
+            if constexpr (S >= NA / 2 && S < NA / 2 + 8) {          // lse / delta of block 0: 4 + 4 reads
+                constexpr int k = S - NA / 2, j = k % 4;
+                const int ql0 = 8 * j + 4 * hi;
+                if constexpr (k < 4) l4[0][j] = *reinterpret_cast<const sf_v4f*>(lds_lse + ql0);
+                else d4[0][j] = *reinterpret_cast<const sf_v4f*>(lds_dlt + ql0);
+            }
+            if constexpr (S >= NA + NA / 2 && S < NA + NA / 2 + 8) { // ... of block 1
+                constexpr int k = S - NA - NA / 2, j = k % 4;
+                const int ql0 = 32 + 8 * j + 4 * hi;
+                if constexpr (k < 4) l4[1][j] = *reinterpret_cast<const sf_v4f*>(lds_lse + ql0);
+                else d4[1][j] = *reinterpret_cast<const sf_v4f*>(lds_dlt + ql0);
+            }
+            if constexpr (S >= P0 && S < P0 + PSPAN) {               // P(0): 16 elements over PSPAN slots
+                constexpr int k = S - P0, e0 = k * 16 / PSPAN, e1 = (k + 1) * 16 / PSPAN;
+                static_for<e0, e1>([&](auto E) SF_LAMBDA_INLINE { element<decltype(E)::value>(0); });
+            }
+            if constexpr (S >= P1 && S < P1 + PSPAN) {               // P(1)
+                constexpr int k = S - P1, e0 = k * 16 / PSPAN, e1 = (k + 1) * 16 / PSPAN;
+                static_for<e0, e1>([&](auto E) SF_LAMBDA_INLINE { element<decltype(E)::value>(1); });
+            }
+            SF_SCHED_FENCE();
+        });
+    }
+};
+
+template <int HD>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
+    constexpr int KS = HD / 16, DB = HD / 32, NW = 4, KB = NW * 32, TILE = 128 * HD * 2 + 768, NBUF = 3;
+    constexpr int NDMA = 2 * TileStage<HD, 64, NW>::NI + 1;   // DMA pieces per wave and tile
+    SF_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
+    // 1-D grid, heaviest first: key block 0 sees every query tile, the last one only the final tiles
+    const int per_kb = p.nkv * p.B;
+    int kbi, g, b;
+    if (p.l2_map) {   // pair-major (tools A/B only: heaviest-first over ALL pairs measured 20 % faster for this kernel)
+        const int nkb = (p.S + KB - 1) / KB;
+        const int v = attn_work_index((int)blockIdx.x, nkb * per_kb, 1);
+        if (v >= nkb * per_kb) return;
+        const int pr = v / nkb;
+        kbi = v - pr * nkb; b = pr / p.nkv; g = pr - b * p.nkv;
+    } else {
+        const int bid = (int)blockIdx.x, gb = bid % per_kb;
+        kbi = bid / per_kb; g = gb % p.nkv; b = gb / p.nkv;
+    }
+    const int kb0 = kbi * KB;
+    const int S = p.S, nrep = p.nh / p.nkv;
+    const int kvlen = p.kv_len ? p.kv_len[b] : S;
+    if (kb0 >= kvlen) return;   // keys at / after kv_len never receive probability mass (workgroup-uniform)
+    const int kw0 = kb0 + wave * 32;
+    const int ki = kw0 + c;  // this lane's key (column of S)
+    const bool kok = ki < S;
+    const long krow = (long)b * S + (kok ? ki : S - 1);
+    FragOff<HD> fo;
+    fo.init(lane);
+
+    DkvBank<HD> bank;
+    bank.init();
+    {
+        sf_v8s kt[KS], vt[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kt[ks] = *reinterpret_cast<const sf_v8s*>(p.k0 + krow * p.ldk + g * HD + 16 * ks + 8 * hi);
+            vt[ks] = *reinterpret_cast<const sf_v8s*>(p.v0 + krow * p.ldv + g * HD + 16 * ks + 8 * hi);
+        }
+        static_for<0, KS>([&](auto I) SF_LAMBDA_INLINE {
+            constexpr int i = decltype(I)::value;
+            bank.template set_k<i>(kt[i]);   // (the asm reads the value: the compiler waits for the load HERE, ahead of the loop)
+            bank.template set_v<i>(vt[i]);
+        });
+    }
+
+    const int qt_first = kb0 / 64;
+    const int nqt = (S + 63) / 64;
+    const int per_head = nqt - qt_first, n_it = nrep * per_head;
+    // a query q of the tile is visible to this lane's key iff  ki <= q < S  (and the key itself is valid): with
+    // q = q0 + 4*hi + C (C a compile-time constant per register) that is  lo <= C < up  for two per-tile values
+    const int key_lo = ki < kvlen ? ki : 0x3fffffff;
+    TileStage<HD, 64, NW> stq, stdo;
+    stq.init(p.ldq, wave, lane);
+    stdo.init(p.lddo, wave, lane);
+    const unsigned qtile = (unsigned)(64 * p.ldq * 2), dotile = (unsigned)(64 * p.lddo * 2);
+    const sf_bf16* qb_base = p.q + (long)b * S * p.ldq + (long)g * nrep * HD;
+    const sf_bf16* dob_base = p.dout + (long)b * S * p.lddo + (long)g * nrep * HD;
+    const float* lse_base = p.lse + ((long)b * p.nh + (long)g * nrep) * S;
+    const float* dlt_base = p.delta + ((long)b * p.nh + (long)g * nrep) * S;
+    // Every wave issues the same number of DMA pieces per tile (a counted vmcnt needs one immediate): its Q and dO pieces
+    // plus ONE 4-byte-per-lane piece -- lse (wave 0), delta (wave 1), or a re-read of lse into the slot's padding.
+    struct Src { SfBufB q, dout, aux; unsigned qoff, dooff, auxoff; char* dst; };
+    auto source = [&](int it) SF_LAMBDA_INLINE {
+        const int hh = it / per_head, qt = qt_first + (it - hh * per_head);
+        Src r;
+        r.q = rows_buf<HD>(qb_base + hh * HD, p.ldq, S);
+        r.dout = rows_buf<HD>(dob_base + hh * HD, p.lddo, S);
+        r.aux = sf_make_bufb((wave == 1 ? dlt_base : lse_base) + (long)hh * S, (unsigned)S * 4u);
+        r.qoff = (unsigned)qt * qtile; r.dooff = (unsigned)qt * dotile; r.auxoff = (unsigned)(qt * 64 + lane) * 4u;
+        r.dst = smem + (it % NBUF) * TILE;
+        return r;
+    };
+    auto piece = [&](const Src& r, int k) SF_LAMBDA_INLINE {   // piece k of NDMA (compile-time k at every call site)
+        constexpr int NI = TileStage<HD, 64, NW>::NI;
+        if (k < NI) sf_bufb_glds16(r.q, stq.off[k] + r.qoff, r.dst + (stq.piece0 + k) * 1024);
+        else if (k < 2 * NI) sf_bufb_glds16(r.dout, stdo.off[k - NI] + r.dooff, r.dst + 64 * HD * 2 + (stdo.piece0 + k - NI) * 1024);
+        else sf_bufb_glds4(r.aux, r.auxoff, r.dst + 128 * HD * 2 + (wave < 2 ? wave : 2) * 256);
+    };
+    auto stage_now = [&](int it) SF_LAMBDA_INLINE {
+        const Src r = source(it);
+        static_for<0, NDMA>([&](auto K) SF_LAMBDA_INLINE { piece(r, decltype(K)::value); });
+    };
+    if (n_it > 0) stage_now(0);
+    if (n_it > 1) stage_now(1);
+    else if (n_it > 0) {                // keep the piece count of the counted wait: an empty stand-in for tile 1
+        Src r = source(0);
+        sf_bufb_empty(r.q); sf_bufb_empty(r.dout); sf_bufb_empty(r.aux);
+        r.dst = smem + TILE;
+        static_for<0, NDMA>([&](auto K) SF_LAMBDA_INLINE { piece(r, decltype(K)::value); });
+    }
+    for (int it = 0; it < n_it; ++it) {
+        const int hh = it / per_head, qt = qt_first + (it - hh * per_head);
+        const int q0 = qt * 64;
+        sf_wait_vmcnt<NDMA>();          // tile `it` landed; the NDMA pieces of tile it+1 (or its empty stand-ins) may be in flight
+        sf_syncthreads();               // ... for every wave; ring slot (it+2) % 3 == (it-1) % 3 is no longer being read
+        const bool more = it + 2 < n_it;
+        const char* lds_q = smem + (it % NBUF) * TILE;
+        if (q0 + 63 < kw0) {            // every query of the tile is before this wave's keys: only the staging duty remains
+            Src r = source(more ? it + 2 : it);
+            if (!more) { sf_bufb_empty(r.q); sf_bufb_empty(r.dout); sf_bufb_empty(r.aux); r.dst = smem + ((it + 2) % NBUF) * TILE; }
+            static_for<0, NDMA>([&](auto K) SF_LAMBDA_INLINE { piece(r, decltype(K)::value); });
+            continue;
+        }
+        // the pieces of tile it+2 are fillers of this tile's first slots.  Past the last tile the same pieces are issued
+        // against empty descriptors (zeros into a ring slot nobody reads any more): no branch inside the slot stream, and
+        // the counted wait at the top of the next iteration stays exact
+        Src nxt = source(more ? it + 2 : it);
+        if (!more) { sf_bufb_empty(nxt.q); sf_bufb_empty(nxt.dout); sf_bufb_empty(nxt.aux); nxt.dst = smem + ((it + 2) % NBUF) * TILE; }
+        auto dma = [&](auto Sl) SF_LAMBDA_INLINE {       // filler: DMA piece (slot - 1) of tile it+2
+            constexpr int k = decltype(Sl)::value - 1;
+            if constexpr (k >= 0 && k < NDMA) piece(nxt, k);
+        };
+        const bool need_mask = (q0 < kw0 + 32) || (kw0 + 31 >= kvlen) || (q0 + 63 >= S);  // wave-uniform
+        const float sc = p.scale * kLog2e;
+        const int lo = key_lo - q0 - 4 * hi, up = S - q0 - 4 * hi;
+        const float* ll = reinterpret_cast<const float*>(lds_q + 128 * HD * 2);
+        if (need_mask) {
+            DkvTile<HD, true> t{lds_q, lds_q + 64 * HD * 2, ll, ll + 64, fo, hi, sc, lo, up};
+            t.run(bank, dma);
+        } else {
+            DkvTile<HD, false> t{lds_q, lds_q + 64 * HD * 2, ll, ll + 64, fo, hi, sc, lo, up};
+            t.run(bank, dma);
+        }
+    }
+    bank.drain();
+    if (!kok) return;
+    float* dkrow = p.dk + krow * p.lddk + g * HD;
+    float* dvrow = p.dv + krow * p.lddk + g * HD;
+    static_for<0, DB>([&](auto D) SF_LAMBDA_INLINE {
+        constexpr int d = decltype(D)::value;
+        const sf_v16f ak = bank.template get_dk<d>(), av = bank.template get_dv<d>();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = d * 32 + 8 * j + 4 * hi;
+            sf_v4f a = *reinterpret_cast<const sf_v4f*>(dkrow + col);
+            sf_v4f e = *reinterpret_cast<const sf_v4f*>(dvrow + col);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { a[t] += ak[4 * j + t] * p.scale; e[t] += av[4 * j + t]; }
+            *reinterpret_cast<sf_v4f*>(dkrow + col) = a;
+            *reinterpret_cast<sf_v4f*>(dvrow + col) = e;
+        }
+    });
+}
+
+}  // namespace
+
+extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long lddo,
+                               const void* k0, long ldk, const void* v0, long ldv, const int* kv_len, const float* lse,
+                               const float* delta, float* dk, float* dv, long lddk, int B, int S, int nh, int nkv,
+                               int hd, float scale, void* stream) {
+    SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_dkv: bad shape");
+    SF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddk % 4 == 0,
+                 "sf_attn_bwd_dkv: row strides must be multiples of 8 (16-byte segments)");
+    SF_CHECK_ARG((long)S * ldq * 2 < (1L << 31) && (long)S * lddo * 2 < (1L << 31),
+                 "sf_attn_bwd_dkv: S * ld exceeds the 2 GiB range of a buffer descriptor");
+    AttnBwdArgs p;
+    memset(&p, 0, sizeof(p));
+    p.q = (const sf_bf16*)q; p.ldq = ldq;
+    p.dout = (const sf_bf16*)dout; p.lddo = lddo;
+    p.k0 = (const sf_bf16*)k0; p.ldk = ldk;
+    p.v0 = (const sf_bf16*)v0; p.ldv = ldv;
+    p.kv_len = kv_len; p.lse = lse; p.delta = delta;
+    p.dk = dk; p.dv = dv; p.lddk = lddk;
+    p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.scale = scale;
+    p.l2_map = sf_knob("SF_ATTN_DKV_L2MAP", 0);   // heaviest-first over ALL pairs wins here (measured: pair-major +20 %)
+    dim3 grid(attn_grid((long)((S + 127) / 128) * nkv * B, p.l2_map));   // 128 keys per workgroup
+    SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD>), 3 * (128 * HD * 2 + 768));
+                   SF_LAUNCH((attn_bwd_dkv_kernel<HD>), grid, dim3(256), 3 * (128 * HD * 2 + 768), stream, p));
+    return sf_check_launch("sf_attn_bwd_dkv");
+}

@@ -41,6 +41,9 @@ template <typename T> SF_DEVICE T sf_shfl(T v, int l) { return sfemu::shfl(v, l)
 SF_DEVICE sf_v4f sf_mfma16(sf_v8s a, sf_v8s b, sf_v4f c) { return sfemu::mfma_16x16x32_bf16(a, b, c); }
 SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) { return sfemu::mfma_32x32x16_bf16(a, b, c); }
 SF_DEVICE void sf_mfma16_acc(sf_v8s a, sf_v8s b, sf_v4f& c) { c = sfemu::mfma_16x16x32_bf16(a, b, c); }
+SF_DEVICE void sf_mfma32_acc(sf_v8s a, sf_v8s b, sf_v16f& c) { c = sfemu::mfma_32x32x16_bf16(a, b, c); }
+SF_DEVICE void sf_acc_touch(sf_v16f&) {}
+SF_DEVICE void sf_valu_to_mfma(sf_v8s&) {}
 SF_DEVICE void sf_mfma_drain() {}
 SF_DEVICE void sf_acc_touch(sf_v4f&) {}
 // a wave's lanes run in lockstep on the GPU; the interpreter's lanes are fibres and need an explicit rendezvous between
@@ -72,6 +75,7 @@ SF_DEVICE void sf_buf_glds16_opaque(SfBufRaw b, unsigned voff, unsigned soff, vo
 // bounded raw buffer for LDS-DMA (zeros past `bytes`), 16 B / 4 B per lane
 struct SfBufB { const char* base; unsigned bytes; };
 SF_DEVICE SfBufB sf_make_bufb(const void* base, unsigned bytes) { return SfBufB{(const char*)base, bytes}; }
+SF_DEVICE void sf_bufb_empty(SfBufB& b) { b.bytes = 0; }
 SF_DEVICE void sf_bufb_glds16(SfBufB b, unsigned voff, void* l) {
     static const char zero16[16] = {0};
     sfemu::global_load_lds16(voff + 16 <= b.bytes ? b.base + voff : zero16, l);
@@ -91,6 +95,7 @@ SF_DEVICE bool sf_all(bool pred) {
     return v != 0;
 }
 SF_DEVICE void sf_wait_vm0() {}
+template <int N> SF_DEVICE void sf_wait_vmcnt() {}
 SF_DEVICE void sf_setprio_hi() {}
 SF_DEVICE void sf_setprio_lo() {}
 template <typename T> SF_DEVICE T sf_atomic_add(T* p, T v) { return sfemu::atomic_add(p, v); }
@@ -144,6 +149,16 @@ SF_DEVICE void sf_mfma_drain() {
 // behind the drain.  Without it the register allocator may copy an asm MFMA's result to a VGPR right after the MFMA that
 // produced it (a v_accvgpr_read one instruction later reads the old value: the hazard recogniser cannot see the asm).
 SF_DEVICE void sf_acc_touch(sf_v4f& c) { asm volatile("" : "+a"(c)); }
+// The 32x32x16 form of sf_mfma16_acc: accumulator tied to 16 AGPRs.  For accumulators that only MFMAs touch until the
+// epilogue (attention dK^T / dV^T): left to the register allocator they compete with VALU-visible values for the 256
+// architectural VGPRs and get shuttled through v_accvgpr_read / _write around every use.
+SF_DEVICE void sf_mfma32_acc(sf_v8s a, sf_v8s b, sf_v16f& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+SF_DEVICE void sf_acc_touch(sf_v16f& c) { asm volatile("" : "+a"(c)); }
+// A fragment a VALU instruction has just written (packed P / dS) is read by an MFMA inside asm, which the hazard recogniser
+// does not see: the required wait states between the two go here, tied to the value so nothing moves across
+SF_DEVICE void sf_valu_to_mfma(sf_v8s& f) { asm volatile("s_nop 1" : "+v"(f)); }
 SF_DEVICE void sf_wave_lockstep() {}   // lanes of a wave execute LDS instructions in order, in lockstep
 SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -226,6 +241,7 @@ SF_DEVICE SfBufB sf_make_bufb(const void* base, unsigned bytes) {
                  __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
     return b;
 }
+SF_DEVICE void sf_bufb_empty(SfBufB& b) { b.w[2] = 0; }   // num_records = 0: every access is out of range, i.e. reads zeros
 SF_DEVICE void sf_bufb_glds16(SfBufB b, unsigned voff, void* l) {
     const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
@@ -265,6 +281,8 @@ SF_DEVICE void sf_flag_wait(const unsigned* c, unsigned target) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 SF_DEVICE void sf_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// counted wait: at most N of this wave's VMEM operations (LDS-DMA pieces included) still outstanding
+template <int N> SF_DEVICE void sf_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" : : "i"(N) : "memory"); }
 SF_DEVICE void sf_setprio_hi() { __builtin_amdgcn_s_setprio(1); }
 SF_DEVICE void sf_setprio_lo() { __builtin_amdgcn_s_setprio(0); }
 template <typename T> SF_DEVICE T sf_atomic_add(T* p, T v) { return atomicAdd(p, v); }
