@@ -29,25 +29,6 @@ namespace {
 #define SF_ATTN_DBG(p, bit) false
 #endif
 
-// TOOLS BUILD ONLY: per-wave cycle sums of the phases of the forward tile loop (tools/attn_phases.py); SF_PROF_* compile to
-// nothing in the product library.  A stamp is s_memtime between two scheduling barriers: it measures ISSUE progress of the
-// wave (a stall shows up at the instruction that waits), and it keeps the compiler from moving work across the stamp, so the
-// instrumented schedule is not the product schedule -- it answers "which phase", not "how many cycles exactly".
-#if defined(SF_ABLATE) && !defined(SF_EMU)
-__device__ unsigned long long* g_attn_prof = nullptr;
-// PROF is a template parameter of the kernel: 0 = nothing (the A/B timings of the tools build run the product schedule),
-// 1 = whole-loop stamps only (workgroup residency census: slots 6 = loop ticks, 7 = s_memrealtime span), 2 = per-phase stamps
-#define SF_PROF_DECL unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0, prof_rt0 = 0
-#define SF_PROF_START() do { if (PROF) { __builtin_amdgcn_sched_barrier(0); prof_rt0 = __builtin_amdgcn_s_memrealtime(); prof_last = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#define SF_PROF_MARK(i) do { if (PROF == 2 || (PROF == 1 && (i) == 6)) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_t[i] += t_ - prof_last; prof_last = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
-#define SF_PROF_FLUSH(slot) do { if (PROF) { prof_t[7] = __builtin_amdgcn_s_memrealtime() - prof_rt0; if (g_attn_prof && lane == 0) for (int i_ = 0; i_ < 8; ++i_) g_attn_prof[(long)(slot) * 8 + i_] = prof_t[i_]; } } while (0)
-#else
-#define SF_PROF_DECL
-#define SF_PROF_START()
-#define SF_PROF_MARK(i)
-#define SF_PROF_FLUSH(slot)
-#endif
-
 struct AttnFwdArgs {
     const sf_bf16* q; long ldq;        // [B*S, nh*hd] view, row stride ldq
     const sf_bf16* k0; long ldk;       // step-0 keys [B*S, nkv*hd] view
@@ -72,7 +53,7 @@ SF_DEVICE void mask_scores(sf_v16f& s, int rel) {
         if ((r & 3) + 8 * (r >> 2) > rel) s[r] = -INFINITY;
 }
 
-template <int HD, int NW, int PROF = 0>
+template <int HD, int NW>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
     constexpr int KS = HD / 16, DB = HD / 32, QB = NW * 32, TILE = 128 * HD * 2;
     SF_DYN_SMEM(smem);  // 2 x { K [64][HD], V [64][HD] }
@@ -131,14 +112,10 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) sf_pin(qf[ks]);   // the Q loads are complete HERE, not at their first use in the loop
-    SF_PROF_DECL;
-    SF_PROF_START();
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 64;
         sf_wait_vm0();
-        SF_PROF_MARK(0);   // own DMA pieces landed
         sf_syncthreads();  // tile kt landed for everyone; buffer (kt+1)&1 is no longer being read
-        SF_PROF_MARK(1);   // barrier
         if (kt + 1 < ntiles && !SF_ATTN_DBG(p, 1)) {
             char* nb = smem + ((kt + 1) & 1) * TILE;
             st.issue(kbuf, (unsigned)(kt + 1) * tile_bytes, nb);
@@ -146,7 +123,6 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
         }
         const char* lds_k = smem + (kt & 1) * TILE;
         const char* lds_v = lds_k + 64 * HD * 2;
-        SF_PROF_MARK(2);   // staging issue
         if (key0 > qw0 + 31) continue;  // whole tile above this wave's diagonal (wave-uniform)
         if (SF_ATTN_DBG(p, 2)) continue;
         const bool need_mask = (key0 + 63 > qw0) || (key0 + 63 >= kvlen);
@@ -161,7 +137,6 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) s[kb] = sf_mfma32(frag_rows<HD>(lds_k, kb * 32, ks, fo), qf[ks], s[kb]);
-        SF_PROF_MARK(3);   // K fragment reads + QK^T issue
         // scores stay unscaled in the accumulators; only diagonal / padded tiles pay for masking (2 VALU per score)
         if (need_mask) {
             const int rel = lim - key0 - 4 * hi;
@@ -184,7 +159,6 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_o[d][r] *= alpha;
         }
-        SF_PROF_MARK(4);   // MFMA drain + mask + row max + rescale decision
         float ps = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -204,10 +178,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
                 for (int d = 0; d < DB; ++d)
                     acc_o[d] = sf_mfma32(frag_tr<HD>(lds_v, d, kb * 32 + 16 * jp, fo), pf, acc_o[d]);
             }
-        SF_PROF_MARK(5);   // exp + pack + V^T fragment reads + PV issue
     }
-    SF_PROF_MARK(6);
-    SF_PROF_FLUSH((long)blockIdx.x * NW + wave);
     float l = sf_pair_sum(lpart);
 
     // diagonal branch terms: one extra key per later TTT step at the query's own position.  A wave only ever needs the
@@ -548,6 +519,10 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
 
 }  // namespace
 
+#if defined(SF_ABLATE) && !defined(SF_EMU)
+#include "../../tools/experiments/sf_attn_w4_variants.inc"
+#endif
+
 constexpr int kAttnFwdWaves = 4;
 
 extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, const void* v0, const void* const* kd,
@@ -571,17 +546,8 @@ extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, co
     constexpr int NW = kAttnFwdWaves;
     dim3 grid(attn_grid((long)((S + NW * 32 - 1) / (NW * 32)) * nh * B, p.l2_map));
 #if defined(SF_ABLATE) && !defined(SF_EMU)
-    const int prof = sf_knob("SF_ATTN_PROF", 0);
-    if (prof == 1 && hd == 128) {
-        SF_ALLOW_SMEM((attn_fwd_kernel<128, NW, 1>), 2 * 128 * 128 * 2);
-        SF_LAUNCH((attn_fwd_kernel<128, NW, 1>), grid, dim3(NW * 64), 2 * 128 * 128 * 2, stream, p);
-        return sf_check_launch("sf_attn_fwd");
-    }
-    if (prof == 2 && hd == 128) {
-        SF_ALLOW_SMEM((attn_fwd_kernel<128, NW, 2>), 2 * 128 * 128 * 2);
-        SF_LAUNCH((attn_fwd_kernel<128, NW, 2>), grid, dim3(NW * 64), 2 * 128 * 128 * 2, stream, p);
-        return sf_check_launch("sf_attn_fwd");
-    }
+    if (sf_knob("SF_ATTN_FWD_W4", 0))   // tools build: the measured-and-rejected one-wave-per-SIMD variant
+        return sfattn_w4::attn_fwd(q, ldq, k0, ldk, v0, kd, vd, ndiag, kv_len, o, ldo, lse, B, S, nh, nkv, hd, scale, stream);
 #endif
     SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_fwd_kernel<HD, NW>), 2 * 128 * HD * 2);
                    SF_LAUNCH((attn_fwd_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
@@ -643,6 +609,11 @@ extern "C" int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long ld
     SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_dq: bad shape");
     SF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0,
                  "sf_attn_bwd_dq: row strides must be multiples of 8 (16-byte segments)");
+#if defined(SF_ABLATE) && !defined(SF_EMU)
+    if (sf_knob("SF_ATTN_DQ_W4", 0))    // tools build: the measured-and-rejected one-wave-per-SIMD variant
+        return sfattn_w4::attn_bwd_dq(q, ldq, dout, lddo, k0, ldk, v0, ldv, kv_len, lse, delta, dq_init, dq, lddq, B, S, nh, nkv, hd,
+                                      scale, stream);
+#endif
     AttnBwdArgs p;
     fill_bwd_args(p, q, ldq, dout, lddo, k0, ldk, v0, ldv, kv_len, lse, delta, dq_init, dq, lddq,
                   nullptr, nullptr, 0, B, S, nh, nkv, scale);
@@ -654,11 +625,3 @@ extern "C" int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long ld
                    SF_LAUNCH((attn_bwd_dq_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
     return sf_check_launch("sf_attn_bwd_dq");
 }
-
-#if defined(SF_ABLATE) && !defined(SF_EMU)
-// TOOLS BUILD ONLY: point the forward kernel's phase profiler at a device buffer of (grid * 4 waves * 8) 64-bit words
-extern "C" int sf_tool_attn_prof(void* buf) {
-    unsigned long long* p = (unsigned long long*)buf;
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), &p, sizeof(p)) == hipSuccess ? 0 : 1;
-}
-#endif

@@ -160,6 +160,122 @@ SF_DEVICE void static_for(F&& f) {
     }
 }
 
+
+#ifdef SF_EMU
+#define SF_SCHED_FENCE()
+#else
+#define SF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#define SF_LAMBDA_INLINE __attribute__((always_inline))
+
+// ---- a wave's asm-owned register bank --------------------------------------------------------------------------------
+// The kernels that run ONE wave per SIMD (512 registers) keep their long-lived MFMA state in AGPRs the compiler never
+// sees: NACC accumulator tiles of 16 registers at a[16 i], then NBF B-operand fragments of 4 registers.  Every MFMA that
+// touches the bank is an asm statement naming those registers; the compiler allocates only what VALU touches and the
+// A fragments in flight.  (Left to the register allocator, 128+ accumulator registers per wave ended up in architectural
+// VGPRs, fragment addresses were spilled to AGPRs, ~290 registers per tile went through v_accvgpr_read / _write, and the
+// pressure-bound scheduler serialised every fragment read.)  Nothing the compiler emits may touch a[0 : kEnd):
+// tests/test_isa_invariants.py audits the ISA.  Interpreter build: plain arrays.
+template <int NACC, int NBF>
+struct AgprBank {
+    static constexpr int kBf = 16 * NACC, kEnd = 16 * NACC + 4 * NBF;
+    static_assert(kEnd == 96 || kEnd == 128 || kEnd == 192 || kEnd == 256, "add the clobber name for this bank size");
+#ifdef SF_EMU
+    sf_v16f acc[NACC];
+    sf_v8s bf[NBF];
+    SF_DEVICE void init() {
+        for (int d = 0; d < NACC; ++d)
+            for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+    }
+    template <int I> SF_DEVICE void set_b(sf_v8s v) { bf[I] = v; }
+    template <int I, bool FIRST> SF_DEVICE void mfma_vb(sf_v16f& c, sf_v8s a) {   // c (+)= a . bf[I]   (c compiler-owned)
+        if (FIRST) for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        c = sf_mfma32(a, bf[I], c);
+    }
+    template <int A> SF_DEVICE void mfma_acc(sf_v8s a, sf_v8s b) { acc[A] = sf_mfma32(a, b, acc[A]); }   // acc[A] += a . b
+    template <int A> SF_DEVICE sf_v16f get() { return acc[A]; }
+    template <int A> SF_DEVICE void scale(float f) { for (int r = 0; r < 16; ++r) acc[A][r] *= f; }
+    SF_DEVICE void drain() {}
+#else
+    // (the clobber makes the kernel descriptor allocate the bank)
+    SF_DEVICE void init() {
+        if constexpr (kEnd == 256) asm volatile("" ::: "a255");
+        else if constexpr (kEnd == 192) asm volatile("" ::: "a191");
+        else if constexpr (kEnd == 128) asm volatile("" ::: "a127");
+        else asm volatile("" ::: "a95");
+        static_for<0, 16 * NACC>([&](auto I) SF_LAMBDA_INLINE { asm volatile("v_accvgpr_write_b32 a[%c0], 0" : : "i"(decltype(I)::value)); });
+    }
+    template <int I> SF_DEVICE void set_b(sf_v8s v) {   // (the asm reads the value: the compiler waits for its load HERE)
+        typedef int v4i_ __attribute__((ext_vector_type(4)));
+        const v4i_ w = __builtin_bit_cast(v4i_, v);
+        constexpr int B = kBf + 4 * I;
+        asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\t"
+                     "v_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+                     : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "i"(B), "i"(B + 1), "i"(B + 2), "i"(B + 3));
+    }
+    template <int I, bool FIRST> SF_DEVICE void mfma_vb(sf_v16f& c, sf_v8s a) {
+        constexpr int B = kBf + 4 * I;
+        if (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(c) : "v"(a), "i"(B), "i"(B + 3));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(c) : "v"(a), "i"(B), "i"(B + 3));
+    }
+    template <int A> SF_DEVICE void mfma_acc(sf_v8s a, sf_v8s b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(a), "v"(b), "i"(16 * A), "i"(16 * A + 15));
+    }
+    template <int A> SF_DEVICE sf_v16f get() {   // only behind drain()
+        sf_v16f r;
+        static_for<0, 16>([&](auto I) SF_LAMBDA_INLINE {
+            constexpr int i = decltype(I)::value;
+            float v;
+            asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(16 * A + i));
+            r[i] = v;
+        });
+        return r;
+    }
+    // acc[A] *= f, lane-wise (online-softmax rescale): read, multiply, write back; the caller keeps it clear of MFMAs in
+    // flight on acc[A] (>= 3 MFMA slots after the last one that wrote it) and of the next one that reads it (s_nop inside)
+    template <int A> SF_DEVICE void scale(float f) {
+        static_for<0, 16>([&](auto I) SF_LAMBDA_INLINE {
+            constexpr int i = decltype(I)::value;
+            float v;
+            asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(16 * A + i));
+            v *= f;
+            asm volatile("v_accvgpr_write_b32 a[%c1], %0" : : "v"(v), "i"(16 * A + i));
+        });
+    }
+    SF_DEVICE void drain() { sf_mfma_drain(); }   // MFMA results in the bank are read only behind this
+#endif
+};
+
+
+// ---- TOOLS BUILD ONLY: cycle stamps inside the slot-planned tile loops ---------------------------------------------
+// SfProf<PROF> accumulates s_memtime deltas between marks into 16 per-wave sums and flushes them to a device buffer
+// (sf_tool_attn_prof); PROF = 0 (always, in the product library) compiles to nothing.  The streams are pinned by
+// SF_SCHED_FENCE already, so the stamps (one SMEM instruction + two scalar adds each) barely move them.
+#if defined(SF_ABLATE) && !defined(SF_EMU)
+extern __device__ unsigned long long* g_attn_prof;
+template <int PROF> struct SfProf {
+    unsigned t[12], last, rt0;   // 32-bit sums: the whole lifetime of a workgroup is < 2^32 ticks (and SGPRs are scarce)
+    SF_DEVICE void start() {
+        if (PROF) { for (int i = 0; i < 12; ++i) t[i] = 0; __builtin_amdgcn_sched_barrier(0); rt0 = (unsigned)__builtin_amdgcn_s_memrealtime(); last = (unsigned)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    }
+    template <int I> SF_DEVICE void mark() {
+        if (PROF) { __builtin_amdgcn_sched_barrier(0); const unsigned x = (unsigned)__builtin_amdgcn_s_memtime(); t[I] += x - last; last = x; __builtin_amdgcn_sched_barrier(0); }
+    }
+    SF_DEVICE void flush(long slot, int lane) {
+        if (PROF) {
+            const unsigned span = (unsigned)__builtin_amdgcn_s_memrealtime() - rt0;
+            if (g_attn_prof && lane == 0) { for (int i = 0; i < 12; ++i) g_attn_prof[slot * 16 + i] = t[i]; g_attn_prof[slot * 16 + 15] = span; }
+        }
+    }
+};
+#else
+template <int PROF> struct SfProf {
+    SF_DEVICE void start() {}
+    template <int I> SF_DEVICE void mark() {}
+    SF_DEVICE void flush(long, int) {}
+};
+#endif
+
 }  // namespace sfattn
 
 #ifdef SF_EMU

@@ -32,84 +32,19 @@ using namespace sfattn;
 
 namespace {
 
-#ifdef SF_EMU
-#define SF_SCHED_FENCE()
-#else
-#define SF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
-#define SF_LAMBDA_INLINE __attribute__((always_inline))
-
-// ---- the wave's asm-owned register bank -----------------------------------------------------------------------------
 // AGPR map (HD = 128): a[0:63] dV^T (4 x 16), a[64:127] dK^T, a[128:159] K fragments (8 x 4), a[160:191] V fragments.
 template <int HD>
-struct DkvBank {
+struct DkvBank : AgprBank<2 * (HD / 32), 2 * (HD / 16)> {
     static constexpr int KS = HD / 16, DB = HD / 32;
-    static constexpr int kAccV = 0, kAccK = 16 * DB, kKf = 32 * DB, kVf = 32 * DB + 4 * KS, kEnd = 32 * DB + 8 * KS;
-#ifdef SF_EMU
-    sf_v16f accv[DB], acck[DB];
-    sf_v8s kf[KS], vf[KS];
-    SF_DEVICE void init() {
-        for (int d = 0; d < DB; ++d)
-            for (int r = 0; r < 16; ++r) { accv[d][r] = 0.f; acck[d][r] = 0.f; }
-    }
-    template <int I> SF_DEVICE void set_k(sf_v8s v) { kf[I] = v; }
-    template <int I> SF_DEVICE void set_v(sf_v8s v) { vf[I] = v; }
-    template <int I, bool FIRST> SF_DEVICE void mfma_s(sf_v16f& s, sf_v8s a) {
-        if (FIRST) for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        s = sf_mfma32(a, kf[I], s);
-    }
-    template <int I, bool FIRST> SF_DEVICE void mfma_dp(sf_v16f& s, sf_v8s a) {
-        if (FIRST) for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        s = sf_mfma32(a, vf[I], s);
-    }
-    template <int D> SF_DEVICE void mfma_dv(sf_v8s a, sf_v8s b) { accv[D] = sf_mfma32(a, b, accv[D]); }
-    template <int D> SF_DEVICE void mfma_dk(sf_v8s a, sf_v8s b) { acck[D] = sf_mfma32(a, b, acck[D]); }
-    template <int D> SF_DEVICE sf_v16f get_dv() { return accv[D]; }
-    template <int D> SF_DEVICE sf_v16f get_dk() { return acck[D]; }
-    SF_DEVICE void drain() {}
-#else
-    // (the clobber makes the kernel descriptor allocate the bank; nothing the compiler emits may touch these registers)
-    SF_DEVICE void init() {
-        if constexpr (HD == 128) asm volatile("" ::: "a191"); else asm volatile("" ::: "a95");
-        static_for<0, 32 * DB>([&](auto I) SF_LAMBDA_INLINE { asm volatile("v_accvgpr_write_b32 a[%c0], 0" : : "i"(decltype(I)::value)); });
-    }
-    template <int BASE> SF_DEVICE void put4(sf_v8s v) {
-        typedef int v4i_ __attribute__((ext_vector_type(4)));
-        const v4i_ w = __builtin_bit_cast(v4i_, v);
-        asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\t"
-                     "v_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
-                     : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "i"(BASE), "i"(BASE + 1), "i"(BASE + 2), "i"(BASE + 3));
-    }
-    template <int I> SF_DEVICE void set_k(sf_v8s v) { put4<kKf + 4 * I>(v); }
-    template <int I> SF_DEVICE void set_v(sf_v8s v) { put4<kVf + 4 * I>(v); }
-    // S / dP accumulate in compiler-owned VGPRs (VALU reads them); B operand = the K / V fragment in the bank
-    template <int BASE, bool FIRST> SF_DEVICE void mfma_b(sf_v16f& s, sf_v8s a) {
-        if (FIRST)
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(s) : "v"(a), "i"(BASE), "i"(BASE + 3));
-        else
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(a), "i"(BASE), "i"(BASE + 3));
-    }
-    template <int I, bool FIRST> SF_DEVICE void mfma_s(sf_v16f& s, sf_v8s a) { mfma_b<kKf + 4 * I, FIRST>(s, a); }
-    template <int I, bool FIRST> SF_DEVICE void mfma_dp(sf_v16f& s, sf_v8s a) { mfma_b<kVf + 4 * I, FIRST>(s, a); }
-    template <int BASE> SF_DEVICE void mfma_acc(sf_v8s a, sf_v8s b) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(a), "v"(b), "i"(BASE), "i"(BASE + 15));
-    }
-    template <int D> SF_DEVICE void mfma_dv(sf_v8s a, sf_v8s b) { mfma_acc<kAccV + 16 * D>(a, b); }
-    template <int D> SF_DEVICE void mfma_dk(sf_v8s a, sf_v8s b) { mfma_acc<kAccK + 16 * D>(a, b); }
-    template <int BASE> SF_DEVICE sf_v16f get16() {
-        sf_v16f r;
-        static_for<0, 16>([&](auto I) SF_LAMBDA_INLINE {
-            constexpr int i = decltype(I)::value;
-            float v;
-            asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(BASE + i));
-            r[i] = v;
-        });
-        return r;
-    }
-    template <int D> SF_DEVICE sf_v16f get_dv() { return get16<kAccV + 16 * D>(); }
-    template <int D> SF_DEVICE sf_v16f get_dk() { return get16<kAccK + 16 * D>(); }
-    SF_DEVICE void drain() { sf_mfma_drain(); }   // MFMA results in the bank are read only behind this
-#endif
+    using Base = AgprBank<2 * DB, 2 * KS>;
+    template <int I> SF_DEVICE void set_k(sf_v8s v) { Base::template set_b<I>(v); }
+    template <int I> SF_DEVICE void set_v(sf_v8s v) { Base::template set_b<KS + I>(v); }
+    template <int I, bool FIRST> SF_DEVICE void mfma_s(sf_v16f& s, sf_v8s a) { Base::template mfma_vb<I, FIRST>(s, a); }
+    template <int I, bool FIRST> SF_DEVICE void mfma_dp(sf_v16f& s, sf_v8s a) { Base::template mfma_vb<KS + I, FIRST>(s, a); }
+    template <int D> SF_DEVICE void mfma_dv(sf_v8s a, sf_v8s b) { Base::template mfma_acc<D>(a, b); }
+    template <int D> SF_DEVICE void mfma_dk(sf_v8s a, sf_v8s b) { Base::template mfma_acc<DB + D>(a, b); }
+    template <int D> SF_DEVICE sf_v16f get_dv() { return Base::template get<D>(); }
+    template <int D> SF_DEVICE sf_v16f get_dk() { return Base::template get<DB + D>(); }
 };
 
 // ---- one 64-query tile ----------------------------------------------------------------------------------------------
@@ -332,6 +267,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
             t.run(bank, dma);
         }
     }
+    sf_wait_vm0();   // (the stand-in pieces of the last iterations are still in flight: LDS must not be released under them)
     bank.drain();
     if (!kok) return;
     float* dkrow = p.dk + krow * p.lddk + g * HD;

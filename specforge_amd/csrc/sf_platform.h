@@ -76,6 +76,7 @@ SF_DEVICE void sf_buf_glds16_opaque(SfBufRaw b, unsigned voff, unsigned soff, vo
 struct SfBufB { const char* base; unsigned bytes; };
 SF_DEVICE SfBufB sf_make_bufb(const void* base, unsigned bytes) { return SfBufB{(const char*)base, bytes}; }
 SF_DEVICE void sf_bufb_empty(SfBufB& b) { b.bytes = 0; }
+SF_DEVICE SfBufB sf_bufb_if(SfBufB b, bool on) { if (!on) b.bytes = 0; return b; }
 SF_DEVICE void sf_bufb_glds16(SfBufB b, unsigned voff, void* l) {
     static const char zero16[16] = {0};
     sfemu::global_load_lds16(voff + 16 <= b.bytes ? b.base + voff : zero16, l);
@@ -242,6 +243,9 @@ SF_DEVICE SfBufB sf_make_bufb(const void* base, unsigned bytes) {
     return b;
 }
 SF_DEVICE void sf_bufb_empty(SfBufB& b) { b.w[2] = 0; }   // num_records = 0: every access is out of range, i.e. reads zeros
+// `b` when the (wave-uniform) condition holds, else an empty buffer; the patched word is forced back into an SGPR (a select of
+// whole descriptors can end up as a per-lane select, and the DMA's descriptor operand must be scalar)
+SF_DEVICE SfBufB sf_bufb_if(SfBufB b, bool on) { b.w[2] = __builtin_amdgcn_readfirstlane(on ? b.w[2] : 0); return b; }
 SF_DEVICE void sf_bufb_glds16(SfBufB b, unsigned voff, void* l) {
     const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
