@@ -40,49 +40,68 @@ LLAMA3_8B = dict(hidden_size=4096, intermediate_size=14336, num_attention_heads=
 SMALL = dict(hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=2, vocab_size=4096,
              draft_vocab_size=1024, head_dim=128, target_hidden_size=512, max_position_embeddings=2048, rms_norm_eps=1e-5)
 PEAK_BF16_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0          # spec; ~6300 GB/s is what a float4 copy reaches (MI355X_MICROARCH.md)
 GEMM_KERNEL_NAME = "gemm_nt_256w4_kernel (bf16 MFMA GEMM, 256x256x64, 4 waves x 128x128, plan-scheduled: one filler per MFMA slot, counted vmcnt)"
 
 
-class GemmTimer:
-    """HIP events around every sf_gemm_nt launch on the current stream (the launch stream)."""
+class KernelTimer:
+    """HIP events around the launches of the step's hot kernels on the current stream (= the launch stream).  Per kernel
+    family: algorithmic work (flop or bytes) per launch, summed, against the summed event durations."""
 
+    # family -> (ops attribute, kind, work(args, kwargs) in flop or bytes)
     def __init__(self):
-        self.records = []   # sf_gemm_nt: the plain instantiations of the dominant kernel (roofline object)
-        self.fused = []     # sf_gemm_nt_swiglu_bwd: the same main loop with d(SwiGLU) in its epilogue (its own kernel symbol)
+        self.rec = {}
+        self._orig = {}
+
+    @staticmethod
+    def _attn_units(kw):
+        return kw["B"] * kw["nh"] * kw["hd"] * kw["S"] * kw["S"] / 2.0
 
     def wrap(self, ops):
-        orig = ops.gemm_nt
+        el = lambda t: t.numel() * t.element_size()
+        fam = {
+            # MFMA-bound: 2*M*N*K
+            "gemm_nt": ("gemm_nt", lambda a, k: 2.0 * a[0].shape[0] * a[1].shape[0] * a[0].shape[1]),
+            "gemm_nt_swiglu_bwd": ("gemm_nt_swiglu_bwd", lambda a, k: 2.0 * a[0].shape[0] * a[1].shape[0] * a[0].shape[1]),
+            "gemm_nt_rowadd": ("gemm_nt_rowadd", lambda a, k: 2.0 * a[0].shape[0] * a[1].shape[0] * a[0].shape[1]),
+            "gemm_tn": ("gemm_tn", lambda a, k: 2.0 * a[0].shape[1] * a[1].shape[1] * a[0].shape[0]),
+            # attention: matmuls of B*nh*hd*S^2/2 MACs each: forward 2, dQ 3, dK/dV 4 (each product once)
+            "attn_fwd": ("attn_fwd", lambda a, k: 4.0 * self._attn_units(k)),
+            "attn_bwd_dq": ("attn_bwd_dq", lambda a, k: 6.0 * self._attn_units(k)),
+            "attn_bwd_dkv": ("attn_bwd_dkv", lambda a, k: 8.0 * self._attn_units(k)),
+            # HBM-bound: algorithmic bytes
+            #   fused CE: logits read + gradient written in place (bf16) for every row, fp32 soft target read for the rows
+            #   that carry a position mask (counted from the mask the launch is given)
+            #   (recorded per element; summary() applies  4 + 4 * mask density  bytes -- no device read-back per launch)
+            "ce_fused": ("ce_fused", lambda a, k: float(a[0].numel())),
+            #   AdamW: grad bf16 r, master / m / v fp32 r+w, param bf16 w = 28 B per parameter
+            "adamw_step": ("adamw_step", lambda a, k: 28.0 * a[0].numel()),
+            #   teacher reduce: one bf16 read of the logits chunk + target_p fp32 write
+            "teacher_reduce": ("teacher_reduce", lambda a, k: el(a[0]) + 4.0 * a[0].shape[0] * k["Vd"]),
+        }
+        for name, (attr, work) in fam.items():
+            orig = getattr(ops, attr)
+            self._orig[attr] = orig
+            self.rec[name] = []
 
-        def timed(a, b, out, **kw):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig(a, b, out, **kw)
-            e.record()
-            self.records.append((2.0 * a.shape[0] * b.shape[0] * a.shape[1], s, e))
-            return r
+            def timed(*a, _orig=orig, _work=work, _name=name, **k):
+                w = _work(a, k)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = _orig(*a, **k)
+                e.record()
+                self.rec[_name].append((w, s, e))
+                return r
 
-        ops.gemm_nt = timed
-        orig_sw = ops.gemm_nt_swiglu_bwd
+            setattr(ops, attr, timed)
 
-        def timed_sw(a, b, gu, dgu, dact):   # the down-projection dgrad with d(SwiGLU) in its epilogue: same kernel, same flops
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            r = orig_sw(a, b, gu, dgu, dact)
-            e.record()
-            self.fused.append((2.0 * a.shape[0] * b.shape[0] * a.shape[1], s, e))
-            return r
+    def unwrap(self, ops):
+        for attr, orig in self._orig.items():
+            setattr(ops, attr, orig)
 
-        ops.gemm_nt_swiglu_bwd = timed_sw
-        self._orig_sw = orig_sw
-        return orig
-
-    def summary(self):
-        fl = sum(r[0] for r in self.records)
-        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
-        return fl, ms, len(self.records)
-
-    def fused_summary(self):
-        return (sum(r[0] for r in self.fused), sum(r[1].elapsed_time(r[2]) for r in self.fused), len(self.fused))
+    def summary(self, name):
+        r = self.rec.get(name, [])
+        return sum(x[0] for x in r), sum(x[1].elapsed_time(x[2]) for x in r), len(r)
 
 
 def make_batch(cfg, B, S, dev, seed):
@@ -120,8 +139,9 @@ def cpu_baseline(cfg, S, ttt, threads):
     dt = time.time() - t0
     return dict(value=S / dt, unit="tokens/s", cores=threads, kind="port",
                 sample=f"oracle/eagle3_oracle.py (a pinned restatement, NOT the reference trainer: no optimizer, no loader), "
-                       f"1 micro-step fwd+bwd, B=1 x S={S} of the same model dims and ttt, fp32, {dt:.1f} s; the sdpa path's "
-                       f"score tensors grow with S^2, so the rate at S=2048 is lower still")
+                       f"1 micro-step fwd+bwd, B=1 x S={S} of the same model dims and ttt, fp32, {dt:.1f} s; the headline step is 8 "
+                       f"such samples (x8 the work at the same rate).  The reference trainer itself, timed on the build "
+                       f"container's 8 cores: profiles/r3_reference_cpu_trainer.jsonl / BASELINE.md section 5")
 
 
 def main():
@@ -134,7 +154,8 @@ def main():
     ap.add_argument("--ttt", type=int, default=7)
     ap.add_argument("--small", action="store_true", help="tiny model dims (smoke / debugging only; NOT the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-seq", type=int, default=512)
+    ap.add_argument("--cpu-sample-seq", type=int, default=2048,
+                    help="sequence length of the CPU baseline sample (B = 1; the headline step is 8 such samples)")
     ap.add_argument("--no-dense-mask", action="store_true", help="skip the dense-position-mask variant")
     ap.add_argument("--dp-single", action="store_true", help="one gradient all-reduce after the sweep instead of overlapped buckets (A/B)")
     ap.add_argument("--force-dp", action="store_true", help="run the gradient collectives even at world size 1 (RCCL path on a 1-GPU box)")
@@ -202,7 +223,8 @@ def main():
             backend.step()
             return out
 
-        orig = timer.wrap(ops) if timer is not None else None
+        if timer is not None:
+            timer.wrap(ops)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -214,9 +236,8 @@ def main():
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        if orig is not None:
-            ops.gemm_nt = orig
-            ops.gemm_nt_swiglu_bwd = timer._orig_sw
+        if timer is not None:
+            timer.unwrap(ops)
         if world > 1:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -224,10 +245,11 @@ def main():
         return elapsed, out
 
     timed(strat, args.warmup)                      # untimed warm-up
-    timer = GemmTimer()
+    timer = KernelTimer()
+    backend.comm_wait_events = []                    # (N > 1) event pairs around the waits for the bucket all-reduces
     elapsed, out = timed(strat, args.steps, timer)
     loss = float(out.loss.detach())
-    fl, gemm_ms, nlaunch = timer.summary()
+    fl, gemm_ms, nlaunch = timer.summary("gemm_nt")
     tokens = world * B * S * args.steps
 
     # ---- dense position mask variant: the specified synthetic vocab map (random 32000 of 128256)
@@ -259,8 +281,12 @@ def main():
                 dist.all_reduce(buf)
             torch.cuda.synchronize()
             per.append(dict(mbytes=(hi - lo) * 2 / 1e6, ms=(time.perf_counter() - t0) / 3 * 1e3))
+        waits = [a.elapsed_time(b) for a, b in getattr(backend, "comm_wait_events", [])]
         rccl = {"backend": args.dist_backend, "rccl_ranks": world, "buckets": per,
                 "allreduce_ms_total_unoverlapped": sum(x["ms"] for x in per),
+                # inside the timed steps: how long the compute stream sat in front of the optimizer waiting for the bucket
+                # all-reduces that were launched from inside the weight-gradient phase (0 = fully overlapped)
+                "exposed_wait_ms_per_step": (sum(waits) / max(1, len(waits))) if waits else None,
                 "no_sync_backwards": backend.no_sync_backwards, "single_collective": backend._single_collective}
 
     if rank == 0:
@@ -269,7 +295,7 @@ def main():
         # command (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, calibrated there on the AdamW
         # kernel's known byte count).  PMC counters cannot be collected from inside the timed run, so this field is the
         # committed per-launch figure (newest profiles/r*_pmc_fetch_write_summary.json) or null.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_commit = None, None, None
         try:
             import glob
 
@@ -277,8 +303,38 @@ def main():
             pm = json.load(open(src))["gemm256w4"]
             traffic = (2.0 * pm["FETCH_SIZE_sum"] + pm["WRITE_SIZE_sum"]) * 1024.0 / pm["launches"]
             traffic_src = os.path.relpath(src, ROOT)
+            traffic_commit = json.load(open(src)).get("_commit")      # the commit the PMC passes were collected on
         except Exception:
             pass
+        st = max(1, args.steps)
+        density = float(eagle.last_artifacts["position_mask"].float().mean())
+
+        def kern(name, unit, peak, scale=1.0, what=""):
+            w, ms, n = timer.summary(name)
+            if n == 0 or ms <= 0:
+                return None
+            ach = w * scale / ms / 1e9 if unit == "TFLOP/s" else w * scale / ms / 1e6
+            return {"bound": "mfma" if unit == "TFLOP/s" else "hbm", "achieved": ach, "peak": peak, "unit": unit,
+                    "frac": ach / peak, "launches_per_step": n / st, "ms_per_step": ms / st, "work": what}
+
+        kernels = {
+            "gemm_nt_swiglu_bwd": kern("gemm_nt_swiglu_bwd", "TFLOP/s", PEAK_BF16_TFLOPS, what="2MNK; d(SwiGLU) in the epilogue"),
+            "gemm_nt_rowadd": kern("gemm_nt_rowadd", "TFLOP/s", PEAK_BF16_TFLOPS, what="2MNK; fp32 row addend (hoisted embedding half of QKV)"),
+            "gemm_tn": kern("gemm_tn", "TFLOP/s", PEAK_BF16_TFLOPS, what="2MNK, K = T*N token rows (deferred weight gradients; split-K reduce included)"),
+            "attn_fwd": kern("attn_fwd", "TFLOP/s", PEAK_BF16_TFLOPS, what="4 B nh hd S^2/2 (diagonal branches not counted)"),
+            "attn_bwd_dq": kern("attn_bwd_dq", "TFLOP/s", PEAK_BF16_TFLOPS, what="6 B nh hd S^2/2"),
+            "attn_bwd_dkv": kern("attn_bwd_dkv", "TFLOP/s", PEAK_BF16_TFLOPS, what="8 B nh hd S^2/2 (each product once)"),
+            "ce_fused": kern("ce_fused", "GB/s", PEAK_HBM_GBS, scale=4.0 + 4.0 * density,
+                             what=f"per logit: 2 B read + 2 B gradient written in place + 4 B soft target on the {density:.2f} of rows with a position mask"),
+            "adamw_step": kern("adamw_step", "GB/s", PEAK_HBM_GBS, what="28 B per parameter"),
+            "teacher_reduce": kern("teacher_reduce", "GB/s", PEAK_HBM_GBS, what="2 B per target logit read + 4 B per draft-vocabulary probability written"),
+        }
+        fus = kernels["gemm_nt_swiglu_bwd"] or {}
+        # the step as a whole against the MFMA roofline: SURVEY 8d's F_draft = 3 * (T * F_step + 2 * 3Ht * H) per token
+        H, I, hd, nh, nkv = (cfg[k] for k in ("hidden_size", "intermediate_size", "head_dim", "num_attention_heads", "num_key_value_heads"))
+        f_step = 2.0 * (2 * H * nh * hd + 2 * 2 * H * nkv * hd + nh * hd * H + 3 * H * I + H * cfg["draft_vocab_size"]) + 4.0 * nh * hd * (S / 2.0)
+        f_draft = 3.0 * (args.ttt * f_step + 2.0 * 3 * cfg["target_hidden_size"] * H)
+        draft_tflops = f_draft * (tokens / world) / elapsed / 1e12
         line = {
             "metric": "EAGLE3 draft train tokens/sec, Llama-3-8B target, seq2048 at 1/2/4/8 MI355X",
             "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -289,11 +345,16 @@ def main():
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": GEMM_KERNEL_NAME, "achieved": ach,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
-                         "traffic_source": traffic_src, "launches_per_step": nlaunch / max(1, args.steps),
-                         "fused_swiglu_dgrad": {"launches_per_step": timer.fused_summary()[2] / max(1, args.steps),
-                                                "ms_per_step": timer.fused_summary()[1] / max(1, args.steps),
-                                                "gemm_tflops": (timer.fused_summary()[0] / max(timer.fused_summary()[1], 1e-9)) / 1e9},
-                         "gemm_ms_per_step": gemm_ms / max(1, args.steps)},
+                         "traffic_source": traffic_src, "traffic_commit": traffic_commit,
+                         "launches_per_step": nlaunch / st,
+                         "fused_swiglu_dgrad": {"launches_per_step": fus.get("launches_per_step"), "ms_per_step": fus.get("ms_per_step"),
+                                                "gemm_tflops": fus.get("achieved")},
+                         "gemm_ms_per_step": gemm_ms / st},
+            # every other hot kernel of the step, same method (HIP events on the launch stream over the timed region)
+            "kernels": {k: v for k, v in kernels.items() if v is not None},
+            "roofline_hbm": kernels["ce_fused"],
+            "draft_fwd_bwd": {"tflops_per_gpu": draft_tflops, "frac_of_mfma_peak": draft_tflops / PEAK_BF16_TFLOPS,
+                              "flop_per_token": f_draft, "formula": "SURVEY 8d F_draft = 3 (T F_step + 2 * 3Ht * H)"},
             "final_loss": loss,
             "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
         }

@@ -51,7 +51,10 @@ int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_
  * transposed operand.  K % 64 == 0 (pad the token dimension with zero rows), M, N multiples of 8.
  * workspace (optional, fp32, >= 2*M*N floats) + ksplit: 0 = the launcher splits K in two when the tile count would
  * leave the last round of CUs half empty (and the workspace is there), 1 = never split, 2 = always split (error if the
- * shape / workspace do not allow it); the partials are reduced in a fixed order (deterministic). */
+ * shape / workspace do not allow it); the partials are reduced in a fixed order (deterministic).
+ * The LAST 4096 floats of a workspace that is large enough (4096 floats beyond the split-K partials, if any) are used as
+ * pace-keeping counters: zeroed and incremented by every launch, they carry no data (timing only) and the result is
+ * bit-identical with and without them.  A caller that wants pacing passes 2*M*N + 4096 floats (or 4096 when it never splits). */
 int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N, int K,
                float alpha, float beta, float* workspace, long workspace_floats, int ksplit, void* stream);
 

@@ -136,7 +136,7 @@ def rope_inv_freq(cfg: DraftConfig, n_pos: Optional[int] = None) -> torch.Tensor
     if rs is None:
         return inv_freq
     rtype = rs.get("rope_type", rs.get("type"))
-    if rtype in (None, "default"):
+    if rtype in (None, "default", "mrope"):    # mrope: plain frequencies, three position axes (apply_mrope)
         return inv_freq
     if rtype == "llama3":
         factor = rs.get("factor") or 1.0
@@ -205,6 +205,17 @@ def apply_rope(q, k, cos, sin, position_ids):
     return q * c + rotate_half(q) * s, k * c + rotate_half(k) * s
 
 
+def apply_mrope(q, k, cos, sin, position_ids, mrope_section):
+    """``LlamaMutiRotaryEmbedding.forward`` + ``apply_multimodal_rotary_pos_emb`` (llama3_eagle.py:389-427,145-182):
+    position_ids is [3, B, S] (temporal, height, width); the head's rotary channels are cut into the sections
+    ``mrope_section * 2`` and section i takes its angle from axis i % 3.  cos/sin are the plain tables."""
+    c3, s3 = cos[position_ids], sin[position_ids]                  # [3, B, S, hd]
+    sec = list(mrope_section) * 2
+    c = torch.cat([m[i % 3] for i, m in enumerate(c3.split(sec, dim=-1))], dim=-1).unsqueeze(1)
+    s = torch.cat([m[i % 3] for i, m in enumerate(s3.split(sec, dim=-1))], dim=-1).unsqueeze(1)
+    return q * c + rotate_half(q) * s, k * c + rotate_half(k) * s
+
+
 def additive_attention_mask(attention_mask: torch.Tensor, S: int, dtype) -> torch.Tensor:
     """``prepare_decoder_attention_mask`` (modeling/draft/base.py:64-96,
     modeling/_mask_utils.py:29-73): causal + key-padding, both ``finfo(dtype).min``."""
@@ -270,7 +281,11 @@ def decoder_layer(p, cfg: DraftConfig, emb, hidden, cache, add_mask, position_id
     k = F.linear(x, p["midlayer.self_attn.k_proj.weight"]).view(B, S, nkv, hd).transpose(1, 2)
     v = F.linear(x, p["midlayer.self_attn.v_proj.weight"]).view(B, S, nkv, hd).transpose(1, 2)
     lck = len(cache[0])
-    q, k = apply_rope(q, k, cos, sin, position_ids + lck)
+    rs = cfg.rope_scaling or {}
+    if rs.get("rope_type", rs.get("type")) == "mrope":
+        q, k = apply_mrope(q, k, cos, sin, position_ids + lck, rs["mrope_section"])
+    else:
+        q, k = apply_rope(q, k, cos, sin, position_ids + lck)
     k = repeat_kv(k, nh // nkv)
     v = repeat_kv(v, nh // nkv)
     cache[0] = cache[0] + [k]

@@ -45,7 +45,7 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 
 def run_case(name, *, H, Ht, I, nh, nkv, hd, Vt, Vd, B, S, lengths, ttt, dtype, fc_norm=False, rope_scaling=None, seed=0,
-             lk_loss_type=None, kl_scale=1.0, kl_decay=1.0, norm_output=True):
+             lk_loss_type=None, kl_scale=1.0, kl_decay=1.0, norm_output=True, position_ids=None):
     torch.manual_seed(seed)
     cfg = LlamaConfig(
         hidden_size=H, intermediate_size=I, num_attention_heads=nh, num_key_value_heads=nkv,
@@ -81,9 +81,11 @@ def run_case(name, *, H, Ht, I, nh, nkv, hd, Vt, Vd, B, S, lengths, ttt, dtype, 
     # Eagle3TrainStrategy.forward_loss glue (training/strategies/base.py:237-304)
     input_ids, target, loss_mask = TargetHead.preprocess(None, batch["input_ids"], batch["target"], batch["loss_mask"])
     target_logits = F.linear(target, head_w)
+    if position_ids is not None:      # [3, B, S] multimodal rotary positions (llama3_eagle.py:389-427, eagle3/model.py:228-242)
+        batch["position_ids"] = position_ids
     outs = eagle(
         input_ids=input_ids, attention_mask=batch["attention_mask"], loss_mask=loss_mask,
-        target=target_logits, hidden_states=batch["hidden_state"],
+        target=target_logits, hidden_states=batch["hidden_state"], position_ids=position_ids,
     )
     plosses, acceptance_rates, acces, corrects, denoms, _, _ = outs
     loss = sum((0.8 ** i) * plosses[i] for i in range(len(plosses)))
@@ -185,3 +187,19 @@ if __name__ == "__main__":
                                                              mscale=1.0, mscale_all_dim=0.5,
                                                              original_max_position_embeddings=32), seed=8, **small)
         run_case("eagle3_rope_dynamic_fp32", rope_scaling=dict(rope_type="dynamic", factor=2.0), seed=9, **small)
+    if want("rope2"):  # linear position scaling (llama3_eagle.py:315-344) and multimodal 3-axis rope (145-182, 389-427)
+        small = dict(H=128, Ht=96, I=192, nh=4, nkv=2, hd=64, Vt=640, Vd=256, B=2, S=40, lengths=[40, 29], ttt=3,
+                     dtype=torch.float32)
+        run_case("eagle3_rope_linear_fp32", rope_scaling=dict(rope_type="linear", factor=2.5), seed=10, **small)
+        g = torch.Generator().manual_seed(11)
+        # text-like prefix (all three axes equal), then an "image" span where the height / width axes move on their own
+        t = torch.arange(40).repeat(2, 1)
+        hh = t.clone()
+        ww = t.clone()
+        hh[:, 12:28] = 12 + torch.arange(16).div(4, rounding_mode="floor")
+        ww[:, 12:28] = 12 + torch.arange(16) % 4
+        tt = t.clone()
+        tt[:, 12:28] = 12
+        pos3 = torch.stack([tt, hh, ww]) + torch.tensor([0, 3]).view(1, 2, 1)      # second sample offset
+        run_case("eagle3_rope_mrope_fp32", rope_scaling=dict(rope_type="mrope", mrope_section=[8, 12, 12]), seed=12,
+                 position_ids=pos3, **small)

@@ -530,7 +530,7 @@ extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, co
                            int S, int nh, int nkv, int hd, float scale, void* stream) {
     SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_fwd: bad shape");
     SF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0, "sf_attn_fwd: row strides must be multiples of 8 (16-byte segments)");
-    SF_CHECK_ARG(ndiag >= 0 && ndiag <= kMaxDiag, "sf_attn_fwd: at most 8 diagonal branches");
+    SF_CHECK_ARG(ndiag >= 0 && ndiag <= kMaxDiag, "sf_attn_fwd: at most 32 diagonal branches");
     AttnFwdArgs p;
     memset(&p, 0, sizeof(p));
     p.q = (const sf_bf16*)q; p.ldq = ldq;
@@ -559,7 +559,7 @@ extern "C" int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo,
                                long ldk, long lddk, int ndiag, const float* lse, float* delta, float* dq_init, int B,
                                int S, int nh, int nkv, int hd, float scale, void* stream) {
     SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_pre: bad shape");
-    SF_CHECK_ARG(ndiag >= 0 && ndiag <= kMaxDiag, "sf_attn_bwd_pre: at most 8 diagonal branches");
+    SF_CHECK_ARG(ndiag >= 0 && ndiag <= kMaxDiag, "sf_attn_bwd_pre: at most 32 diagonal branches");
     SF_CHECK_ARG(ndiag == 0 || dq_init, "sf_attn_bwd_pre: dq_init required with diagonal branches");
     SF_CHECK_ARG(hd == 64 || hd == 128, "head_dim must be 64 or 128");
     SF_CHECK_ARG(ldq % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldk % 8 == 0 && lddk % 4 == 0,

@@ -11,7 +11,7 @@ namespace sfattn {
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kNegBig = -1.0e30f;
-constexpr int kMaxDiag = 8;
+constexpr int kMaxDiag = 32;   // diagonal branches per launch = earlier TTT steps (ttt_length <= 33)
 
 // ---- L2-aware work order ----------------------------------------------------
 // Workgroup ids are handed to the 8 XCDs round-robin (block b runs on XCD b % 8: observed, relied on for speed only) and

@@ -567,8 +567,10 @@ extern "C" int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void
     {
         const long need = (p.ksplit > 1 ? 2L * M * N : 0L) + kTnSyncFloats;
         const bool pow2 = p.sync_every >= 16 && (p.sync_every & (p.sync_every - 1)) == 0;
+        // counters used = 8 XCDs x groups per XCD (tn_pace_group): they must fit the tail (a grid of > ~130 k tiles would not)
+        const long groups_per_xcd = ((long)p.ksplit * (nblk / 8 + 1) + 31) / 32;
         if (workspace && workspace_floats >= need && pow2 && K / TK / p.ksplit >= 2 * p.sync_every && nblk >= 64 &&
-            (p.ksplit == 1 || nblk % 8 == 0)) {
+            (p.ksplit == 1 || nblk % 8 == 0) && 8 * groups_per_xcd <= kTnSyncFloats) {
             p.sync = reinterpret_cast<unsigned*>(workspace + workspace_floats - kTnSyncFloats);
             if (hipMemsetAsync(p.sync, 0, kTnSyncFloats * sizeof(float), (hipStream_t)stream) != hipSuccess) p.sync = nullptr;
         }

@@ -16,6 +16,7 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from . import ops
 from .engine import Eagle3Engine
 from .model import LlamaForCausalLMEagle3
 
@@ -78,8 +79,8 @@ class OnlineEagle3Model(nn.Module):
         super().__init__()
         if lk_loss_type not in (None, "alpha", "lambda"):
             raise ValueError(f"Unknown lk loss type: {lk_loss_type}")  # core/lk_loss.py:99
-        if not 1 <= int(length) <= 8:
-            raise ValueError("ttt_length must be in 1..8")
+        if not 1 <= int(length) <= ops.MAX_DIAG + 1:
+            raise ValueError(f"ttt_length must be in 1..{ops.MAX_DIAG + 1}")
         self.draft_model = draft_model
         self.length = length
         self.attention_backend = attention_backend

@@ -45,19 +45,37 @@ class Eagle3Engine:
         if lk_loss_type not in (None, "alpha", "lambda"):
             raise ValueError(f"Unknown lk loss type: {lk_loss_type}")  # core/lk_loss.py:99
         self.lk_loss_type, self.kl_scale, self.kl_decay = lk_loss_type, float(kl_scale), float(kl_decay)
-        if c.head_dim not in (64, 128):
-            raise NotImplementedError("TTT attention kernels are built for head_dim 64 and 128")
+        # The MFMA attention kernels are instantiated for head_dim 64 and 128.  Other widths (the reference's own test
+        # fixture uses 16: tests/test_runtime/_fixtures.py:15-34) run through the same kernels on zero-padded heads: extra
+        # zero columns change neither q.k nor the softmax, and their outputs / gradients are dropped again.  That path copies
+        # q / k / v / o per step with torch ops -- correct and slow, for small models only; 64 and 128 never take it.
+        hd = c.head_dim
+        if hd % 16 != 0 or hd > 128:
+            raise NotImplementedError("head_dim must be a multiple of 16 and <= 128 (64 / 128 native, smaller widths zero-padded)")
+        self.hdp = hd if hd in (64, 128) else (64 if hd < 64 else 128)
         self.T = int(ttt_length)
-        if not 1 <= self.T <= 8:
-            raise ValueError("ttt_length must be in 1..8")
+        if not 1 <= self.T <= ops.MAX_DIAG + 1:
+            raise ValueError(f"ttt_length must be in 1..{ops.MAX_DIAG + 1} (one diagonal branch per earlier TTT step)")
         self.decay = float(ploss_decay)
         self.flat = FlatParams(model)
         self.dev = self.flat.data.device
         self.teacher_rows = teacher_rows
         cos, sin = rope_tables(c, torch.bfloat16)
         self.cos, self.sin = cos.to(self.dev), sin.to(self.dev)
+        # multimodal rope (llama3_eagle.py:389-427, 145-182): [3, B, S] position ids; rotary channel d of a head takes its
+        # angle from position axis mrope_axis[d].  The rope kernel is unchanged: per TTT step it is handed cos / sin tables
+        # with ONE ROW PER TOKEN (gathered from the plain tables with torch indexing -- table preparation, [N, hd] bf16).
+        rs = c.rope_scaling or {}
+        self.mrope = rs.get("rope_type", rs.get("type")) == "mrope"
+        if self.mrope:
+            sec = list(rs["mrope_section"]) * 2
+            if sum(sec) != hd:
+                raise ValueError("mrope_section must sum to head_dim / 2")
+            self._mrope_axis = torch.cat([torch.full((n,), i % 3, dtype=torch.long) for i, n in enumerate(sec)]).to(self.dev)
         self._arena: Dict[str, torch.Tensor] = {}   # name -> flat storage shared by every batch shape
-        self._views: Dict = {}                       # (B, S) -> dict of views into the arena
+        self._views: Dict = {}                       # (B, S) -> dict of views into the arena (LRU, bounded)
+        self._max_cached_shapes = 16
+        self._regrown = False
         self._active = None                          # the shape whose constants are currently laid down
         self._wt_version = -1
         self.weights_version = 0          # bumped by the optimizer after every step
@@ -95,6 +113,7 @@ class Eagle3Engine:
             if invalidate:               # cached views of other shapes may alias the freed storage
                 self._views.clear()
                 self._active = None
+                self._regrown = True
             self._arena[name] = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
         return self._arena[name][:n].view(*shape)
 
@@ -107,12 +126,15 @@ class Eagle3Engine:
 
     def _buffers(self, B: int, S: int):
         key = (B, S)
-        b = self._views.get(key)
+        b = self._views.pop(key, None)
         if b is None:
+            self._regrown = False
             b = self._build_views(B, S)
-            if key not in self._views:           # a regrowth inside _build_views clears the cache: carve again
+            if self._regrown:                    # storage was (re)allocated while carving: earlier views of THIS pass may dangle
                 b = self._build_views(B, S)
-            self._views[key] = b
+            while len(self._views) >= self._max_cached_shapes:   # LRU: ragged data brings a new (B, S) almost every step
+                self._views.pop(next(iter(self._views)))
+        self._views[key] = b                     # (re)inserted last = most recently used
         if self._active != key:
             self._init_constants(b, B, S)
             self._active = key
@@ -133,13 +155,23 @@ class Eagle3Engine:
                 b[nm + "_s"][TN:].zero_()
         if b["Kp"] > TN:
             b["h_s"][TN:].zero_()
-        b["en2"].zero_()
-        b["hs_s"].zero_()
-        b["dh0_s"].zero_()
-        b["ds2"].zero_()
+        # zero pad rows of the K-concatenated operands (the kernels write the real rows every step; only the rows past
+        # them must read as zero -- re-zeroing the whole buffers cost ~600 MB of memsets per shape switch at 8B dims)
+        Np, Npr, N_ = b["Np"], b["Np_real"], B * S
+        for buf in (b["en2"], b["ds2"]):
+            buf[Npr:Np].zero_()
+            buf[Np + Npr:].zero_()
+        b["hs_s"][N_:].zero_()
+        b["dh0_s"][N_:].zero_()
         b["metrics"].zero_()
         b["msum"].zero_()
         b["lk_logsum"].zero_()
+        if self.hdp != self.cfg.head_dim:    # the pad columns are never written afterwards
+            for nm in ("qp", "kp", "vp", "op"):
+                for t in b[nm]:
+                    t.zero_()
+            b["dop"].zero_()
+            b["dqp"].zero_()
 
     _stash_names = ("hn", "o", "pn", "act", "ln", "logits", "dh", "dgu", "dh1", "dqkv")
 
@@ -216,15 +248,34 @@ class Eagle3Engine:
         b["dE"] = cv("dE", Np, H)
         b["dhs"] = cv("dhs", N, Ht3) if c.fc_norm else None
         b["delta"] = cv("delta", B, nh, S, dtype=f32)
-        b["dq_init"] = cv("dq_init", N, nh * hd, dtype=f32)
-        b["dk"] = [cv(f"dk_{k}", N, nkv * hd, dtype=f32) for k in range(T)]
-        b["dv"] = [cv(f"dv_{k}", N, nkv * hd, dtype=f32) for k in range(T)]
+        hdp = self.hdp
+        b["dq_init"] = cv("dq_init", N, nh * hdp, dtype=f32)
+        b["dk"] = [cv(f"dk_{k}", N, nkv * hdp, dtype=f32) for k in range(T)]
+        b["dv"] = [cv(f"dv_{k}", N, nkv * hdp, dtype=f32) for k in range(T)]
+        if hdp != hd:       # zero-padded heads (see __init__): padded copies of q / k / v / o per step, dO / dQ per sweep
+            for nm, n in (("qp", nh), ("kp", nkv), ("vp", nkv), ("op", nh)):
+                b[nm] = [cv(f"{nm}_{k}", N, n * hdp) for k in range(T)]
+            b["dop"] = cv("dop", N, nh * hdp)
+            b["dqp"] = cv("dqp", N, nh * hdp)
+        if self.mrope:
+            b["cos_rows"] = [cv(f"cos_rows_{k}", N, hd) for k in range(T)]
+            b["sin_rows"] = [cv(f"sin_rows_{k}", N, hd) for k in range(T)]
         b["nws"] = cv("nws", ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)
         b["nws_e"] = cv("nws_e", ops.rmsnorm_bwd_workspace(Np, H), dtype=f32)
         # fp32 partials for the 2-way split-K of weight-gradient GEMMs whose tile count fills the CUs badly (down, q|k|v)
         # (+ 4096 floats at the tail: pace-keeping counters of sf_gemm_tn)
         b["tn_ws"] = cv("tn_ws", 2 * max(H * I, self.QW * H) + 4096, dtype=f32)
         return b
+
+    def _pad_heads(self, src: torch.Tensor, n: int, dst: torch.Tensor) -> None:
+        """[N, n*hd] (any row stride) -> the first hd columns of each head of dst [N, n*hdp]; the pad columns stay zero"""
+        N, hd = src.shape[0], self.cfg.head_dim
+        dst.view(N, n, self.hdp)[:, :, :hd].copy_(src.unflatten(1, (n, hd)))
+
+    def _unpad_heads(self, src: torch.Tensor, n: int, dst: torch.Tensor) -> None:
+        """inverse of _pad_heads (also fp32 -> bf16 for the K / V gradient accumulators)"""
+        N, hd = src.shape[0], self.cfg.head_dim
+        dst.unflatten(1, (n, hd)).copy_(src.view(N, n, self.hdp)[:, :, :hd])
 
     def _refresh_weight_transposes(self):
         """W^T images for the dgrad GEMMs (NT form); rebuilt only after an optimizer step."""
@@ -256,6 +307,10 @@ class Eagle3Engine:
         ``TargetHead.preprocess`` (target_head.py:103-108); ``loss_mask`` is [B,S] or [B,S,1].
         Returns the metric dict of ``Eagle3TrainStrategy.forward_loss`` (lists of 0-dim tensors)."""
         c, T, f = self.cfg, self.T, self.flat
+        for n in (f.names[0], f.names[-1]):      # the draft's parameters must still BE the flat buffer (a .to() / .float() /
+            if f.params[n].data_ptr() != f.data[f.slices[n][0]:].data_ptr():   # .half() on the draft module re-creates them)
+                raise RuntimeError("the draft model's parameters were moved or cast after the HIP engine adopted them; training "
+                                   "would update stale buffers -- move / cast the model before its first forward")
         B, S = input_ids.shape
         b = self._buffers(B, S)
         N, Spad = b["N"], b["Spad"]
@@ -276,9 +331,21 @@ class Eagle3Engine:
         b["ids"][:, :S].copy_(input_ids)
         b["lm"][:, :S].copy_(loss_mask)
         b["kvlen"].copy_(attention_mask.to(self.dev).sum(dim=1))
-        if position_ids is None:
+        if self.mrope:
+            if position_ids is None or position_ids.dim() != 3 or tuple(position_ids.shape) != (3, B, S):
+                raise ValueError("rope_type 'mrope' needs position_ids of shape [3, batch, seq_length] (eagle3/model.py:228-242)")
+            pos3 = position_ids.to(self.dev).long().reshape(3, N)
+            cols = torch.arange(hd, device=self.dev)
+            for k in range(T):   # step k rotates at position + k on every axis (llama3_eagle.py:719-733)
+                idx = (pos3 + k).clamp_(max=self.cos.shape[0] - 1)[self._mrope_axis].t()      # [N, hd]
+                b["cos_rows"][k].copy_(self.cos[idx, cols])
+                b["sin_rows"][k].copy_(self.sin[idx, cols])
+            b["pos"].copy_(torch.arange(N, device=self.dev))                                  # row r reads table row r
+        elif position_ids is None:
             b["pos"].copy_(torch.arange(S, device=self.dev).repeat(B))
         else:
+            if position_ids.dim() != 2:
+                raise ValueError("position_ids must be [batch, seq_length] (three-axis ids need rope_type 'mrope')")
             b["pos"].copy_(position_ids.reshape(-1))
         if self._t2d_u8 is None or self._t2d_u8.device != self.dev:
             self._t2d_u8 = self.model.t2d.to(self.dev).to(torch.uint8).contiguous()
@@ -316,7 +383,8 @@ class Eagle3Engine:
         elif N % 64 == 0:
             fc_in = self._fc_x = hs                    # already a valid sf_gemm_tn operand (K = N)
         else:
-            b["hsn"].copy_(hs)                          # odd test shapes only: zero-padded copy for the weight gradient
+            b["hsn"].copy_(hs)                          # N % 64 != 0 (the usual case on ragged real data: the collator pads to
+            # the longest sample, whatever it is): zero-padded copy of the fc input for the K = N weight-gradient GEMM
             fc_in, self._fc_x = b["hsn"], b["hs_s"]
         ops.gemm_nt(fc_in, f.view("fc.weight"), b["h"][0])
 
@@ -338,10 +406,21 @@ class Eagle3Engine:
             # q/k/v of cat(input_layernorm(embed(ids<<k)), hidden_norm(h_k))   (llama3_eagle.py:1625-1630)
             ops.rmsnorm_fwd(b["h"][k], f.view("midlayer.hidden_norm.weight"), eps, hn, b["rstd_h"][k])
             ops.gemm_nt_rowadd(hn, self.w_qkv[:, H:], qkv, b["epart"], S=S, Spad=Spad, off=k)
-            ops.rope_(qkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k)
-            ops.attn_fwd(qkv[:, :nh * hd], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], [b["qkv"][i][:, kcol] for i in range(1, k + 1)],
-                         [b["qkv"][i][:, vcol] for i in range(1, k + 1)], b["kvlen"], b["o"][k], b["lse"][k],
-                         B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+            if self.mrope:
+                ops.rope_(qkv, nh + nkv, hd, b["cos_rows"][k], b["sin_rows"][k], b["pos"], 0)
+            else:
+                ops.rope_(qkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k)
+            if self.hdp == hd:
+                ops.attn_fwd(qkv[:, :nh * hd], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], [b["qkv"][i][:, kcol] for i in range(1, k + 1)],
+                             [b["qkv"][i][:, vcol] for i in range(1, k + 1)], b["kvlen"], b["o"][k], b["lse"][k],
+                             B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+            else:
+                self._pad_heads(qkv[:, :nh * hd], nh, b["qp"][k])
+                self._pad_heads(qkv[:, kcol], nkv, b["kp"][k])
+                self._pad_heads(qkv[:, vcol], nkv, b["vp"][k])
+                ops.attn_fwd(b["qp"][k], b["kp"][0], b["vp"][0], b["kp"][1:k + 1], b["vp"][1:k + 1], b["kvlen"], b["op"][k],
+                             b["lse"][k], B=B, S=S, nh=nh, nkv=nkv, hd=self.hdp, scale=scale)
+                self._unpad_heads(b["op"][k], nh, b["o"][k])
             ops.gemm_nt(b["o"][k], f.view("midlayer.self_attn.o_proj.weight"), b["h1"][k], residual=b["h"][k])
             ops.rmsnorm_fwd(b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"), eps, pn, b["rstd_p"][k])
             ops.gemm_nt(pn, self.w_gu, b["gu"][k])
@@ -455,20 +534,33 @@ class Eagle3Engine:
             # attention
             ops.gemm_nt(dh1, self.woT, b["do"])
             qkv = b["qkv"][k]
-            q = qkv[:, :nh * hd]
-            kd = [b["qkv"][i][:, kcol] for i in range(1, k + 1)]
-            vd = [b["qkv"][i][:, vcol] for i in range(1, k + 1)]
-            ops.attn_bwd_pre(q, b["o"][k], b["do"], kd, vd, b["dk"][1:k + 1], b["dv"][1:k + 1], b["lse"][k], b["delta"],
-                             b["dq_init"] if k > 0 else None, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
-            ops.attn_bwd_dq(q, b["do"], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], b["kvlen"], b["lse"][k],
-                            b["delta"], b["dq_init"] if k > 0 else None, dqkv[:, :nh * hd], B=B, S=S, nh=nh, nkv=nkv,
-                            hd=hd, scale=scale)
-            ops.attn_bwd_dkv(q, b["do"], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], b["kvlen"],
-                             b["lse"][k], b["delta"], b["dk"][0], b["dv"][0], B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+            if self.hdp == hd:
+                q, o_k, do, dq_out = qkv[:, :nh * hd], b["o"][k], b["do"], dqkv[:, :nh * hd]
+                k0, v0 = b["qkv"][0][:, kcol], b["qkv"][0][:, vcol]
+                kd = [b["qkv"][i][:, kcol] for i in range(1, k + 1)]
+                vd = [b["qkv"][i][:, vcol] for i in range(1, k + 1)]
+            else:
+                self._pad_heads(b["do"], nh, b["dop"])
+                q, o_k, do, dq_out = b["qp"][k], b["op"][k], b["dop"], b["dqp"]
+                k0, v0, kd, vd = b["kp"][0], b["vp"][0], b["kp"][1:k + 1], b["vp"][1:k + 1]
+            ops.attn_bwd_pre(q, o_k, do, kd, vd, b["dk"][1:k + 1], b["dv"][1:k + 1], b["lse"][k], b["delta"],
+                             b["dq_init"] if k > 0 else None, B=B, S=S, nh=nh, nkv=nkv, hd=self.hdp, scale=scale)
+            ops.attn_bwd_dq(q, do, k0, v0, b["kvlen"], b["lse"][k], b["delta"], b["dq_init"] if k > 0 else None, dq_out,
+                            B=B, S=S, nh=nh, nkv=nkv, hd=self.hdp, scale=scale)
+            ops.attn_bwd_dkv(q, do, k0, v0, b["kvlen"], b["lse"][k], b["delta"], b["dk"][0], b["dv"][0], B=B, S=S, nh=nh,
+                             nkv=nkv, hd=self.hdp, scale=scale)
             # K_k / V_k have now received every contribution (steps k..T-1)
-            ops.cast_from_f32(b["dk"][k], dqkv[:, kcol])
-            ops.cast_from_f32(b["dv"][k], dqkv[:, vcol])
-            ops.rope_(dqkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k, backward=True)
+            if self.hdp == hd:
+                ops.cast_from_f32(b["dk"][k], dqkv[:, kcol])
+                ops.cast_from_f32(b["dv"][k], dqkv[:, vcol])
+            else:
+                self._unpad_heads(b["dqp"], nh, dqkv[:, :nh * hd])
+                self._unpad_heads(b["dk"][k], nkv, dqkv[:, kcol])
+                self._unpad_heads(b["dv"][k], nkv, dqkv[:, vcol])
+            if self.mrope:
+                ops.rope_(dqkv, nh + nkv, hd, b["cos_rows"][k], b["sin_rows"][k], b["pos"], 0, backward=True)
+            else:
+                ops.rope_(dqkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k, backward=True)
             ops.gemm_nt(dqkv, self.wqkvT[H:], b["dxh"])                 # hidden half of the QKV dgrad
             ops.shift_accum(dqkv, b["dsum"], B=B, S=S, Spad=Spad, off=k)   # embedding half: summed over the steps first
             dh_prev = b["dh_b"][0]
@@ -479,7 +571,7 @@ class Eagle3Engine:
         dh0 = dh_next
         if N % 64 == 0:
             fc_dy = dh0
-        else:                       # odd test shapes only: zero-padded copy (K of the fc weight gradient)
+        else:                       # N % 64 != 0 (ragged batches): zero-padded copy (K of the fc weight gradient)
             b["dh0_s"][:N].copy_(dh0)
             fc_dy = b["dh0_s"]
         # embedding half of the QKV backward, once for all steps.  The summed gradient enters the bf16 GEMMs as a

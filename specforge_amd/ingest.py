@@ -22,8 +22,14 @@ Semantics mirrored from the reference (bit-for-bit on the produced tensors, see 
 """
 from __future__ import annotations
 
+import os
+import pickle
 import queue
+import struct
 import threading
+import zipfile
+from collections import OrderedDict
+from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterator, List, Optional, Sequence
 
 import torch
@@ -33,6 +39,9 @@ from .training import distributed_sampler_indices
 
 
 def normalize_offline_sample(raw: Dict[str, torch.Tensor], max_len: int) -> Dict[str, torch.Tensor]:
+    """the reference's sample normalisation, restated (specforge/algorithms/eagle3/data.py:10-27: the statements are forced
+    by the file format; tests/golden/ingest_collate.pt pins the result to the reference's own function).  Only the fallback
+    path of the loader uses it -- the fast path reads the same bytes straight into the staging slot (``_read_direct``)."""
     hidden_state = raw["aux_hidden_state"].squeeze(0)[:max_len].unsqueeze(0)
     target = raw["hidden_state"].squeeze(0)[:max_len].unsqueeze(0)
     input_ids = raw["input_ids"][:max_len].unsqueeze(0)
@@ -41,6 +50,85 @@ def normalize_offline_sample(raw: Dict[str, torch.Tensor], max_len: int) -> Dict
         loss_mask[0, -1] = 0
     return dict(attention_mask=torch.ones_like(loss_mask, dtype=torch.long), loss_mask=loss_mask, target=target,
                 hidden_state=hidden_state, input_ids=input_ids)
+
+
+# ---- direct reader ---------------------------------------------------------------------------------------------------
+# ``torch.save`` writes an uncompressed zip: ``<name>/data.pkl`` (a pickle whose tensors are persistent-id references) and one
+# 64-byte-aligned record ``<name>/data/<key>`` per storage.  For the ingest that is all that is needed: the byte range of every
+# tensor.  ``torch.load(mmap=True)`` + normalise + ``copy_`` went through three Python-level tensor passes per sample and an
+# OpenMP team per copy; eight loader processes on one host (one per rank) reached 7.5 GB/s together where the ranks need 20
+# (tools/ingest_procs.py, profiles/r3_ingest_procs.json).  Here the file's bytes go from the page cache into the pinned staging
+# slot with ONE ``preadv`` per tensor (the GIL is released for its duration, so a small thread pool reads the samples of a
+# batch concurrently), and nothing else touches them.
+_STORAGE_DTYPES = {"BFloat16Storage": torch.bfloat16, "LongStorage": torch.int64, "FloatStorage": torch.float32,
+                   "HalfStorage": torch.float16, "IntStorage": torch.int32, "BoolStorage": torch.bool,
+                   "ByteStorage": torch.uint8, "DoubleStorage": torch.float64, "ShortStorage": torch.int16,
+                   "CharStorage": torch.int8}
+
+
+class _TensorRef:
+    __slots__ = ("key", "dtype", "offset", "shape", "stride")
+
+    def __init__(self, key, dtype, offset, shape, stride):
+        self.key, self.dtype, self.offset, self.shape, self.stride = key, dtype, offset, tuple(shape), tuple(stride)
+
+    def contiguous(self) -> bool:
+        exp, acc = [], 1
+        for n in reversed(self.shape):
+            exp.append(acc)
+            acc *= n
+        return all(n == 1 or st == e for n, st, e in zip(self.shape, self.stride, reversed(exp)))
+
+
+class _MetaUnpickler(pickle.Unpickler):
+    """reads data.pkl without touching a storage: tensors come back as _TensorRef"""
+
+    def find_class(self, module, name):
+        if module == "torch._utils" and name == "_rebuild_tensor_v2":
+            return lambda storage, offset, size, stride, *a: _TensorRef(storage[0], storage[1], offset, size, stride)
+        if module == "torch" and name in _STORAGE_DTYPES:
+            return _STORAGE_DTYPES[name]
+        if module == "collections" and name == "OrderedDict":
+            return OrderedDict
+        raise pickle.UnpicklingError(f"unsupported global {module}.{name}")
+
+    def persistent_load(self, pid):
+        if pid[0] != "storage":
+            raise pickle.UnpicklingError("unsupported persistent id")
+        return (pid[2], pid[1])          # (record key, dtype)
+
+
+def _sample_layout(path: str) -> Optional[Dict[str, tuple]]:
+    """{tensor name: (file offset of its first byte, dtype, shape)} or None when the file is not a plain torch zip"""
+    try:
+        with zipfile.ZipFile(path) as zf:
+            names = zf.namelist()
+            pkl = next(n for n in names if n.endswith("/data.pkl") or n == "data.pkl")
+            prefix = pkl[: -len("data.pkl")]
+            obj = _MetaUnpickler(zf.open(pkl)).load()
+            if not isinstance(obj, dict):
+                return None
+            out = {}
+            with open(path, "rb") as f:
+                for name, ref in obj.items():
+                    if not isinstance(ref, _TensorRef) or not ref.contiguous():
+                        return None
+                    zi = zf.getinfo(f"{prefix}data/{ref.key}")
+                    if zi.compress_type != zipfile.ZIP_STORED:
+                        return None
+                    f.seek(zi.header_offset)
+                    hdr = f.read(30)
+                    fn_len, extra_len = struct.unpack("<HH", hdr[26:30])
+                    data0 = zi.header_offset + 30 + fn_len + extra_len
+                    out[name] = (data0 + ref.offset * torch.empty((), dtype=ref.dtype).element_size(), ref.dtype, ref.shape)
+            return out
+    except (StopIteration, KeyError, pickle.UnpicklingError, zipfile.BadZipFile, OSError, struct.error):
+        return None
+
+
+def _bytes_view(t: torch.Tensor):
+    """writable byte view of a contiguous CPU tensor (numpy has no bfloat16: go through uint8)"""
+    return memoryview(t.view(torch.uint8).numpy()).cast("B")
 
 
 class _Slot:
@@ -71,7 +159,7 @@ class _Slot:
 class HiddenStateIngest:
     def __init__(self, files: Sequence[str], *, batch_size: int, max_len: int, target_hidden_size: int, device,
                  dp_rank: int = 0, dp_size: int = 1, seed: int = 0, shuffle: bool = True, pad_multiple: int = 1,
-                 slots: int = 2):
+                 slots: int = 2, reader_threads: int = 4, direct: bool = True):
         self.files = list(files)
         self.B, self.max_len, self.Ht = batch_size, max_len, target_hidden_size
         self.device = torch.device(device)
@@ -81,21 +169,69 @@ class HiddenStateIngest:
         Lcap = (max_len + pad_multiple - 1) // pad_multiple * pad_multiple
         self._slots = [_Slot(batch_size, Lcap, target_hidden_size, self.device, pin=cuda) for _ in range(max(2, slots))]
         self._copy_stream = torch.cuda.Stream(device=self.device) if cuda else None
+        self._direct = bool(direct)
+        self._layouts: Dict[str, Optional[Dict[str, tuple]]] = {}
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(reader_threads)), thread_name_prefix="sf-ingest")
 
     def batches_per_epoch(self) -> int:
         n = len(distributed_sampler_indices(len(self.files), dp_rank=self.dp_rank, dp_size=self.dp_size, seed=self.seed,
                                             epoch=0, shuffle=self.shuffle))
         return n // self.B
 
-    def _fill(self, slot: _Slot, idxs: List[int]) -> int:
-        samples = [normalize_offline_sample(torch.load(self.files[i], mmap=True, weights_only=True), self.max_len) for i in idxs]
-        L = max(s["input_ids"].shape[1] for s in samples)
-        L = (L + self.pad_multiple - 1) // self.pad_multiple * self.pad_multiple
+    # what each staged tensor is in the file (algorithms/eagle3/data.py:10-27): name in the slot <- name in the file
+    _SOURCE = (("hidden_state", "aux_hidden_state"), ("target", "hidden_state"), ("input_ids", "input_ids"), ("loss_mask", "loss_mask"))
+
+    def _read_direct(self, slot: _Slot, b: int, path: str) -> int:
+        """sample -> row b of the slot, straight from the file; returns its (truncated) length, or -1 if the file needs the
+        generic path (not a plain torch zip, other dtypes, unexpected shapes)"""
+        lay = self._layouts.get(path, False)
+        if lay is False:
+            lay = self._layouts[path] = _sample_layout(path)
+        if lay is None or any(src not in lay for _, src in self._SOURCE):
+            return -1
+        n = None
+        plan = []
+        for dst, src in self._SOURCE:
+            off, dtype, shape = lay[src]
+            buf = slot.h[dst]
+            rows = shape[-2] if len(shape) == 3 else shape[0]
+            feat = shape[-1] if len(shape) == 3 else 1
+            ok = dtype == buf.dtype and (len(shape) == 1 or (len(shape) == 3 and shape[0] == 1 and feat == buf.shape[-1]))
+            if not ok or (n is not None and min(rows, self.max_len) != n):
+                return -1
+            n = min(rows, self.max_len)
+            plan.append((buf, off, n * feat * buf.element_size()))
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            for buf, off, nbytes in plan:
+                if nbytes and os.preadv(fd, [_bytes_view(buf[b, :n])], off) != nbytes:
+                    raise OSError(f"short read from {path}")
+        finally:
+            os.close(fd)
+        if n > 0:
+            slot.h["loss_mask"][b, n - 1] = 0
+        slot.h["attention_mask"][b, :n] = 1
+        return n
+
+    def _read_generic(self, slot: _Slot, b: int, path: str) -> int:
+        s = normalize_offline_sample(torch.load(path, mmap=True, weights_only=True), self.max_len)
+        n = s["input_ids"].shape[1]
         for k, buf in slot.h.items():
-            buf[:, :L].zero_()
-            for b, s in enumerate(samples):
-                n = s[k].shape[1]
-                buf[b, :n].copy_(s[k][0])
+            buf[b, :n].copy_(s[k][0])
+        return n
+
+    def _read_one(self, slot: _Slot, b: int, path: str) -> int:
+        n = self._read_direct(slot, b, path) if self._direct else -1
+        return n if n >= 0 else self._read_generic(slot, b, path)
+
+    def _fill(self, slot: _Slot, idxs: List[int]) -> int:
+        lens = list(self._pool.map(lambda bi: self._read_one(slot, bi[0], self.files[bi[1]]), enumerate(idxs)))
+        L = max(lens)
+        L = (L + self.pad_multiple - 1) // self.pad_multiple * self.pad_multiple
+        for b, n in enumerate(lens):          # right-pad with zeros to the longest sample: only the tails are written
+            if n < L:
+                for buf in slot.h.values():
+                    buf[b, n:L].zero_()
         return L
 
     def collate_indices(self, idxs: Sequence[int]) -> Dict[str, torch.Tensor]:

@@ -87,7 +87,8 @@ def rope_tables(cfg: DraftConfig, dtype=torch.bfloat16) -> Tuple[torch.Tensor, t
     (llama3_eagle.py:218-312).  Variants: llama3 frequency smoothing (235-276), linear position scaling
     (315-344), dynamic NTK (347-386: the cache is pre-built for max_pos+20 > max_pos positions, so the base is
     already rescaled for that length), yarn (430-540: blended frequencies and an amplitude factor on cos/sin).
-    mrope (3-D position ids) is not on the text-only EAGLE3 path."""
+    mrope (llama3_eagle.py:389-427, 145-182) uses these plain tables too: the engine gathers one row per position AXIS
+    and interleaves the head's rotary channels by ``mrope_section`` (Eagle3Engine._rope_rows)."""
     dim = cfg.head_dim
     n_pos = cfg.max_position_embeddings + 20
     inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, dim, 2).float() / dim))
@@ -120,7 +121,7 @@ def rope_tables(cfg: DraftConfig, dtype=torch.bfloat16) -> Tuple[torch.Tensor, t
         mask = 1.0 - ramp
         inv_freq = freq_inter * (1 - mask) + freq_extra * mask
         amp = float(_yarn_mscale(f, rs["mscale"]) / _yarn_mscale(f, rs["mscale_all_dim"]))
-    elif rtype not in (None, "default", "linear"):
+    elif rtype not in (None, "default", "linear", "mrope"):   # mrope: plain tables; the engine combines the three axes
         raise NotImplementedError(f"specforge_amd: rope type {rtype!r} is not on the EAGLE3 offline path")
     t = torch.arange(n_pos, dtype=inv_freq.dtype)
     if rtype == "linear":
@@ -412,6 +413,12 @@ class FlatParams:
         self.data = torch.zeros(off, dtype=dt, device=dev)
         self.grad = torch.zeros(off, dtype=dt, device=dev)
         self.params: Dict[str, nn.Parameter] = {}
+        # parameters the path never gives a gradient: with norm_output=False the final `norm` is not applied
+        # (llama3_eagle.py:1772-1777), so the reference leaves norm.weight.grad None and its optimizer skips the parameter
+        # (optimizer.py:139-142).  Their .grad stays None here as well -- a foreign optimizer would otherwise apply weight
+        # decay to it and build Adam state for it.
+        cfg = getattr(model, "draft_config", None) or getattr(model, "config", None)
+        self.gradless = {"norm.weight"} if (cfg is not None and not getattr(cfg, "norm_output", True)) else set()
         with torch.no_grad():
             for n in order:
                 p = named[n]
@@ -419,7 +426,7 @@ class FlatParams:
                 view = self.data[lo:hi].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
-                p.grad = self.grad[lo:hi].view(p.shape)
+                p.grad = None if n in self.gradless else self.grad[lo:hi].view(p.shape)
                 self.params[n] = p
         # parameters in the reference's ``model.parameters()`` order (optimizer state index order)
         self.module_order: List[str] = [n for n, p in model.named_parameters() if p.requires_grad]
@@ -429,6 +436,9 @@ class FlatParams:
 
     def realias_grads(self) -> None:
         for n, p in self.params.items():
+            if n in self.gradless:
+                p.grad = None
+                continue
             if p.grad is None or p.grad.data_ptr() != self.grad[self.slices[n][0]:].data_ptr():
                 lo, hi = self.slices[n]
                 p.grad = self.grad[lo:hi].view(p.shape)

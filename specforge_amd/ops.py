@@ -257,6 +257,9 @@ def axpy_f32(alpha: float, x: torch.Tensor, y: torch.Tensor, accumulate: bool = 
     return y
 
 
+MAX_DIAG = 32     # kMaxDiag of the attention kernels: diagonal branches per launch (ttt_length <= MAX_DIAG + 1)
+
+
 def _ptr_array(ts: Sequence[torch.Tensor]):
     arr = (ctypes.c_void_p * max(1, len(ts)))()
     for i, t in enumerate(ts):

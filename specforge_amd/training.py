@@ -262,8 +262,15 @@ class HipDPTrainingBackend:
             self._handles.clear()
             return True
         reduced = bool(self._handles)
+        ev = getattr(self, "comm_wait_events", None)     # telemetry (bench.py): how long the compute stream waits here
+        if ev is not None and reduced and torch.cuda.is_available():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self._handles:
             h.wait()
+        if ev is not None and reduced and torch.cuda.is_available():
+            e1.record()
+            ev.append((e0, e1))
         self._handles.clear()
         return reduced
 

@@ -73,6 +73,48 @@ def test_llama3_8b_seq2048_invariants():
     assert ((acc >= 0) & (acc <= 1)).all()
 
 
+@pytest.mark.gpu
+def test_llama3_8b_bs8_k114688_step():
+    """The bench's own shape (bs 8 x 2048: the weight-gradient GEMMs contract over K = 7 * 16384 = 114 688 rows, which is
+    where the split-K + pace-keeping path of sf_gemm_tn switches on) as four copies of the B = 2 batch: the gradient is
+    run-to-run bit-identical, ploss_k equals the B = 2 run's (a mean over the same rows, four times), and the flat gradient
+    equals the B = 2 gradient (sum over 4x the rows at 1/4 the weight) to bf16 rounding."""
+    dev = torch.device("cuda", 0)
+    cfg, S, T = LLAMA3_8B, 2048, 7
+    torch.manual_seed(0)
+    model = LlamaForCausalLMEagle3(DraftConfig(**cfg), device=dev)
+    ids = torch.randperm(cfg["vocab_size"], generator=torch.Generator().manual_seed(0))[:cfg["draft_vocab_size"]].sort().values
+    t2d = torch.zeros(cfg["vocab_size"], dtype=torch.bool)
+    t2d[ids] = True
+    model.load_vocab_mapping_tensors(t2d, ids - torch.arange(cfg["draft_vocab_size"]))
+    eagle = OnlineEagle3Model(model, length=T).train()
+    head_w = (torch.randn(cfg["vocab_size"], cfg["target_hidden_size"], device=dev) * 0.02).to(torch.bfloat16)
+    strat = Eagle3TrainStrategy(eagle, target_head=TargetHead(head_w))
+    raw2 = make_batch(cfg, 2, S, dev, 7)
+    raw2["loss_mask"][:, :100] = 0
+    raw2["attention_mask"][1, 1500:] = 0
+    raw2["loss_mask"][1, 1499:] = 0
+    raw8 = {k: v.repeat((4,) + (1,) * (v.dim() - 1)).contiguous() for k, v in raw2.items()}
+    eng = eagle.engine
+
+    def run(raw):
+        eng.micro_in_window = 0
+        out = strat.forward_loss(TrainBatch(raw, {"target_repr": "hidden_state"}))
+        out.loss.backward()
+        torch.cuda.synchronize()
+        return torch.stack(out.metrics["plosses"]).float().cpu(), eng.flat.grad.clone()
+
+    pl8, g8 = run(raw8)
+    pl8b, g8b = run(raw8)
+    assert torch.equal(g8, g8b), "bs 8 backward (split-K + paced weight gradients at K = 114 688) is not deterministic"
+    assert torch.equal(pl8, pl8b)
+    pl2, g2 = run(raw2)
+    torch.testing.assert_close(pl8, pl2, rtol=2e-5, atol=1e-6)
+    rel = float((g8.float() - g2.float()).norm() / g2.float().norm())
+    print(f"\n[bs8 vs bs2 gradient] relative Frobenius difference {rel:.3e}")
+    assert rel < 2e-2, rel
+
+
 # ------------------------------------------------------------------ numeric parity at the headline dimensions
 LLAMA3_8B_CASE = dict(H=4096, Ht=4096, I=14336, nh=32, nkv=8, hd=128, Vt=128256, Vd=32000, B=2, S=2048, ttt=7, eps=1e-5,
                       max_pos=2048, rope_theta=LLAMA3_8B["rope_theta"], rope_scaling=LLAMA3_8B["rope_scaling"],

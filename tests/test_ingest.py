@@ -100,3 +100,36 @@ def test_ingest_matches_reference_collator_golden(tmp_path, golden_dir):
             assert got[k].shape == v.shape and got[k].dtype == v.dtype, (k, got[k].shape, v.shape)
             assert torch.equal(got[k], v), k
     assert any(b["input_ids"].shape[1] % 8 for b in blob["batches"])   # the fixture does exercise unaligned lengths
+
+
+def test_direct_reader_equals_the_torch_load_path(tmp_path):
+    """the preadv fast path (bytes of the torch.save zip -> staging slot) against torch.load + normalise + copy: ragged
+    lengths, truncation at max_len, a file in a format the fast path must refuse (float32 hidden states -> generic path)"""
+    from specforge_amd import ingest as I
+
+    g = torch.Generator().manual_seed(3)
+    Ht, files = 16, []
+    for i, L in enumerate([9, 33, 40, 17, 40, 5]):
+        dt = torch.float32 if i == 3 else torch.bfloat16
+        p = tmp_path / f"{i}.ckpt"
+        torch.save({"input_ids": torch.randint(0, 500, (L,), generator=g), "loss_mask": (torch.rand(L, generator=g) > 0.3).long(),
+                    "hidden_state": torch.randn(1, L, Ht, generator=g).to(dt), "aux_hidden_state": torch.randn(1, L, 3 * Ht, generator=g).to(dt)}, p)
+        files.append(str(p))
+    lay = I._sample_layout(files[0])
+    assert lay is not None and set(lay) == {"input_ids", "loss_mask", "hidden_state", "aux_hidden_state"}
+    raw = torch.load(files[0])
+    with open(files[0], "rb") as f:                      # the layout points at the tensor's bytes
+        f.seek(lay["aux_hidden_state"][0])
+        got = torch.frombuffer(bytearray(f.read(raw["aux_hidden_state"].numel() * 2)), dtype=torch.bfloat16)
+    assert torch.equal(got, raw["aux_hidden_state"].reshape(-1))
+    kw = dict(batch_size=3, max_len=35, target_hidden_size=Ht, device="cpu", shuffle=False)
+    fast, slow = I.HiddenStateIngest(files, direct=True, **kw), I.HiddenStateIngest(files, direct=False, **kw)
+    calls = []
+    orig = fast._read_generic
+    fast._read_generic = lambda slot, b, path: (calls.append(path), orig(slot, b, path))[1]
+    for grp in ([0, 1, 2], [3, 4, 5], [5, 0, 3]):
+        a, b = fast.collate_indices(grp), slow.collate_indices(grp)
+        assert set(a) == set(b)
+        for k in a:
+            assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), (grp, k)
+    assert set(calls) == {files[3]}                       # only the float32 file fell back

@@ -30,8 +30,6 @@ def _hip_loss_and_grad(logits, target, mask, scale=1.0):
 @pytest.mark.parametrize("T", [1024, 2048, 4096, 6000])
 @pytest.mark.parametrize("V", [4096, 8192, 10000])
 def test_ce_matches_eager_reference_grid(B, T, V):
-    if B * T * V > 4 * 4096 * 8192 + 1:  # keep the largest cells out (memory/time); the grid's corners are covered
-        pytest.skip("cell beyond the budget of the round-end GPU tier")
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(B * 7 + T + V)
     logits = torch.randn(B, T, V, device=dev, generator=g)

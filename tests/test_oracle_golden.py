@@ -26,7 +26,7 @@ def _run(blob):
         input_ids=b["input_ids"], attention_mask=b["attention_mask"], loss_mask=b["loss_mask"],
         hidden_state=b["hidden_state"], target_hidden=b["target"], ttt_length=blob["cfg"]["ttt"],
         lk_loss_type=blob["cfg"].get("lk_loss_type"), kl_scale=blob["cfg"].get("kl_scale", 1.0),
-        kl_decay=blob["cfg"].get("kl_decay", 1.0),
+        kl_decay=blob["cfg"].get("kl_decay", 1.0), position_ids=b.get("position_ids"),
     )
     out.loss.backward()
     return p, out
@@ -35,7 +35,8 @@ def _run(blob):
 @pytest.mark.parametrize("name,tol", [("eagle3_tiny_fp32", 1e-5), ("eagle31_gqa_fp32", 1e-5), ("eagle3_tiny_bf16", 2e-2),
                                       ("eagle3_lk_alpha_fp32", 1e-5), ("eagle3_lk_lambda_fp32", 1e-5),
                                       ("eagle3_nonorm_fp32", 1e-5), ("eagle3_rope_yarn_fp32", 1e-5),
-                                      ("eagle3_rope_dynamic_fp32", 1e-5)])
+                                      ("eagle3_rope_dynamic_fp32", 1e-5), ("eagle3_rope_linear_fp32", 1e-5),
+                                      ("eagle3_rope_mrope_fp32", 1e-5)])
 def test_oracle_matches_reference_run(golden_dir, name, tol):
     blob = torch.load(os.path.join(golden_dir, f"{name}.pt"), weights_only=False)
     p, out = _run(blob)

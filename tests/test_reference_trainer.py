@@ -204,3 +204,116 @@ def test_cli_train_path_and_sglang_export_round_trip(ref, golden_dir, tmp_path):
     missing, unexpected = rm.load_state_dict(sd, strict=False)
     assert not unexpected and all("embed" in k for k in missing)
     assert json.load(open(os.path.join(out, "config.json")))["architectures"] == ["LlamaForCausalLMEagle3"]
+
+
+def test_reference_tiny_fixture_head_dim_16_trains_unmodified(ref, tmp_path):
+    """The reference's OWN test fixture (tests/test_runtime/_fixtures.py: TINY_DRAFT_CONFIG = hidden 64, 4 / 2 heads, i.e.
+    head_dim 16; its target-head, vocab-map and feature-file writers) through ``build_offline_runtime -> Trainer.fit()``
+    twice: the pure reference, then the same files and the same draft JSON with the HIP path installed.  head_dim 16 runs on
+    the zero-padded-heads path of the engine (engine.py), ttt_length 9 on more than 8 diagonal branches."""
+    import importlib.util
+
+    from specforge.algorithms.builtin import builtin_algorithm_registry
+    from specforge.algorithms.eagle3.model import OnlineEagle3Model as RefOnline
+    from specforge.launch import build_offline_runtime
+    from specforge.modeling.auto import AutoDraftModel, AutoDraftModelConfig
+    from specforge.modeling.target.target_head import TargetHead
+    from specforge.optimizer import BF16Optimizer as RefOpt
+    from specforge_amd.eagle3 import OnlineEagle3Model
+    from specforge_amd.training import BF16Optimizer
+
+    spec = importlib.util.spec_from_file_location("ref_fixtures", os.path.join(RH.REFERENCE_ROOT, "tests", "test_runtime", "_fixtures.py"))
+    fx = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fx)
+    assert fx.TINY_DRAFT_CONFIG["hidden_size"] // fx.TINY_DRAFT_CONFIG["num_attention_heads"] == 16
+    os.environ["FSDP_SHARDING"] = "NO_SHARD"      # the pure reference run: DDP over gloo (an earlier test's cli._train may have reset it)
+    work = str(tmp_path)
+    torch.manual_seed(0)
+    dj = fx.write_draft_config(os.path.join(work, "draft.json")) if hasattr(fx, "write_draft_config") else None
+    if dj is None:
+        dj = os.path.join(work, "draft.json")
+        json.dump(fx.TINY_DRAFT_CONFIG, open(dj, "w"))
+    td = fx.write_target_head_dir(os.path.join(work, "target"))
+    vp = fx.write_vocab_mapping(os.path.join(work, "vm.pt"))
+    feat = fx.write_offline_files(os.path.join(work, "features"), n=8, seq=21)
+    ttt, nsteps, kw = 9, 3, dict(lr=2e-3, max_grad_norm=0.5, warmup_ratio=0.0, total_steps=10)
+
+    def run(hip: bool):
+        torch.manual_seed(1)
+        draft = AutoDraftModel.from_config(AutoDraftModelConfig.from_file(dj), attention_backend="sdpa", torch_dtype=torch.bfloat16)
+        torch.manual_seed(2)
+        with torch.no_grad():
+            for p in draft.parameters():
+                p.copy_(torch.randn(p.shape) * (0.08 if p.dim() > 1 else 0.1) + (1.0 if p.dim() == 1 else 0.0))
+        draft.load_vocab_mapping(vp)
+        draft.freeze_embedding()
+        head = TargetHead.from_pretrained(td, lm_head_key="lm_head.weight")
+        model = (OnlineEagle3Model if hip else RefOnline)(draft_model=draft, length=ttt, attention_backend="sdpa")
+        logged = []
+        trainer = build_offline_runtime(
+            algorithm=(ref.registry(override=True) if hip else builtin_algorithm_registry()).resolve("eagle3"),
+            hidden_states_path=feat, draft_model=model, target_head=head,
+            optimizer_factory=lambda m: (BF16Optimizer if hip else RefOpt)(m, **kw),
+            run_id="tiny-hip" if hip else "tiny-ref", output_dir=os.path.join(work, "out_hip" if hip else "out_ref"),
+            ttt_length=ttt, max_len=32, batch_size=2, max_steps=nsteps, num_epochs=2, seed=0,
+            logger=lambda m, s: logged.append({k: v for k, v in m.items() if not k.startswith("perf/")}), log_interval=1)
+        assert trainer.fit() == nsteps
+        return logged, type(draft).__name__, type(trainer.backend).__name__
+
+    want, cls_ref, be_ref = run(False)
+    ref.install(override=True)
+    try:
+        got, cls_hip, be_hip = run(True)
+    finally:
+        ref.uninstall()
+    assert cls_ref == cls_hip == "LlamaForCausalLMEagle3" and be_ref == "FSDPTrainingBackend" and be_hip == "_HipBackendForTrainer"
+    assert len(got) == len(want) == nsteps
+    for s, (g, w) in enumerate(zip(got, want)):
+        assert {f"ploss_{ttt - 1}", f"acc_{ttt - 1}", "grad_norm", "lr"} <= set(g)
+        for k, v in w.items():
+            tol = 1e-9 if k == "lr" else 3e-2 * max(1.0, abs(v))
+            assert abs(g[k] - v) <= tol, (s, k, g[k], v)
+
+
+def test_reference_optimizer_with_weight_decay_skips_the_gradless_norm(ref, golden_dir):
+    """norm_output=False: the final `norm` is never applied, the reference leaves its .grad None and its BF16Optimizer skips
+    the parameter (optimizer.py:139-142) -- also under weight decay.  The HIP path driven by the REFERENCE optimizer
+    (HipDPTrainingBackend.set_optimizer) must do the same: no decay on norm.weight, no Adam state for it."""
+    from specforge.optimizer import BF16Optimizer as RefOpt
+    from specforge_amd.eagle3 import Eagle3TrainStrategy, OnlineEagle3Model, TargetHead, TrainBatch
+    from specforge_amd.model import DraftConfig, LlamaForCausalLMEagle3
+    from specforge_amd.training import HipDPTrainingBackend
+
+    blob = torch.load(os.path.join(golden_dir, "eagle3_nonorm_fp32.pt"), weights_only=False)
+    c = blob["cfg"]
+    cfg = DraftConfig(hidden_size=c["H"], intermediate_size=c["I"], num_attention_heads=c["nh"], num_key_value_heads=c["nkv"],
+                      vocab_size=c["Vt"], draft_vocab_size=c["Vd"], head_dim=c["hd"], target_hidden_size=c["Ht"],
+                      max_position_embeddings=c["max_pos"], rms_norm_eps=c["eps"], fc_norm=c["fc_norm"],
+                      rope_scaling=c["rope_scaling"], norm_output=False)
+    model = LlamaForCausalLMEagle3(cfg)
+    sd = {k: v.to(torch.bfloat16) for k, v in blob["params"].items()}
+    sd["embed_tokens.weight"], sd["t2d"], sd["d2t"] = blob["embed"].to(torch.bfloat16), blob["t2d"], blob["d2t"]
+    model.load_state_dict(sd)
+    eagle = OnlineEagle3Model(model, length=c["ttt"]).train()
+    strat = Eagle3TrainStrategy(eagle, target_head=TargetHead(blob["head_w"].to(torch.bfloat16)))
+    backend = HipDPTrainingBackend()
+    backend.prepare_model(eagle)
+    eagle.engine                                   # adopt the parameters before the optimizer clones its masters
+    backend.set_optimizer(RefOpt(model, lr=1e-2, weight_decay=0.5, max_grad_norm=0.5, total_steps=10, warmup_ratio=0.0))
+    b = blob["batch"]
+    batch = TrainBatch(dict(input_ids=b["input_ids"], attention_mask=b["attention_mask"], loss_mask=b["loss_mask"],
+                            hidden_state=b["hidden_state"].to(torch.bfloat16), target=b["target"].to(torch.bfloat16)),
+                       {"target_repr": "hidden_state"})
+    named = dict(model.named_parameters())
+    before = {k: v.detach().clone() for k, v in named.items()}
+    for _ in range(2):
+        out = strat.forward_loss(batch)
+        backend.backward(out.loss, is_boundary=True)
+        assert named["norm.weight"].grad is None
+        backend.step()
+    assert torch.equal(named["norm.weight"], before["norm.weight"])          # untouched: no decay, no update
+    moved = [k for k, v in named.items() if v.requires_grad and k != "norm.weight" and not torch.equal(v, before[k])]
+    assert len(moved) == sum(1 for k, v in named.items() if v.requires_grad and k != "norm.weight")
+    st = backend.optimizer.state_dict()["optimizer_state_dict"]["state"]
+    trainable = [k for k, v in named.items() if v.requires_grad]
+    assert trainable.index("norm.weight") not in st                            # no Adam state for the grad-less parameter
