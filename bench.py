@@ -249,6 +249,7 @@ def main():
     backend.comm_wait_events = []                    # (N > 1) event pairs around the waits for the bucket all-reduces
     elapsed, out = timed(strat, args.steps, timer)
     loss = float(out.loss.detach())
+    mask_density = float(eagle.last_artifacts["position_mask"].float().mean())   # of the timed steps (before the dense-mask variant)
     fl, gemm_ms, nlaunch = timer.summary("gemm_nt")
     tokens = world * B * S * args.steps
 
@@ -307,7 +308,7 @@ def main():
         except Exception:
             pass
         st = max(1, args.steps)
-        density = float(eagle.last_artifacts["position_mask"].float().mean())
+        density = mask_density
 
         def kern(name, unit, peak, scale=1.0, what=""):
             w, ms, n = timer.summary(name)

@@ -1,5 +1,6 @@
 """Aggregate a rocprofv3 --pmc run (counter_collection.csv) per kernel family.
-usage: python tools/pmc_summary.py <rocprof output dir> <out.json>"""
+usage: python tools/pmc_summary.py <rocprof output dir> <out.json> [commit]   (the commit is stored as "_commit": bench.py stamps
+roofline.traffic with it)"""
 import csv, glob, json, re, sys
 from collections import defaultdict
 
@@ -17,7 +18,7 @@ def family(name):
     return None
 
 
-def main(d, out):
+def main(d, out, commit=None):
     # one csv per rocprofv3 run; several runs of the same command (one counter group each) may sit under `d`
     agg = defaultdict(lambda: defaultdict(float))
     nlaunch = defaultdict(int)
@@ -43,10 +44,14 @@ def main(d, out):
             # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md, calibrated on AdamW)
             e["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024.0 / e["launches"]
         res[fam] = e
+    if commit:
+        res["_commit"] = commit
     json.dump(res, open(out, "w"), indent=1)
     for fam, e in res.items():
+        if not isinstance(e, dict):
+            continue
         print(fam, {k: (round(v, 2) if isinstance(v, float) else v) for k, v in e.items()})
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)
