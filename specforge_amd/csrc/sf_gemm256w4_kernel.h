@@ -213,7 +213,7 @@ template <int SCHED> using W4PlanFor = std::conditional_t<SCHED == 13, W4PlanAFi
 // SCHED: 12 = W4PlanBFirst, 13 = W4PlanAFirst (product); 0 and 2..11 exist in the tools build only.
 // ABL (tools build, timing ablations of the round-1 schedule only, results are wrong): bit0 = no ds_reads after the first
 // tile, bit1 = no DMA in the loop, ...
-// ADD: 0 = plain, 1 = accumulators start from the fp32 row-mapped addend (sf_gemm_nt_rowadd), 2 = d(SwiGLU) in the bf16 epilogue
+// ADD: 0 = plain, 1 = + fp32 row-mapped addend in the epilogue, before the single bf16 rounding (sf_gemm_nt_rowadd), 2 = d(SwiGLU) in the bf16 epilogue
 // (sf_gemm_nt_swiglu_bwd; whole tiles only -- its launcher guarantees it)
 template <int OUT_F32, int ADD = 0, int SCHED = 12, int ABL = 0>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
@@ -291,26 +291,6 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = sf_v4f{0.f, 0.f, 0.f, 0.f};
-    if (ADD == 1) {
-        // row-mapped fp32 addend: START the accumulators from it (alpha == 1 is enforced by the launcher), so the
-        // K loop and the epilogue are exactly the plain kernel's -- the loads overlap the staging of K-tiles 0 and 1
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-            if (m < p.M) {
-                const int bb = m / p.e.add_S;
-                const float* a = p.e.Cadd + ((long)bb * p.e.add_Spad + (m - bb * p.e.add_S) + p.e.add_off) * p.e.ldadd;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int n = n0 + wc * 128 + j * 16 + 4 * (lane >> 4);
-                    if (n + 3 < p.N) acc[i][j] = *reinterpret_cast<const sf_v4f*>(a + n);
-                    else
-                        for (int r = 0; r < 4; ++r)
-                            if (n + r < p.N) acc[i][j][r] = a[n + r];
-                }
-            }
-        }
-    }
     };
     acc_init();
     sf_v8s f[2][16];  // [set][0..7 = B n-tiles, 8..15 = A m-tiles]
@@ -419,9 +399,29 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     // ---- hand-over: the finished tile's coordinates, then the next tile's first two K-tiles go in flight
     const int mc = m0, nc = n0;
     const int next = tile + (int)gridDim.x;
-    // (the row-addend form is launched one workgroup per tile -- sf_w4_grid -- and compiles without the second tile:
-    //  a second call site of its 256-register accumulator load made the compiler spill 152 registers)
-    const bool has_next = ADD != 1 && next < nblk;
+    const bool has_next = next < nblk;
+    // the interior-tile fast path of the epilogue (workgroup-uniform; 16-byte row segments need 16-byte aligned rows)
+    const bool fast = SF_W4_FAST_EPI && mc + TM <= p.M && nc + TN <= p.N && p.e.beta == 0.f && !p.e.R && (p.e.ldc & 7) == 0 &&
+                      ((size_t)p.e.C & 15) == 0;
+    // Row-addend form (round 3): the fp32 addend joins the accumulator in the EPILOGUE, before the single bf16 rounding.  Round 2
+    // started the accumulators from it: 256 KiB of loads per tile in front of the first MFMA, every workgroup of a round at
+    // once (64 MiB per round at the fabric's speed: ~0.1 ms of a 0.67 ms launch, 0.82 of hipBLASLt), and no persistent walk
+    // (a second call site of that 256-register load made the compiler spill).  Here the rows of m-tile i + 2 are loaded while
+    // m-tile i is packed and stored -- the epilogue is bound by the CU's store path, the loads ride under it -- and the first
+    // two m-tiles' rows are requested BEFORE the next tile's DMA pieces (vmcnt is in-order: a wait for an addend row younger
+    // than the DMAs would drain them).  The fragment registers are dead here, so the 64 registers are free.
+    sf_v4f ad[2][8];
+    const int arow_l = mc + wr * 128 + (lane & 15), acol = nc + wc * 128 + 4 * (lane >> 4);
+    auto addend_rows = [&](int i, sf_v4f (&dst)[8]) SF_INLINE_LAMBDA {
+        const int m = arow_l + i * 16;
+        const int bb = m / p.e.add_S;
+        const float* a = p.e.Cadd + ((long)bb * p.e.add_Spad + (m - bb * p.e.add_S) + p.e.add_off) * p.e.ldadd + acol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = *reinterpret_cast<const sf_v4f*>(a + j * 16);
+    };
+    if constexpr (ADD == 1) {
+        if (fast) { addend_rows(0, ad[0]); addend_rows(1, ad[1]); }
+    }
     w4_wait_lgkm();
     w4_barrier();                 // every wave's last fragment reads returned: both K-tile buffers are free
     if (has_next) {
@@ -442,15 +442,18 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     if ((p.cyc & 4) || ((p.cyc & 8) && (blockIdx.x & 1))) {   // timing experiments: no stores at all / only every other workgroup stores
     } else
 #endif
-    if (SF_W4_FAST_EPI && mc + TM <= p.M && nc + TN <= p.N && p.e.beta == 0.f && !p.e.R && (p.e.ldc & 7) == 0 &&
-        ((size_t)p.e.C & 15) == 0) {   // workgroup-uniform; 16-byte row segments need 16-byte aligned rows
+    if (fast) {
         const float alpha = p.e.alpha;
         if constexpr (OUT_F32) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float* crow = (float*)p.e.C + (long)(mc + wr * 128 + i * 16 + (lane & 15)) * p.e.ldc + nc + wc * 128 + 4 * (lane >> 4);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) *reinterpret_cast<sf_v4f*>(crow + j * 16) = acc[i][j] * alpha;
+                for (int j = 0; j < 8; ++j) {
+                    if constexpr (ADD == 1) *reinterpret_cast<sf_v4f*>(crow + j * 16) = acc[i][j] + ad[i & 1][j];   // (alpha == 1)
+                    else *reinterpret_cast<sf_v4f*>(crow + j * 16) = acc[i][j] * alpha;
+                }
+                if constexpr (ADD == 1) { if (i + 2 < 8) addend_rows(i + 2, ad[i & 1]); }
             }
             newer = 64;
         } else {
@@ -467,12 +470,15 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const sf_v4f v = acc[i][j] * alpha;
+                    sf_v4f v;
+                    if constexpr (ADD == 1) v = acc[i][j] + ad[i & 1][j];   // (alpha == 1 is enforced by the launcher)
+                    else v = acc[i][j] * alpha;
                     sf_v4s o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (short)sf_f2bf(v[e]);
                     *reinterpret_cast<sf_v4s*>(st + r * kStageRow + j * 32 + q * 8) = o;
                 }
+                if constexpr (ADD == 1) { if (i + 2 < 8) addend_rows(i + 2, ad[i & 1]); }
                 sf_wave_lockstep();
                 if constexpr (ADD == 2) {   // its own instantiation: a different operator with its own line in a kernel trace
                     // fused d(SwiGLU): this row segment of d(act) never goes to memory.  gate / up of the same 8 positions
@@ -519,10 +525,9 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                w4_store4<OUT_F32, 0>(p, mc + wr * 128 + i * 16 + (lane & 15), nc + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
+                w4_store4<OUT_F32, ADD == 1 ? 1 : 0>(p, mc + wr * 128 + i * 16 + (lane & 15), nc + wc * 128 + j * 16 + 4 * (lane >> 4), acc[i][j]);
     }
     if (!has_next) break;
-    if constexpr (ADD == 1) break;
 
     // ---- the next tile: accumulators, then its K-tiles 0 and 1 (in flight since before the epilogue) must have landed.
     // vmcnt retires in order, so "all but the `newer` youngest" covers the DMAs without waiting for the epilogue's stores.
@@ -570,9 +575,8 @@ static inline unsigned sf_w4_grid(long nblk, int add = 0) {
         return n >= 8 ? n / 8 * 8 : 256;
 #endif
     }();
-    // the row-addend form stays one workgroup per tile: its accumulators START from a 256 KB fp32 tile, a load that
-    // overlaps the first K-tiles' DMA at workgroup start but would sit between epilogue and K loop in the persistent form
-    return (unsigned)((persist && !add && nblk > cus) ? cus : nblk);
+    (void)add;   // (the row-addend form is persistent too since its addend moved to the epilogue)
+    return (unsigned)((persist && nblk > cus) ? cus : nblk);
 }
 
 // one launch function per instantiation; each lives in its own translation unit (sf_gemm256w4_i*.hip) so that the
