@@ -77,7 +77,16 @@ def init_single_rank(port: int = 29577):
     os.environ.setdefault("WORLD_SIZE", "1")
     os.environ.setdefault("LOCAL_RANK", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", str(port))
+    if "MASTER_PORT" not in os.environ:   # `port` is only a hint: parallel test workers (pytest -n) must not collide
+        import socket
+
+        with socket.socket() as sk:
+            try:
+                sk.bind(("127.0.0.1", port))
+            except OSError:
+                sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ["MASTER_PORT"] = str(port)
     from specforge.distributed import init_distributed
 
     init_distributed(timeout=10, tp_size=1)
