@@ -29,7 +29,7 @@ extern "C" {
 #define SF_BF16 0
 #define SF_F32 1
 
-#define SF_ABI_VERSION 3
+#define SF_ABI_VERSION 4
 
 int sf_abi_version(void);
 /* 1 if this library is the SIMT-emulator test build, 0 for the gfx950 product build */
@@ -137,6 +137,14 @@ int sf_swiglu_bwd(const void* dact, int dtype, long lddact, const void* gu, long
 int sf_gemm_nt_swiglu_bwd(const void* A, long lda, const void* B, long ldb, int M, int I, int K, const void* gu, long ldgu,
                           void* dgu, long lddgu, void* dact, long lddact, void* stream);
 
+/* The fused gate|up projection with the activation in its epilogue (llama3_eagle.py:1518-1549 forward:
+ * down_proj(act_fn(gate_proj(x)) * up_proj(x))): A [M, K] = x, Wgu [2I, K] = [gate_proj.weight ; up_proj.weight] (adjacent in the
+ * flat parameter buffer), gu [M, 2I] = gate|up out (the backward needs both), act [M, I] = round(silu(gate)) * up out.  One launch
+ * when the chip-filling kernel takes the shape (M % 256 == 0, I % 128 == 0, K % 64 == 0), sf_gemm_nt + sf_swiglu_fwd otherwise;
+ * same bits either way (ABI 4). */
+int sf_gemm_nt_swiglu_fwd(const void* A, long lda, const void* Wgu, long ldw, int M, int I, int K, void* gu, long ldgu,
+                          void* act, long ldact, void* stream);
+
 /* out[b1][b2][c][r] = in[b1][b2][r][c]: operand transposes for dgrad/wgrad and the K^T/V^T/Q^T/dO^T
  * images of the attention kernels (no reference equivalent: autograd transposes are views). */
 int sf_transpose(const void* in, int dtype, long in_b1, long in_b2, long in_ld, void* out, long out_b1, long out_b2,
@@ -153,6 +161,13 @@ int sf_shift_accum(const void* src, long ldsrc, float* dst, long lddst, int B, i
  * bf16 MFMA GEMM with 16 mantissa bits (the reference adds T bf16 products in fp32; rounding the sum once to 8 bits
  * would be coarser than that). */
 int sf_split_bf16(const float* in, long ldin, void* hi, void* lo, long ldout, long rows, int C, void* stream);
+/* The two above over all T steps in one pass (ABI 4): src [T*N, C] bf16 = the per-step q/k/v gradients stacked by step (N = B*S
+ * rows each: the weight-gradient stash), hi | lo [B*Spad, C] = the two-term expansion of
+ * sum_k src[k*N + b*S + (p - k)] over the steps k with 0 <= p - k < S, added in fp32 for k = T-1 .. 0 (the order T calls of
+ * sf_shift_accum with off = k ran them, so the bits are the same).  Reads every stash row once instead of an fp32
+ * read-modify-write of the whole sum per step. */
+int sf_shift_sum_split(const void* src, long ldsrc, int T, int B, int S, int Spad, int C, void* hi, void* lo, long ldout,
+                       void* stream);
 /* y = (accumulate ? y : 0) + alpha*x, fp32: carries norm-weight gradients across micro-steps. */
 int sf_axpy_f32(long n, float alpha, const float* x, float* y, int accumulate, void* stream);
 int sf_cast_from_f32(const float* in, long ldin, void* out, int dtype, long ldout, long rows, int C, float scale,

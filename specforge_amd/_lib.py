@@ -39,11 +39,13 @@ _SIGS = {
     "sf_rope": (c_int, [P, c_int, c_long, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
     "sf_swiglu_fwd": (c_int, [P, c_int, c_long, c_long, c_int, P, c_long, P]),
     "sf_swiglu_bwd": (c_int, [P, c_int, c_long, P, c_long, c_long, c_int, P, c_long, P]),
+    "sf_gemm_nt_swiglu_fwd": (c_int, [P, c_long, P, c_long, c_int, c_int, c_int, P, c_long, P, c_long, P]),
     "sf_gemm_nt_swiglu_bwd": (c_int, [P, c_long, P, c_long, c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P]),
     "sf_transpose": (c_int, [P, c_int, c_long, c_long, c_long, P, c_long, c_long, c_long, c_int, c_int, c_int, c_int, P]),
     "sf_axpy_f32": (c_int, [c_long, c_float, P, P, c_int, P]),
     "sf_add_bf16": (c_int, [c_long, P, P, P, P]),
     "sf_shift_accum": (c_int, [P, c_long, P, c_long, c_int, c_int, c_int, c_int, c_int, P]),
+    "sf_shift_sum_split": (c_int, [P, c_long, c_int, c_int, c_int, c_int, c_int, P, P, c_long, P]),
     "sf_split_bf16": (c_int, [P, c_long, P, P, c_long, c_long, c_int, P]),
     "sf_cast_from_f32": (c_int, [P, c_long, P, c_int, c_long, c_long, c_int, c_float, P]),
     "sf_attn_fwd": (c_int, [P, c_long, P, c_long, P, P, P, c_int, P, P, c_long, P, c_int, c_int, c_int, c_int, c_int,

@@ -208,13 +208,61 @@ extern "C" int sf_gemm_nt_swiglu_bwd(const void* A, long lda, const void* B, lon
 #endif
     static const int fuse = sf_knob("SF_GEMM_SWIGLU_FUSE", 1);
     const bool aligned = ((size_t)gu & 15) == 0 && ((size_t)dgu & 15) == 0 && ((size_t)dact & 15) == 0;
-    if (fuse && big && aligned && M % 256 == 0 && I % 256 == 0 && K % 64 == 0 && sf_gemm_use_256()) {
-        e.sw_gu = (const sf_bf16*)gu; e.sw_ldgu = ldgu;
-        e.sw_dgu = (sf_bf16*)dgu; e.sw_lddgu = lddgu;
-        return sf_gemm_nt_256w4_launch(A, lda, B, ldb, K, e, SF_BF16, stream);
+    if (fuse && big && aligned && M >= 256 && I % 256 == 0 && K % 64 == 0 && sf_gemm_use_256()) {
+        // ragged M (real data: the collator pads a batch to its own longest sample): the whole 256-row tiles take the fused kernel,
+        // the last M % 256 rows the two steps -- same bits either way, so the split is invisible
+        const int Mf = M / 256 * 256, Mt = M - Mf;
+        SfGemmEpi ef = e;
+        ef.M = Mf;
+        ef.sw_gu = (const sf_bf16*)gu; ef.sw_ldgu = ldgu;
+        ef.sw_dgu = (sf_bf16*)dgu; ef.sw_lddgu = lddgu;
+        if (int st = sf_gemm_nt_256w4_launch(A, lda, B, ldb, K, ef, SF_BF16, stream)) return st;
+        if (Mt == 0) return 0;
+        SfGemmEpi et = e;
+        et.M = Mt;
+        et.C = (sf_bf16*)dact + (long)Mf * lddact;
+        if (int st = sf_gemm_dispatch((const sf_bf16*)A + (long)Mf * lda, lda, B, ldb, K, et, SF_BF16, stream)) return st;
+        return sf_swiglu_bwd(et.C, SF_BF16, lddact, (const sf_bf16*)gu + (long)Mf * ldgu, ldgu, Mt, I, (sf_bf16*)dgu + (long)Mf * lddgu,
+                             lddgu, stream);
     }
     if (int st = sf_gemm_dispatch(A, lda, B, ldb, K, e, SF_BF16, stream)) return st;
     return sf_swiglu_bwd(dact, SF_BF16, lddact, gu, ldgu, M, I, dgu, lddgu, stream);
+}
+
+// gu = A . Wgu^T (the fused gate|up projection, [M, 2I]) and act = round(silu(gate)) * up in ONE launch when the 4-wave kernel
+// can take the shape (whole tiles; see ADD = 3 in sf_gemm256w4_kernel.h); every other shape: the GEMM, then sf_swiglu_fwd.
+extern "C" int sf_gemm_nt_swiglu_fwd(const void* A, long lda, const void* Wgu, long ldw, int M, int I, int K, void* gu, long ldgu,
+                                     void* act, long ldact, void* stream) {
+    SF_CHECK_ARG(I >= 0 && I < (1 << 29), "sf_gemm_nt_swiglu_fwd: bad I");
+    if (int st = sf_gemm_check(lda, ldw, ldgu, 0, M, 2 * I, K, SF_BF16, nullptr)) return st;
+    SF_CHECK_ARG(gu && act && ldgu % 8 == 0 && ldact % 8 == 0 && I % 8 == 0, "sf_gemm_nt_swiglu_fwd: gu / act rows must be 16-byte aligned");
+    if (M == 0 || I == 0) return 0;
+    SfGemmEpi e;
+    e.C = gu; e.ldc = ldgu; e.R = nullptr; e.ldr = 0;
+    e.Cadd = nullptr; e.ldadd = 0; e.add_S = 1; e.add_Spad = 1; e.add_off = 0;
+    e.M = M; e.N = 2 * I; e.alpha = 1.f; e.beta = 0.f;
+#ifdef SF_EMU
+    const bool big = K >= 512;
+#else
+    const bool big = (long)(M / 256) * (I / 128) >= 256 && K >= 512;
+#endif
+    static const int fuse = sf_knob("SF_GEMM_SWIGLU_FWD_FUSE", 1);
+    const bool aligned = ((size_t)gu & 15) == 0 && ((size_t)act & 15) == 0;
+    if (fuse && big && aligned && M >= 256 && I % 128 == 0 && K % 64 == 0 && (I + 256L) * ldw * 2 < (1L << 31) && sf_gemm_use_256()) {
+        const int Mf = M / 256 * 256, Mt = M - Mf;        // ragged M: whole tiles fused, the tail rows in two steps (same bits)
+        SfGemmEpi ef = e;
+        ef.M = Mf;
+        ef.sw_dgu = (sf_bf16*)act; ef.sw_lddgu = ldact;   // (sw_gu stays null: that is what selects the forward form)
+        if (int st = sf_gemm_nt_256w4_launch(A, lda, Wgu, ldw, K, ef, SF_BF16, stream)) return st;
+        if (Mt == 0) return 0;
+        SfGemmEpi et = e;
+        et.M = Mt;
+        et.C = (sf_bf16*)gu + (long)Mf * ldgu;
+        if (int st = sf_gemm_dispatch((const sf_bf16*)A + (long)Mf * lda, lda, Wgu, ldw, K, et, SF_BF16, stream)) return st;
+        return sf_swiglu_fwd(et.C, SF_BF16, ldgu, Mt, I, (sf_bf16*)act + (long)Mf * ldact, ldact, stream);
+    }
+    if (int st = sf_gemm_dispatch(A, lda, Wgu, ldw, K, e, SF_BF16, stream)) return st;
+    return sf_swiglu_fwd(gu, SF_BF16, ldgu, M, I, act, ldact, stream);
 }
 
 extern "C" int sf_gemm_nt_rowadd(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M,

@@ -18,7 +18,11 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     // the 32-bit per-lane byte offsets of the buffer-descriptor DMA cover one 256-row tile of either operand
     SF_CHECK_ARG(256L * lda * 2 < (1L << 31) && 256L * ldb * 2 < (1L << 31), "sf_gemm_nt: row stride too large for the 256-tile kernel");
     if (p.e.Cadd) SF_CHECK_ARG(p.e.alpha == 1.0f, "sf_gemm_nt_rowadd: the 4-wave kernel needs alpha == 1");
-    const int add = p.e.Cadd ? 1 : (p.e.sw_gu ? 2 : 0), f32 = c_dtype == SF_F32 ? 1 : 0;
+    // (sw_dgu without sw_gu = the SwiGLU-forward form: C = gate|up [M, N = 2I], sw_dgu = act [M, I])
+    const int add = p.e.Cadd ? 1 : (p.e.sw_gu ? 2 : (p.e.sw_dgu ? 3 : 0)), f32 = c_dtype == SF_F32 ? 1 : 0;
+    SF_CHECK_ARG(add != 3 || (!f32 && M % TM == 0 && N % TN == 0 && p.e.alpha == 1.f && p.e.beta == 0.f && !p.e.R &&
+                              (p.e.ldc & 7) == 0 && ((size_t)p.e.C & 15) == 0 && (N / 2 + 256L) * ldb * 2 < (1L << 31)),
+                 "sf_gemm_nt_swiglu_fwd: the fused form takes whole bf16 tiles only");
     SF_CHECK_ARG(add != 2 || (!f32 && M % TM == 0 && N % TN == 0 && p.e.alpha == 1.f && p.e.beta == 0.f && !p.e.R),
                  "sf_gemm_nt_swiglu_bwd: the fused form takes whole bf16 tiles only");
     // which operand's LDS half is released and re-staged first: B for narrow N, A for wide N (measured, see the header)
@@ -27,8 +31,8 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     if (f32 == F32 && add == ADD && sched == SCHED) return sf_w4_launch_##F32##_##ADD##_##SCHED(p, nblk, stream);
 #define SF_W4_LOCAL(F32, ADD, SCHED)                                                                                      \
     if (f32 == F32 && add == ADD && sched == SCHED) {                                                                    \
-        SF_W4_SMEM((gemm_nt_256w4_kernel<F32, ADD, SCHED>));                                                             \
-        SF_LAUNCH((gemm_nt_256w4_kernel<F32, ADD, SCHED>), dim3(sf_w4_grid(nblk, ADD == 1)), dim3(256), kW4SmemBytes, stream, p);   \
+        SF_W4_SMEM((gemm_nt_256w4_kernel<F32, ADD, SCHED>), w4_smem_bytes<ADD>());                                       \
+        SF_LAUNCH((gemm_nt_256w4_kernel<F32, ADD, SCHED>), dim3(sf_w4_grid(nblk, ADD == 1)), dim3(256), w4_smem_bytes<ADD>(), stream, p);   \
         return sf_check_launch("sf_gemm_nt(256w4 tools)");                                                               \
     }
 #ifdef SF_ABLATE   // A/B variants, tools only (tools/experiments/sf_gemm256w4_*.inc)
@@ -66,6 +70,7 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     SF_W4_CASE(0, 0, 12) SF_W4_CASE(0, 0, 13) SF_W4_CASE(1, 0, 12) SF_W4_CASE(1, 0, 13)
     SF_W4_CASE(0, 1, 12) SF_W4_CASE(0, 1, 13) SF_W4_CASE(1, 1, 12) SF_W4_CASE(1, 1, 13)
     SF_W4_CASE(0, 2, 12) SF_W4_CASE(0, 2, 13)
+    SF_W4_CASE(0, 3, 12) SF_W4_CASE(0, 3, 13)
 #undef SF_W4_CASE
 #undef SF_W4_LOCAL
     SF_CHECK_ARG(false, "sf_gemm_nt(256w4): no kernel for this configuration");

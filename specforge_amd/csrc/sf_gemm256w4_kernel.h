@@ -44,13 +44,13 @@
 #endif
 
 #ifdef SF_EMU
-#define SF_W4_SMEM(kernel)
+#define SF_W4_SMEM(kernel, ...)
 #else
-#define SF_W4_SMEM(kernel)                                                                                       \
+#define SF_W4_SMEM(kernel, ...)                                                                                  \
     do {                                                                                                         \
         static bool done_ = false;                                                                               \
         if (!done_) {                                                                                            \
-            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kW4SmemBytes); \
+            hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (kW4SmemBytes, ##__VA_ARGS__)); \
             (void)hipGetLastError();                                                                             \
             done_ = true;                                                                                        \
         }                                                                                                        \
@@ -80,6 +80,10 @@ constexpr int kBufBytes = 2 * kOpBytes;      // A + B
 constexpr int kStageRow = 272;               // epilogue staging: 256 B of a 128-column bf16 row + 16 B pad (bank spread)
 constexpr int kStageBytes = 4 * 16 * kStageRow;  // 4 waves x 16 rows
 constexpr int kW4SmemBytes = 2 * kBufBytes + kStageBytes;   // two K-tile buffers + the staging area = 145 KiB of the CU's 160
+// fused SwiGLU forward (ADD = 3): a staged row holds the wave's 64 gate, 64 up and 64 act values (3 x 128 B) + 16 B pad
+constexpr int kStageRow3 = 400;
+constexpr int kW4SmemBytes3 = 2 * kBufBytes + 4 * 16 * kStageRow3;   // 153 KiB
+template <int ADD> constexpr int w4_smem_bytes() { return ADD == 3 ? kW4SmemBytes3 : kW4SmemBytes; }
 
 
 #ifdef SF_EMU
@@ -214,7 +218,11 @@ template <int SCHED> using W4PlanFor = std::conditional_t<SCHED == 13, W4PlanAFi
 // ABL (tools build, timing ablations of the round-1 schedule only, results are wrong): bit0 = no ds_reads after the first
 // tile, bit1 = no DMA in the loop, ...
 // ADD: 0 = plain, 1 = + fp32 row-mapped addend in the epilogue, before the single bf16 rounding (sf_gemm_nt_rowadd), 2 = d(SwiGLU) in the bf16 epilogue
-// (sf_gemm_nt_swiglu_bwd; whole tiles only -- its launcher guarantees it)
+// (sf_gemm_nt_swiglu_bwd; whole tiles only -- its launcher guarantees it), 3 = SwiGLU forward in the bf16 epilogue of the fused
+// gate|up projection (sf_gemm_nt_swiglu_fwd; whole tiles only): B = [gate rows ; up rows] of the fused weight, N = 2 I; tile tn takes
+// the gate AND the up rows of act columns tn*128 .. +127, interleaved 16 / 16 along its 256 B rows, so that a lane's accumulators
+// [i][2 jj] / [i][2 jj + 1] are gate / up of the SAME 4 columns: gate|up leave in their natural [M, 2I] layout (the backward reads
+// them), act = round(silu(gate)) * up leaves beside them, and the separate pass over gate|up (0.94 GB read per call) is gone
 template <int OUT_F32, int ADD = 0, int SCHED = 12, int ABL = 0>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     SF_DYN_SMEM(smem);
@@ -246,16 +254,23 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
         m0 = tm * TM;
         n0 = tn * TN;
         bufA = sf_make_buf(p.A + (long)m0 * p.lda, 0x7fffffffu);
-        bufB = sf_make_buf(p.B + (long)n0 * p.ldb, 0x7fffffffu);
+        const long brow0 = ADD == 3 ? (long)tn * (TN / 2) : (long)n0;   // (ADD = 3: the tile's first gate row)
+        bufB = sf_make_buf(p.B + brow0 * p.ldb, 0x7fffffffu);
 #ifndef SF_EMU
         rawA = sf_make_buf_raw(p.A + (long)m0 * p.lda);
-        rawB = sf_make_buf_raw(p.B + (long)n0 * p.ldb);
+        rawB = sf_make_buf_raw(p.B + brow0 * p.ldb);
 #endif
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             int ra = (8 * wave + j) * 8 + srow, rb = ra;
             ra = m0 + ra < p.M ? ra : p.M - 1 - m0;
-            rb = n0 + rb < p.N ? rb : p.N - 1 - n0;
+            if constexpr (ADD == 3) {
+                // tile row rb = wave column block (rb >> 7) | pair (2 bits) | up? (1 bit) | column in the 16-group (4 bits)
+                const int w7 = rb & 127;
+                rb = ((w7 >> 4) & 1) * (p.N >> 1) + (rb >> 7) * 64 + (w7 >> 5) * 16 + (w7 & 15);
+            } else {
+                rb = n0 + rb < p.N ? rb : p.N - 1 - n0;
+            }
             voff[j] = (unsigned)(((long)ra * p.lda + slc * 8) * 2);
             voff[8 + j] = (unsigned)(((long)rb * p.ldb + slc * 8) * 2);
         }
@@ -463,9 +478,42 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
             // through LDS instead (a staging area behind the K-tile buffers, 16 rows per wave at a time): 8-byte writes in
             // the accumulator layout, 16-byte reads in row-major order, so every store instruction writes 4 rows x 256 B =
             // 8 full 128-byte lines (~5 us: the CU's 16 B/clk store path).
-            char* st = smem + 2 * kBufBytes + wave * (16 * kStageRow);     // wave-private
+            char* st = smem + 2 * kBufBytes + wave * (16 * (ADD == 3 ? kStageRow3 : kStageRow));     // wave-private
             const int r = lane & 15, q = lane >> 4;
             sf_bf16* cbase = (sf_bf16*)p.e.C + (long)(mc + wr * 128 + q) * p.e.ldc + nc + wc * 128 + r * 8;
+            if constexpr (ADD == 3) {
+                // gate | up | act of the wave's 64 act columns: [row][3][128 B]; out as 8 rows x 128 B per store instruction
+                const int srow3 = lane >> 3, sch = lane & 7;
+                const int I = p.N >> 1, acol0 = (nc >> 1) + wc * 64 + sch * 8;
+                sf_bf16* gub = (sf_bf16*)p.e.C + (long)(mc + wr * 128 + srow3) * p.e.ldc + acol0;
+                sf_bf16* actb = p.e.sw_dgu + (long)(mc + wr * 128 + srow3) * p.e.sw_lddgu + acol0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        sf_v4s og, ou, oa;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            og[e] = (short)sf_f2bf(acc[i][2 * jj][e]);
+                            ou[e] = (short)sf_f2bf(acc[i][2 * jj + 1][e]);
+                            oa[e] = (short)sf_f2bf(sf_swiglu_fwd_elem<sf_bf16>(sf_bf2f((sf_bf16)og[e]), sf_bf2f((sf_bf16)ou[e])));
+                        }
+                        *reinterpret_cast<sf_v4s*>(st + r * kStageRow3 + jj * 32 + q * 8) = og;
+                        *reinterpret_cast<sf_v4s*>(st + r * kStageRow3 + 128 + jj * 32 + q * 8) = ou;
+                        *reinterpret_cast<sf_v4s*>(st + r * kStageRow3 + 256 + jj * 32 + q * 8) = oa;
+                    }
+                    sf_wave_lockstep();
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {          // rows 8 h + srow3 of this m-tile
+                        const char* sp = st + (8 * h + srow3) * kStageRow3 + sch * 16;
+                        const long ro = (long)(i * 16 + 8 * h);
+                        *reinterpret_cast<sf_v8s*>(gub + ro * p.e.ldc) = *reinterpret_cast<const sf_v8s*>(sp);
+                        *reinterpret_cast<sf_v8s*>(gub + ro * p.e.ldc + I) = *reinterpret_cast<const sf_v8s*>(sp + 128);
+                        *reinterpret_cast<sf_v8s*>(actb + ro * p.e.sw_lddgu) = *reinterpret_cast<const sf_v8s*>(sp + 256);
+                    }
+                    sf_wave_lockstep();
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -518,7 +566,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                 }
                 sf_wave_lockstep();
             }
-            newer = 32;   // (the fused form issues 64 stores + 64 loads: more, which is the safe direction)
+            }
+            newer = 32;   // (the fused forms issue 48 stores / 64 stores + 64 loads: more, which is the safe direction)
         }
     } else {
 #pragma unroll
@@ -584,10 +633,11 @@ static inline unsigned sf_w4_grid(long nblk, int add = 0) {
 #define SF_W4_DECLARE(F32, ADD, SCHED) int sf_w4_launch_##F32##_##ADD##_##SCHED(const GemmW4Args& p, long nblk, void* stream)
 #define SF_W4_DEFINE(F32, ADD, SCHED)                                                                                  \
     SF_W4_DECLARE(F32, ADD, SCHED) {                                                                                   \
-        SF_W4_SMEM((gemm_nt_256w4_kernel<F32, ADD, SCHED>));                                                           \
-        SF_LAUNCH((gemm_nt_256w4_kernel<F32, ADD, SCHED>), dim3(sf_w4_grid(nblk, ADD == 1)), dim3(256), kW4SmemBytes, stream, p); \
+        SF_W4_SMEM((gemm_nt_256w4_kernel<F32, ADD, SCHED>), w4_smem_bytes<ADD>());                                     \
+        SF_LAUNCH((gemm_nt_256w4_kernel<F32, ADD, SCHED>), dim3(sf_w4_grid(nblk, ADD == 1)), dim3(256), w4_smem_bytes<ADD>(), stream, p); \
         return sf_check_launch("sf_gemm_nt(256w4)");                                                                   \
     }
 SF_W4_DECLARE(0, 0, 12); SF_W4_DECLARE(0, 0, 13); SF_W4_DECLARE(1, 0, 12); SF_W4_DECLARE(1, 0, 13);
 SF_W4_DECLARE(0, 1, 12); SF_W4_DECLARE(0, 1, 13); SF_W4_DECLARE(1, 1, 12); SF_W4_DECLARE(1, 1, 13);
 SF_W4_DECLARE(0, 2, 12); SF_W4_DECLARE(0, 2, 13);
+SF_W4_DECLARE(0, 3, 12); SF_W4_DECLARE(0, 3, 13);

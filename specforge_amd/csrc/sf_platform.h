@@ -104,6 +104,7 @@ SF_DEVICE float sf_exp(float x) { return expf(x); }
 SF_DEVICE float sf_exp2(float x) { return exp2f(x); }
 SF_DEVICE float sf_exp2_raw(float x) { return exp2f(x); }
 SF_DEVICE float sf_exp_fast(float x) { return exp2f(x * 1.4426950408889634f); }
+SF_DEVICE float sf_rcp_fast(float x) { return 1.0f / x; }
 SF_DEVICE float sf_log(float x) { return logf(x); }
 SF_DEVICE float sf_rsqrt(float x) { return 1.0f / sqrtf(x); }
 
@@ -297,6 +298,9 @@ SF_DEVICE float sf_exp2_raw(float x) { return __builtin_amdgcn_exp2f(x); }
 // exp(x) for the streamed softmax terms (x <= 0): one multiply + v_exp_f32, relative error ~|x| * 2^-24; libm's expf costs
 // ~10 VALU instructions per element and made the 128 k-column teacher rows VALU-bound
 SF_DEVICE float sf_exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+// 1 / x as one v_rcp_f32 (1 ulp): for the sigmoid of the SwiGLU epilogues, whose result is rounded to bf16 right after; the IEEE
+// division is ~8 VALU instructions per element and the fused GEMM epilogues run them with the matrix pipe idle
+SF_DEVICE float sf_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 SF_DEVICE float sf_log(float x) { return logf(x); }
 SF_DEVICE float sf_rsqrt(float x) { return rsqrtf(x); }
 #endif

@@ -224,10 +224,7 @@ SF_GLOBAL void swiglu_fwd_kernel(const T* gu, long ldgu, int I, long rows, T* ac
         SfVec8<T>::ld(gu + r * ldgu + j, g);
         SfVec8<T>::ld(gu + r * ldgu + I + j, up);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float sg = 1.0f / (1.0f + sf_exp_fast(-g[i]));
-            o[i] = SfElem<T>::rnd(g[i] * sg) * up[i];
-        }
+        for (int i = 0; i < 8; ++i) o[i] = sf_swiglu_fwd_elem<T>(g[i], up[i]);
         SfVec8<T>::st(act + r * ldact + j, o);
     }
 }
@@ -488,7 +485,58 @@ SF_GLOBAL void split_bf16_kernel(const float* in, long ldin, sf_bf16* hi, sf_bf1
         SfVec8<sf_bf16>::st(lo + r * ldout + c, l);
     }
 }
+// hi | lo [b*Spad + p][c] = two-term bf16 expansion of  sum_{k = T-1 .. 0} src[k*N + b*S + (p - k)][c]  (terms with p - k outside
+// 0 .. S-1 are absent): the T per-step shift-accumulate passes (an fp32 read-modify-write of the whole [B*Spad, C] sum each) and the
+// split, in ONE pass that reads each stash row once.  The fp32 adds run in the order the per-step form ran them (k descending).
+SF_GLOBAL void shift_sum_split_kernel(const sf_bf16* src, long ldsrc, long N, int T, sf_bf16* hi, sf_bf16* lo, long ldout, long rows_pad,
+                                      int S, int Spad, int C8) {
+    const long total = rows_pad * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C8;
+        const int c = (int)(i - r * C8) * 8;
+        const long b = r / Spad;
+        const int p = (int)(r - b * Spad);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = p < T - 1 ? p : T - 1;                 // s = p - k >= 0
+        const int klo = p - (S - 1) > 0 ? p - (S - 1) : 0;   // s <= S - 1
+        // the (at most T) rows are independent loads: batches of 4 in flight per lane
+        for (; k - 3 >= klo; k -= 4) {
+            SfRaw8<sf_bf16> x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u].ld(src + ((long)(k - u) * N + b * S + (p - (k - u))) * ldsrc + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += x[u].at(j);
+        }
+        for (; k >= klo; --k) {
+            SfRaw8<sf_bf16> x;
+            x.ld(src + ((long)k * N + b * S + (p - k)) * ldsrc + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += x.at(j);
+        }
+        float h[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            h[j] = sf_round_bf(acc[j]);
+            l[j] = acc[j] - h[j];
+        }
+        SfVec8<sf_bf16>::st(hi + r * ldout + c, h);
+        SfVec8<sf_bf16>::st(lo + r * ldout + c, l);
+    }
+}
 }  // namespace
+
+extern "C" int sf_shift_sum_split(const void* src, long ldsrc, int T, int B, int S, int Spad, int C, void* hi, void* lo, long ldout,
+                                  void* stream) {
+    SF_CHECK_ARG(T >= 1 && B >= 0 && S > 0 && Spad >= S + T - 1, "sf_shift_sum_split: bad shape (Spad must hold S + T - 1 positions)");
+    SF_CHECK_ARG(C >= 0 && C % 8 == 0 && ldsrc % 8 == 0 && ldout % 8 == 0, "sf_shift_sum_split: C and strides must be multiples of 8");
+    const long rows_pad = (long)B * Spad;
+    if (rows_pad == 0 || C == 0) return 0;
+    SF_LAUNCH(shift_sum_split_kernel, dim3(grid_for(rows_pad * (C / 8))), dim3(256), 0, stream, (const sf_bf16*)src, ldsrc, (long)B * S, T,
+              (sf_bf16*)hi, (sf_bf16*)lo, ldout, rows_pad, S, Spad, C / 8);
+    return sf_check_launch("sf_shift_sum_split");
+}
 
 extern "C" int sf_shift_accum(const void* src, long ldsrc, float* dst, long lddst, int B, int S, int Spad, int off, int C,
                               void* stream) {

@@ -52,9 +52,16 @@ template <> struct SfRaw8<float> {
 // d(SwiGLU): act = round_T(silu(g)) * u  ->  dg = da * u * silu'(g), du = da * round_T(silu(g)); one definition for the
 // standalone kernel and the fused GEMM epilogue, so the two produce the same bits.  The sigmoid's exponential is one multiply +
 // v_exp_f32 (relative error ~1e-6, far inside the bf16 rounding that follows); libm's expf made the fused epilogue VALU-bound
+// act = round_T(silu(g)) * u (llama3_eagle.py:1518-1549: act_fn(gate_proj(x)) is a bf16 tensor before the product): one
+// definition for swiglu_fwd_kernel and the fused gate|up GEMM epilogue (sf_gemm_nt_swiglu_fwd), so both give the same bits
+template <typename T>
+SF_DEVICE float sf_swiglu_fwd_elem(float g, float up) {
+    const float sg = sf_rcp_fast(1.0f + sf_exp_fast(-g));
+    return SfElem<T>::rnd(g * sg) * up;
+}
 template <typename T>
 SF_DEVICE void sf_swiglu_bwd_elem(float g, float up, float da, float& dg, float& du) {
-    const float sg = 1.0f / (1.0f + sf_exp_fast(-g));
+    const float sg = sf_rcp_fast(1.0f + sf_exp_fast(-g));
     const float silu = g * sg;
     dg = da * up * (sg * (1.0f + g * (1.0f - sg)));
     du = da * SfElem<T>::rnd(silu);

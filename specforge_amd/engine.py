@@ -240,9 +240,8 @@ class Eagle3Engine:
         b["dpn"] = cv("dpn", N, H)
         b["do"] = cv("do", N, nh * hd)
         b["dxh"] = cv("dxh", N, H)
-        # backward of the hoisted embedding half: fp32 sum over the steps of dqkv re-aligned to token positions, its
-        # two-term bf16 expansion (transposed, K-concatenated) for the wgrad, and the matching operand [en^T | en^T]
-        b["dsum"] = cv("dsum", Np, self.QW, dtype=f32)
+        # backward of the hoisted embedding half: the fp32 sum over the steps of dqkv re-aligned to token positions, as a
+        # two-term bf16 expansion [hi ; lo] (one pass over the dqkv stash after the sweep), and the matching operand [en ; en]
         b["ds2"] = cv("ds2", 2 * Np, self.QW)              # [hi ; lo] stacked along the contraction
         b["ds_hi"], b["ds_lo"] = b["ds2"][:Np], b["ds2"][Np:]
         b["dE"] = cv("dE", Np, H)
@@ -423,8 +422,7 @@ class Eagle3Engine:
                 self._unpad_heads(b["op"][k], nh, b["o"][k])
             ops.gemm_nt(b["o"][k], f.view("midlayer.self_attn.o_proj.weight"), b["h1"][k], residual=b["h"][k])
             ops.rmsnorm_fwd(b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"), eps, pn, b["rstd_p"][k])
-            ops.gemm_nt(pn, self.w_gu, b["gu"][k])
-            ops.swiglu_fwd(b["gu"][k], act)
+            ops.gemm_nt_swiglu_fwd(pn, self.w_gu, b["gu"][k], act)      # gate|up projection, SwiGLU in its epilogue
             ops.gemm_nt(act, f.view("midlayer.mlp.down_proj.weight"), b["h"][k + 1], residual=b["h1"][k])
             if c.norm_output:   # compute_logits (llama3_eagle.py:1772-1777)
                 ln = b["ln"][k]
@@ -503,7 +501,6 @@ class Eagle3Engine:
         ws = b["nws"]
         for t in b["dk"] + b["dv"]:
             t.zero_()
-        b["dsum"].zero_()
         nm = self._norm_micro
         first = {n: True for n in nm}
 
@@ -562,7 +559,6 @@ class Eagle3Engine:
             else:
                 ops.rope_(dqkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k, backward=True)
             ops.gemm_nt(dqkv, self.wqkvT[H:], b["dxh"])                 # hidden half of the QKV dgrad
-            ops.shift_accum(dqkv, b["dsum"], B=B, S=S, Spad=Spad, off=k)   # embedding half: summed over the steps first
             dh_prev = b["dh_b"][0]
             acc, a = nacc("midlayer.hidden_norm.weight")
             ops.rmsnorm_bwd(b["dxh"], b["h"][k], f.view("midlayer.hidden_norm.weight"), b["rstd_h"][k],
@@ -577,7 +573,7 @@ class Eagle3Engine:
         # embedding half of the QKV backward, once for all steps.  The summed gradient enters the bf16 GEMMs as a
         # two-term expansion hi + lo for the weight gradient; input_layernorm.weight only needs the leading term (the
         # reference rounds every step's d(input) to bf16 before the norm backward, which is coarser than that).
-        ops.split_bf16(b["dsum"], b["ds_hi"], b["ds_lo"])
+        ops.shift_sum_split(b["dqkv_s"], b["ds_hi"], b["ds_lo"], T=T, B=B, S=S, Spad=Spad)   # sum over the steps, re-aligned, hi + lo
         ops.gemm_nt(b["ds_hi"], self.wqkvT[:H], b["dE"])
         acc, a = nacc("midlayer.input_layernorm.weight")
         ops.rmsnorm_bwd(b["dE"][:b["Np_real"]], self.model.embed_tokens.weight.data, f.view("midlayer.input_layernorm.weight"),

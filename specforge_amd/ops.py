@@ -174,6 +174,18 @@ def swiglu_fwd(gu: torch.Tensor, act: torch.Tensor):
     return act
 
 
+def gemm_nt_swiglu_fwd(a: torch.Tensor, w_gu: torch.Tensor, gu: torch.Tensor, act: torch.Tensor):
+    """gu = a @ w_gu.T ([M, 2I] gate|up) and act = round(silu(gate)) * up: the fused gate|up projection with SwiGLU in its
+    epilogue (one launch for chip-filling shapes; gemm_nt + swiglu_fwd otherwise)"""
+    L = _lib.lib()
+    M, K = a.shape
+    I = w_gu.shape[0] // 2
+    assert w_gu.shape == (2 * I, K) and gu.shape == (M, 2 * I) and act.shape == (M, I)
+    assert a.dtype == w_gu.dtype == gu.dtype == act.dtype == torch.bfloat16
+    _lib.check(L.sf_gemm_nt_swiglu_fwd(_p(a), _rowmajor(a), _p(w_gu), _rowmajor(w_gu), M, I, K, _p(gu), _rowmajor(gu), _p(act),
+                                       _rowmajor(act), _stream()), "sf_gemm_nt_swiglu_fwd")
+
+
 def gemm_nt_swiglu_bwd(a: torch.Tensor, b: torch.Tensor, gu: torch.Tensor, dgu: torch.Tensor, dact: torch.Tensor):
     """dgu = d(SwiGLU)(a @ b.T, gu): the down-projection input gradient with the activation's backward in its epilogue
     (one launch for chip-filling shapes; gemm_nt + swiglu_bwd through `dact` otherwise)"""
@@ -248,6 +260,15 @@ def split_bf16(x: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor):
     assert _rowmajor(hi) == _rowmajor(lo)
     _lib.check(L.sf_split_bf16(_p(x), _rowmajor(x), _p(hi), _p(lo), _rowmajor(hi), x.shape[0], x.shape[1], _stream()),
                "sf_split_bf16")
+
+
+def shift_sum_split(src: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor, *, T: int, B: int, S: int, Spad: int):
+    """hi + lo ~= sum_k src[k*B*S + b*S + (p - k)] re-aligned to the padded positions p (src bf16 [>= T*B*S, C]; hi / lo bf16 [B*Spad, C])"""
+    L = _lib.lib()
+    assert src.dtype == hi.dtype == lo.dtype == torch.bfloat16 and src.shape[0] >= T * B * S
+    assert hi.shape == lo.shape and hi.shape[0] >= B * Spad and hi.shape[1] == src.shape[1] and _rowmajor(hi) == _rowmajor(lo)
+    _lib.check(L.sf_shift_sum_split(_p(src), _rowmajor(src), T, B, S, Spad, src.shape[1], _p(hi), _p(lo), _rowmajor(hi), _stream()),
+               "sf_shift_sum_split")
 
 
 def axpy_f32(alpha: float, x: torch.Tensor, y: torch.Tensor, accumulate: bool = True):

@@ -242,6 +242,25 @@ def test_shift_accum_and_split(backend):
     assert float(err) < 2 ** -15
 
 
+@pytest.mark.parametrize("B,S,T,C", [(3, 8, 3, 24), (2, 5, 7, 16), (1, 37, 9, 40)])
+def test_shift_sum_split_equals_the_per_step_form(backend, B, S, T, C):
+    """one pass over the T stacked step gradients == T x shift_accum (off = k, k = T-1 .. 0) + split_bf16, bit for bit"""
+    g = torch.Generator().manual_seed(9)
+    N, Spad = B * S, S + T
+    src = torch.randn(T * N + 5, C, generator=g).to(torch.bfloat16)      # (+ pad rows the kernel must not read)
+    dd = torch.zeros(B * Spad, C, device=backend)
+    for k in range(T - 1, -1, -1):
+        ops.shift_accum(src[k * N:(k + 1) * N].to(backend), dd, B=B, S=S, Spad=Spad, off=k)
+    hi_ref = torch.empty(B * Spad, C, dtype=torch.bfloat16, device=backend)
+    lo_ref = torch.empty_like(hi_ref)
+    ops.split_bf16(dd, hi_ref, lo_ref)
+    hi = torch.full((B * Spad + 3, C), 7.0, dtype=torch.bfloat16, device=backend)
+    lo = torch.full_like(hi, 5.0)
+    ops.shift_sum_split(src.to(backend), hi, lo, T=T, B=B, S=S, Spad=Spad)
+    assert torch.equal(hi[:B * Spad].cpu(), hi_ref.cpu()) and torch.equal(lo[:B * Spad].cpu(), lo_ref.cpu())
+    assert float((hi[B * Spad:].float() - 7.0).abs().max()) == 0.0 and float((lo[B * Spad:].float() - 5.0).abs().max()) == 0.0
+
+
 def test_add_bf16(backend):
     g = torch.Generator().manual_seed(3)
     a = torch.randn(40, 24, generator=g).to(torch.bfloat16)
@@ -366,6 +385,7 @@ def test_swiglu(backend, dtype, tol):
 
 
 @pytest.mark.parametrize("M,I,K", [(512, 768, 512),    # whole 256 x 256 tiles, long K: the fused epilogue of the 4-wave kernel (interpreter)
+                                   (600, 256, 512),    # ragged M: 2 fused row tiles + 88 tail rows in two steps
                                    (300, 264, 128)])   # everything else: gemm_nt + swiglu_bwd through the scratch
 def test_gemm_nt_swiglu_bwd_equals_the_two_steps(backend, M, I, K):
     """d(act) = dY . W_down with d(SwiGLU) in the GEMM epilogue == the same GEMM followed by swiglu_bwd (same roundings)"""
@@ -382,6 +402,31 @@ def test_gemm_nt_swiglu_bwd_equals_the_two_steps(backend, M, I, K):
     same = float((out == ref).float().mean())
     assert same >= 0.999, same                       # fp contraction may differ between the two call sites: <= 1 bf16 ulp, rarely
     torch.testing.assert_close(out.float().cpu(), ref.float().cpu(), rtol=2 ** -6, atol=1e-30)
+
+
+@pytest.mark.parametrize("M,I,K", [(512, 384, 512),    # whole tiles (3 n-tiles of 128 act columns), long K: the fused epilogue of the 4-wave kernel
+                                   (768, 128, 576),    # one n-tile; K-tile count odd
+                                   (600, 256, 512),    # ragged M: 2 fused row tiles + 88 tail rows in two steps
+                                   (300, 264, 128)])   # everything else: gemm_nt + swiglu_fwd
+def test_gemm_nt_swiglu_fwd_equals_the_two_steps(backend, M, I, K):
+    """gate|up = x . Wgu^T with SwiGLU in the GEMM epilogue == the same GEMM followed by swiglu_fwd: gate|up bit-identical (the
+    interleaved B-row order of the fused tile changes no accumulation order), act from the same rounded gate / up"""
+    x, w = _rand((M, K), torch.bfloat16, 1), _rand((2 * I, K), torch.bfloat16, 2)
+    d = lambda t: t.to(backend)
+    gu_ref = torch.empty((M, 2 * I), dtype=torch.bfloat16, device=backend)
+    act_ref = torch.empty((M, I), dtype=torch.bfloat16, device=backend)
+    ops.gemm_nt(d(x), d(w), gu_ref)
+    ops.swiglu_fwd(gu_ref, act_ref)
+    gu = torch.full((M, 2 * I), 7.0, dtype=torch.bfloat16, device=backend)
+    act = torch.full((M, I), 5.0, dtype=torch.bfloat16, device=backend)
+    ops.gemm_nt_swiglu_fwd(d(x), d(w), gu, act)
+    assert torch.equal(gu.cpu(), gu_ref.cpu())
+    same = float((act == act_ref).float().mean())
+    assert same >= 0.999, same                       # fp contraction may differ between the two call sites: <= 1 bf16 ulp, rarely
+    torch.testing.assert_close(act.float().cpu(), act_ref.float().cpu(), rtol=2 ** -6, atol=1e-30)
+    ref32 = x.float() @ w.float().t()
+    want = torch.nn.functional.silu(ref32[:, :I]) * ref32[:, I:]
+    torch.testing.assert_close(act.float().cpu(), want, rtol=3e-2, atol=3e-2 * float(want.abs().max()) / 4)
 
 
 def test_transpose_and_cast(backend):

@@ -91,6 +91,37 @@ def test_gemm_nt_swiglu_bwd_headline_shape():
     assert worst < 8e-3, worst
 
 
+def test_gemm_nt_swiglu_fwd_headline_shape():
+    """the fused gate|up projection with SwiGLU in its epilogue (16384 x 2*14336 x 4096: 64 x 112 whole tiles, persistent walk)
+    against gemm_nt + swiglu_fwd on the same operands, and act directly against fp32 torch"""
+    M, I, K = 16384, 14336, 4096
+    x, w = _randn((M, K), 1), _randn((2 * I, K), 2, scale=1.0 / math.sqrt(K))
+    gu_ref = torch.empty((M, 2 * I), dtype=torch.bfloat16, device=DEV)
+    act_ref = torch.empty((M, I), dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(x, w, gu_ref)
+    ops.swiglu_fwd(gu_ref, act_ref)
+    gu = torch.full((M, 2 * I), 7.0, dtype=torch.bfloat16, device=DEV)
+    act = torch.full((M, I), 5.0, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt_swiglu_fwd(x, w, gu, act)
+    assert torch.equal(gu, gu_ref)
+    same = float((act == act_ref).float().mean())
+    print(f"\n[swiglu-fused gate|up] identical act elements {same:.6f}")
+    assert same >= 0.999, same
+    torch.testing.assert_close(act.float(), act_ref.float(), rtol=2 ** -6, atol=1e-30)
+    blk, worst = 2048, 0.0
+    for m0 in range(0, M, blk):
+        z = x[m0:m0 + blk].float() @ w.float().t()
+        want = torch.nn.functional.silu(z[:, :I]) * z[:, I:]
+        got = act[m0:m0 + blk].float()
+        worst = max(worst, float((got - want).abs().max() / want.abs().max()))
+    print(f"[swiglu-fused gate|up vs fp32 torch] max|err|/max|ref| = {worst:.3e}")
+    assert worst < 1e-2, worst
+    runs = [torch.empty_like(act) for _ in range(3)]
+    for o in runs:
+        ops.gemm_nt_swiglu_fwd(x, w, gu, o)
+    assert all(torch.equal(o, act) for o in runs)          # run-to-run bit-identical
+
+
 def test_gemm_nt_rowadd_headline_shape():
     M, N, K, S, T = 16384, 6144, 4096, 2048, 7
     B, Spad = M // S, S + T
