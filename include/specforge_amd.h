@@ -107,6 +107,27 @@ int sf_teacher_reduce(const void* z, int dtype, long ldz, int rows, int Vt, int 
                       const unsigned char* t2d, const int* loss_mask_pad, int S, int Spad, float* target_p_pad,
                       float* pod_scale_pad, float* tsum_pad, long long* ids_pad, int* pos_mask_pad, void* stream);
 
+/* The same reduction for logits whose COLUMNS ARE PERMUTED, draft sub-vocabulary first (ABI 4): column c of z is vocabulary entry
+ * perm[c], perm[j] = j + d2t[j] for j < Vd, the other entries after them.  The caller permutes the rows of the frozen teacher head
+ * once (specforge/modeling/target/target_head.py:93-101 computes logits = hidden . W^T: W[perm] gives this layout for free), so the
+ * draft softmax reads Vd contiguous logits instead of gathering them through d2t.  Same outputs as sf_teacher_reduce (argmax in
+ * original indices, lowest original index on ties).  z holds the first Vz >= Vd permuted columns; the columns from Vz on, if any,
+ * arrive as `nparts` per-column-block partials {max, sum exp(z - max), argmax column, -} per row, block q of row r at
+ * part[(r * part_stride + q) * 4] (written by sf_gemm_nt_teacher: those logits are never stored). */
+int sf_teacher_reduce_perm(const void* z, int dtype, long ldz, int rows, int Vz, int Vt, int Vd, const int* perm,
+                           const unsigned char* t2d, const float* part, int nparts, long part_stride, const int* loss_mask_pad,
+                           int S, int Spad, float* target_p_pad, float* pod_scale_pad, float* tsum_pad, long long* ids_pad,
+                           int* pos_mask_pad, void* stream);
+
+/* The teacher head GEMM for that layout (TargetHead.forward, target_head.py:93-101, on the row-permuted weight Wp [Vt, K]):
+ * z = A . Wp^T in bf16.  With `part` given and a chip-filling shape, only the first *vz_out = roundup(Vd, 256) columns of z are
+ * stored (the draft sub-vocabulary's logits); every later 128-column block of a row is reduced in the GEMM epilogue to one record
+ * {max, sum exp(z - max), argmax column, 0} at part[(row * part_stride + block) * 4] (*nparts_out blocks <= part_stride) -- 3/4 of
+ * the [rows, Vt] logits are never written or read back.  Otherwise (small shapes, part == NULL) all Vt columns are stored and
+ * *nparts_out = 0.  z needs room for Vt columns either way.  Feed both to sf_teacher_reduce_perm (ABI 4). */
+int sf_gemm_nt_teacher(const void* A, long lda, const void* Wp, long ldw, int M, int Vt, int K, int Vd, void* z, long ldz, float* part,
+                       long part_stride, int* vz_out, int* nparts_out, void* stream);
+
 /* ---- RMSNorm (+frozen-embedding gather) ---------------------------------------------------
  * replaces llama3_eagle.py:1561-1567 (LlamaRMSNorm.forward), 1759-1760 (embed_input_ids) and
  * the cat() placement of 1625-1630 (y/ldy address one half of the 2H-wide layer input).

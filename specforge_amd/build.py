@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = ["sf_core.hip", "sf_loss.hip", "sf_pointwise.hip", "sf_gemm.hip", "sf_gemm256.hip", "sf_gemm256w4.hip", "sf_gemm256w4_i0.hip", "sf_gemm256w4_i1.hip", "sf_gemm256w4_i2.hip", "sf_gemm256w4_i3.hip", "sf_gemm256w4_i4.hip", "sf_gemm256w4_i5.hip", "sf_gemm256tn.hip", "sf_attn.hip", "sf_attn_dkv.hip"]
+SOURCES = ["sf_core.hip", "sf_loss.hip", "sf_pointwise.hip", "sf_gemm.hip", "sf_gemm256.hip", "sf_gemm256w4.hip", "sf_gemm256w4_i0.hip", "sf_gemm256w4_i1.hip", "sf_gemm256w4_i2.hip", "sf_gemm256w4_i3.hip", "sf_gemm256w4_i4.hip", "sf_gemm256w4_i5.hip", "sf_gemm256w4_i6.hip", "sf_gemm256tn.hip", "sf_attn.hip", "sf_attn_dkv.hip"]
 HIP_LIB = os.path.join(PKG, "libsfhip.so")
 EMU_LIB = os.path.join(ROOT, "tests", "emu", "libsfhip_emu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -275,13 +275,14 @@ struct AttnBwdPreArgs {
 // A group of HD/8 lanes owns one token row (8 consecutive d per lane, 16-byte loads), so a wave covers 4 (HD=128)
 // or 8 (HD=64) rows; wave w handles kv groups w, w+4, ... and walks the query heads of a group serially, which
 // keeps the dK_i / dV_i sums over those heads in registers.  Every dot product is an all-reduce over the lane group
-// done with DPP row operations (sf_row_sum) -- no LDS crossbar traffic.  One launch handles at most kPreChunk
+// done with DPP row operations (sf_row_sum) -- no LDS crossbar traffic.  One launch handles at most ND
 // diagonals (their K/V/dK/dV slices live in registers); the host splits longer lists into chunks, later chunks
 // accumulate into dq_init.
-constexpr int kPreChunk = 4;
-template <int HD>
+// ND = diagonals per launch.  Measured and rejected (round 3): an 8-wide instantiation that takes 5 .. 8 diagonals in ONE launch
+// (saves a second read of q / o / dO and an fp32 read-modify-write of dq_init: 56 KB of 216 per row at 6 diagonals) needs 349
+// registers = one wave per SIMD, and the streaming kernel then runs no faster than two 4-wide launches (0.660 vs 0.669 ms).
+template <int HD, int ND>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_pre_kernel(AttnBwdPreArgs p) {
-    constexpr int ND = kPreChunk;
     constexpr int LPH = HD / 8;     // lanes per row
     constexpr int RPW = 64 / LPH;   // rows per wave
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
@@ -566,13 +567,14 @@ extern "C" int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo,
                  "sf_attn_bwd_pre: strides must be multiples of 8 (16-byte row segments)");
     const int rows_per_block = 64 / (hd / 8);
     const dim3 grid((unsigned)((B * S + rows_per_block - 1) / rows_per_block));
-    for (int lo = 0; lo == 0 || lo < ndiag; lo += kPreChunk) {
+    constexpr int chunk = 4;
+    for (int lo = 0; lo == 0 || lo < ndiag; lo += chunk) {
         AttnBwdPreArgs p;
         memset(&p, 0, sizeof(p));
         p.q = (const sf_bf16*)q; p.ldq = ldq;
         p.o = (const sf_bf16*)o; p.ldo = ldo;
         p.dout = (const sf_bf16*)dout; p.lddo = lddo;
-        const int n = ndiag - lo < kPreChunk ? ndiag - lo : kPreChunk;
+        const int n = ndiag - lo < chunk ? ndiag - lo : chunk;
         for (int i = 0; i < n; ++i) {
             p.kd[i] = (const sf_bf16*)kd[lo + i]; p.vd[i] = (const sf_bf16*)vd[lo + i];
             p.dkd[i] = dkd[lo + i]; p.dvd[i] = dvd[lo + i];
@@ -580,7 +582,7 @@ extern "C" int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo,
         p.ldk = ldk; p.lddk = lddk; p.ndiag = n > 0 ? n : 0;
         p.lse = lse; p.delta = delta; p.dq_init = dq_init; p.dq_accumulate = lo > 0;
         p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.hd = hd; p.scale = scale;
-        SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_pre_kernel<HD>), grid, dim3(256), 0, stream, p));
+        SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_pre_kernel<HD, chunk>), grid, dim3(256), 0, stream, p));
     }
     return sf_check_launch("sf_attn_bwd_pre");
 }

@@ -265,6 +265,37 @@ extern "C" int sf_gemm_nt_swiglu_fwd(const void* A, long lda, const void* Wgu, l
     return sf_swiglu_fwd(gu, SF_BF16, ldgu, M, I, act, ldact, stream);
 }
 
+// Teacher head: z = A . Wp^T where Wp is the frozen head with its rows permuted draft-sub-vocabulary-first (see
+// sf_teacher_reduce_perm).  When the chip-filling kernel takes the shape and `part` is given, only the first *vz_out =
+// roundup(Vd, 256) columns are stored; every later 128-column block of a row leaves as one {max, sum exp, argmax column, 0} record
+// in `part` (*nparts_out blocks, row-major: block q of row r at part[(r * part_stride + q) * 4]).  Otherwise all Vt columns are stored and *nparts_out = 0.  z must have room for Vt columns.
+extern "C" int sf_gemm_nt_teacher(const void* A, long lda, const void* Wp, long ldw, int M, int Vt, int K, int Vd, void* z, long ldz,
+                                  float* part, long part_stride, int* vz_out, int* nparts_out, void* stream) {
+    if (int st = sf_gemm_check(lda, ldw, ldz, 0, M, Vt, K, SF_BF16, nullptr)) return st;
+    SF_CHECK_ARG(Vd > 0 && Vd <= Vt && ldz >= Vt && vz_out && nparts_out, "sf_gemm_nt_teacher: bad shape / missing outputs");
+    *vz_out = Vt;
+    *nparts_out = 0;
+    if (M == 0) return 0;
+    SfGemmEpi e;
+    e.C = z; e.ldc = ldz; e.R = nullptr; e.ldr = 0;
+    e.Cadd = nullptr; e.ldadd = 0; e.add_S = 1; e.add_Spad = 1; e.add_off = 0;
+    e.M = M; e.N = Vt; e.alpha = 1.f; e.beta = 0.f;
+#ifdef SF_EMU
+    const bool big = K >= 512;
+#else
+    const bool big = (long)((M + 255) / 256) * ((Vt + 255) / 256) >= 256 && K >= 512;
+#endif
+    static const int fuse = sf_knob("SF_GEMM_TEACHER_FUSE", 1);
+    const int vz = (Vd + 255) / 256 * 256;
+    if (fuse && part && big && vz < Vt && K % 64 == 0 && M >= 192 && part_stride >= (Vt - vz + 127) / 128 && ((size_t)part & 15) == 0 && sf_gemm_use_256()) {
+        e.red_part = part; e.red_stride = part_stride; e.red_n0 = vz;
+        *vz_out = vz;
+        *nparts_out = (Vt - vz + 127) / 128;
+        return sf_gemm_nt_256w4_launch(A, lda, Wp, ldw, K, e, SF_BF16, stream);
+    }
+    return sf_gemm_dispatch(A, lda, Wp, ldw, K, e, SF_BF16, stream);
+}
+
 extern "C" int sf_gemm_nt_rowadd(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M,
                                  int N, int K, float alpha, const float* Cadd, long ldadd, int S, int Spad, int off,
                                  void* stream) {

@@ -19,7 +19,9 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     SF_CHECK_ARG(256L * lda * 2 < (1L << 31) && 256L * ldb * 2 < (1L << 31), "sf_gemm_nt: row stride too large for the 256-tile kernel");
     if (p.e.Cadd) SF_CHECK_ARG(p.e.alpha == 1.0f, "sf_gemm_nt_rowadd: the 4-wave kernel needs alpha == 1");
     // (sw_dgu without sw_gu = the SwiGLU-forward form: C = gate|up [M, N = 2I], sw_dgu = act [M, I])
-    const int add = p.e.Cadd ? 1 : (p.e.sw_gu ? 2 : (p.e.sw_dgu ? 3 : 0)), f32 = c_dtype == SF_F32 ? 1 : 0;
+    const int add = p.e.Cadd ? 1 : (p.e.sw_gu ? 2 : (p.e.sw_dgu ? 3 : (p.e.red_part ? 4 : 0))), f32 = c_dtype == SF_F32 ? 1 : 0;
+    SF_CHECK_ARG(add != 4 || (!f32 && p.e.alpha == 1.f && p.e.beta == 0.f && !p.e.R && p.e.red_n0 % TN == 0 && p.e.red_stride >= (N - p.e.red_n0 + 127) / 128),
+                 "sf_gemm_nt_teacher: bf16 logits, alpha 1, reduced range on a tile boundary");
     SF_CHECK_ARG(add != 3 || (!f32 && M % TM == 0 && N % TN == 0 && p.e.alpha == 1.f && p.e.beta == 0.f && !p.e.R &&
                               (p.e.ldc & 7) == 0 && ((size_t)p.e.C & 15) == 0 && (N / 2 + 256L) * ldb * 2 < (1L << 31)),
                  "sf_gemm_nt_swiglu_fwd: the fused form takes whole bf16 tiles only");
@@ -71,6 +73,7 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     SF_W4_CASE(0, 1, 12) SF_W4_CASE(0, 1, 13) SF_W4_CASE(1, 1, 12) SF_W4_CASE(1, 1, 13)
     SF_W4_CASE(0, 2, 12) SF_W4_CASE(0, 2, 13)
     SF_W4_CASE(0, 3, 12) SF_W4_CASE(0, 3, 13)
+    SF_W4_CASE(0, 4, 12) SF_W4_CASE(0, 4, 13)
 #undef SF_W4_CASE
 #undef SF_W4_LOCAL
     SF_CHECK_ARG(false, "sf_gemm_nt(256w4): no kernel for this configuration");

@@ -219,7 +219,8 @@ template <int SCHED> using W4PlanFor = std::conditional_t<SCHED == 13, W4PlanAFi
 // tile, bit1 = no DMA in the loop, ...
 // ADD: 0 = plain, 1 = + fp32 row-mapped addend in the epilogue, before the single bf16 rounding (sf_gemm_nt_rowadd), 2 = d(SwiGLU) in the bf16 epilogue
 // (sf_gemm_nt_swiglu_bwd; whole tiles only -- its launcher guarantees it), 3 = SwiGLU forward in the bf16 epilogue of the fused
-// gate|up projection (sf_gemm_nt_swiglu_fwd; whole tiles only): B = [gate rows ; up rows] of the fused weight, N = 2 I; tile tn takes
+// gate|up projection (sf_gemm_nt_swiglu_fwd; whole tiles only), 4 = teacher head: column tiles from red_n0 on are reduced (row max,
+// sum-exp, argmax per 128-column block) instead of stored (sf_gemm_nt_teacher); 3 in detail: B = [gate rows ; up rows] of the fused weight, N = 2 I; tile tn takes
 // the gate AND the up rows of act columns tn*128 .. +127, interleaved 16 / 16 along its 256 B rows, so that a lane's accumulators
 // [i][2 jj] / [i][2 jj + 1] are gate / up of the SAME 4 columns: gate|up leave in their natural [M, 2I] layout (the backward reads
 // them), act = round(silu(gate)) * up leaves beside them, and the separate pass over gate|up (0.94 GB read per call) is gone
@@ -453,6 +454,79 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     // Interior tiles without beta / residual (every launch of the training step) take a straight path; the general store
     // below re-derives address, bounds and the beta / residual cases per 4 values (~7500 instructions).
     int newer = 0;   // vector-memory instructions this wave issues AFTER the next tile's DMAs (lower bound; 0 = unknown)
+    bool reduced = false;
+    if constexpr (ADD == 4) {
+        // Teacher head (eagle3/model.py:487-501 needs, of the [rows, Vt] logits, the row maximum, its sum-exp, the argmax and the
+        // draft sub-vocabulary's logits): the columns from red_n0 on are only REDUCED.  A lane holds, per 16-row m-tile, 32 logits of
+        // ONE row (8 n-tiles x 4 columns); the 4 lanes of a row (lane >> 4) are merged with two xor steps.  The logits are rounded
+        // to bf16 first: TargetHead is a bf16 module, its argmax near-ties are reference semantics.  The first column wins ties
+        // (the permuted head keeps original order inside this range; across blocks sf_teacher_reduce_perm compares original ids).
+        if (nc >= p.e.red_n0) {
+            reduced = true;
+            const int r = lane & 15, q = lane >> 4;
+            const int cw = nc + wc * 128;                         // first column of this wave's block
+            const int blk = (cw - p.e.red_n0) >> 7;
+            if (cw < p.N) {
+                auto reduce_block = [&](auto EDGE) SF_INLINE_LAMBDA {
+                    constexpr float kLog2e = 1.4426950408889634f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float v[8][4];
+                        float lm = -__builtin_inff();
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float t = sf_round_bf(acc[i][j][e]);
+                                if constexpr (decltype(EDGE)::value) {     // the block reaches past the last column (Vt % 128 != 0)
+                                    if (cw + j * 16 + 4 * q + e >= p.N) t = -__builtin_inff();
+                                }
+                                v[j][e] = t;
+                                lm = fmaxf(lm, t);
+                            }
+                        int lc = 0;
+#pragma unroll
+                        for (int j = 7; j >= 0; --j)
+#pragma unroll
+                            for (int e = 3; e >= 0; --e) lc = (v[j][e] == lm) ? j * 16 + e : lc;
+                        lc += cw + 4 * q;
+                        auto merge = [&](auto MK) SF_INLINE_LAMBDA {   // both lanes of a pair see the same (a, b): same winner
+                            float ma, mb;
+                            int ca, cb;
+                            sf_xor_pair<decltype(MK)::value>(lm, ma, mb);
+                            sf_xor_pair<decltype(MK)::value>(lc, ca, cb);
+                            const bool tb = (mb > ma) | ((mb == ma) & (cb < ca));    // (no short-circuit: branch-free)
+                            lm = tb ? mb : ma;
+                            lc = tb ? cb : ca;
+                        };
+                        merge(std::integral_constant<int, 16>{});
+                        merge(std::integral_constant<int, 32>{});
+                        const float nb = -lm * kLog2e;      // exp(v - max) = exp2(v * log2e - max * log2e): one fma + v_exp_f32
+                        float se = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) se += sf_exp2_raw(__builtin_fmaf(v[j][e], kLog2e, nb));
+                        {
+                            float sa, sb;
+                            sf_xor_pair<16>(se, sa, sb);
+                            se = sa + sb;
+                            sf_xor_pair<32>(se, sa, sb);
+                            se = sa + sb;
+                        }
+                        const int row = mc + wr * 128 + i * 16 + r;
+                        if (q == 0 && row < p.M)
+                            *reinterpret_cast<sf_v4f*>(p.e.red_part + ((long)row * p.e.red_stride + blk) * 4) = sf_v4f{lm, se, (float)lc, 0.f};
+                    }
+                };
+                if (cw + 128 > p.N) reduce_block(std::true_type{});
+                else reduce_block(std::false_type{});
+            }
+            newer = 0;
+        }
+    }
+    if (reduced) {
+    } else
 #ifdef SF_ABLATE
     if ((p.cyc & 4) || ((p.cyc & 8) && (blockIdx.x & 1))) {   // timing experiments: no stores at all / only every other workgroup stores
     } else
@@ -641,3 +715,4 @@ SF_W4_DECLARE(0, 0, 12); SF_W4_DECLARE(0, 0, 13); SF_W4_DECLARE(1, 0, 12); SF_W4
 SF_W4_DECLARE(0, 1, 12); SF_W4_DECLARE(0, 1, 13); SF_W4_DECLARE(1, 1, 12); SF_W4_DECLARE(1, 1, 13);
 SF_W4_DECLARE(0, 2, 12); SF_W4_DECLARE(0, 2, 13);
 SF_W4_DECLARE(0, 3, 12); SF_W4_DECLARE(0, 3, 13);
+SF_W4_DECLARE(0, 4, 12); SF_W4_DECLARE(0, 4, 13);

@@ -20,6 +20,10 @@ struct SfGemmEpi {
     // writes d(gate) / d(up) to dgu [M, 2I].  Null = plain store.
     const sf_bf16* sw_gu = nullptr; long sw_ldgu = 0;
     sf_bf16* sw_dgu = nullptr; long sw_lddgu = 0;
+    // teacher-head form (4-wave kernel, sf_gemm_nt_teacher): tiles whose first column is >= red_n0 are REDUCED instead of
+    // stored -- per row and 128-column block {max, sum exp(z - max), argmax column, 0} of the bf16-rounded logits goes to
+    // red_part[(row * red_stride + block) * 4], block = (column - red_n0) / 128.  Null = plain store everywhere.
+    float* red_part = nullptr; long red_stride = 0; int red_n0 = 0;
 };
 
 // ADD = 0 compiles the addend out (the 4-wave kernel's register allocation is sensitive to epilogue code, so its

@@ -434,6 +434,164 @@ teacher_reduce_kernel(const T* z, long ldz, int Vt, int Vd, const long long* d2t
     }
 }
 
+// The same reduction over a row whose columns are PERMUTED so that the draft sub-vocabulary comes first, in draft order:
+// column c of z is target-vocabulary entry perm[c]; perm[j] = j + d2t[j] for j < Vd, the remaining entries follow in ascending
+// order (the host permutes the rows of the frozen teacher head once, so the head GEMM writes this layout for free).  What it
+// buys: the draft softmax reads Vd CONTIGUOUS logits (the natural layout gathers them through d2t: two dependent loads per
+// element over a 256 KiB row, which kept the launch at 2.8 TB/s), and the streaming pass needs no t2d mask words.  Same results:
+// the argmax is taken in original indices (lowest original index among equal maxima, as torch.argmax).
+// `part` (optional): the row's columns from Vz on are not in z -- they arrive as per-block partials written by the head GEMM's
+// reduction epilogue (sf_gemm_nt_teacher): part[r * part_stride + blk] = {max, sum exp(z - max), argmax column (permuted), 0}.
+template <typename T>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2)
+teacher_reduce_perm_kernel(const T* z, long ldz, int Vz, int Vd, const int* perm, const unsigned char* t2d, const sf_v4f* part,
+                           int nparts, long part_stride, const int* loss_mask_pad, int S, int Spad, float* target_p_pad,
+                           float* pod_scale_pad, float* tsum_pad, long long* ids_pad, int* pos_mask_pad) {
+    SF_SHARED float red[40];
+    SF_SHARED int redi[16];
+    const int r = (int)blockIdx.x;
+    const int b = r / S, s = r - b * S;
+    const long pr = (long)b * Spad + s;
+    const T* x = z + (long)r * ldz;
+    const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+    const int V8 = Vz >> 3, D8 = Vd >> 3;
+    // (m, d): online max / sum-exp over the row; dd: the sum-exp of the DRAFT columns relative to the same running maximum (the
+    // terms are shared, so the draft pair costs no exponentials); md: the draft maximum (max only) -- the softmax reference
+    float m = SF_NEG_BIG, d = 0.f, dd = 0.f, md = SF_NEG_BIG;
+    ArgMax am{SF_NEG_BIG, 0x7fffffff};
+    auto chunk = [&](int c, const SfRaw8<T>& raw) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = raw.at(i);
+        float cm = v[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) cm = fmaxf(cm, v[i]);
+        if (cm >= am.v) {   // rare after the first chunks: a new maximum, or a tie to be settled by the original index
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (v[i] == cm) {
+                    const int o = perm[c * 8 + i];
+                    if (cm > am.v || o < am.i) { am.v = cm; am.i = o; }
+                }
+        }
+        if (cm > m) {       // (rare too) the running maximum moves: rescale both sums
+            const float f = (m == SF_NEG_BIG) ? 0.f : sf_exp_fast(m - cm);
+            d *= f;
+            dd *= f;
+            m = cm;
+        }
+        float s8 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s8 += sf_exp_fast(v[i] - m);
+        d += s8;
+        if (c < D8) {
+            dd += s8;
+            md = fmaxf(md, cm);
+        }
+    };
+    constexpr int PU = 4;
+    int c = tid;
+    for (; c + (PU - 1) * nt < V8; c += PU * nt) {
+        SfRaw8<T> raw[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) raw[u].ld(x + (c + u * nt) * 8);
+#pragma unroll
+        for (int u = 0; u < PU; ++u) chunk(c + u * nt, raw[u]);
+    }
+    for (; c < V8; c += nt) {
+        SfRaw8<T> raw;
+        raw.ld(x + c * 8);
+        chunk(c, raw);
+    }
+    auto merge3 = [&](float m2, float d2, float dd2) {   // (m, d, dd) <- merged with another partial on the common maximum
+        const float mn = fmaxf(m, m2);
+        const float fa = (m == SF_NEG_BIG) ? 0.f : sf_exp(m - mn), fb = (m2 == SF_NEG_BIG) ? 0.f : sf_exp(m2 - mn);
+        d = d * fa + d2 * fb;
+        dd = dd * fa + dd2 * fb;
+        m = mn;
+    };
+    for (int j = V8 * 8 + tid; j < Vz; j += nt) {   // (Vz % 8 != 0: never a draft column, Vd % 8 == 0 <= V8 * 8)
+        const float v = SfElem<T>::ld(x + j);
+        const int o = perm[j];
+        if (v > am.v || (v == am.v && o < am.i)) { am.v = v; am.i = o; }
+        merge3(v, 1.f, 0.f);
+    }
+    for (int q = tid; q < nparts; q += nt) {        // column blocks that exist only as the head GEMM's partials
+        const sf_v4f pp = part[(long)r * part_stride + q];
+        const int o = perm[(int)pp[2]];
+        if (pp[0] > am.v || (pp[0] == am.v && o < am.i)) { am.v = pp[0]; am.i = o; }
+        merge3(pp[0], pp[1], 0.f);
+    }
+    for (int k = 32; k >= 1; k >>= 1) {
+        const float m2 = sf_shfl_xor(m, k), d2 = sf_shfl_xor(d, k), dd2 = sf_shfl_xor(dd, k);
+        merge3(m2, d2, dd2);
+        md = fmaxf(md, sf_shfl_xor(md, k));
+    }
+    am = am_wave(am);
+    const int w = tid >> 6, nw = nt >> 6;
+    if (sf_lane() == 0) { red[w] = m; red[8 + w] = d; red[16 + w] = am.v; redi[w] = am.i; red[24 + w] = md; red[32 + w] = dd; }
+    sf_syncthreads();
+    m = red[0]; d = red[8]; dd = red[32];
+    am.v = red[16]; am.i = redi[0];
+    md = red[24];
+    for (int i = 1; i < nw; ++i) {
+        merge3(red[i], red[8 + i], red[32 + i]);
+        am = am_pick(am, ArgMax{red[16 + i], redi[i]});
+        md = fmaxf(md, red[24 + i]);
+    }
+    const float lse_full = m + sf_log(d);
+    sf_syncthreads();
+    // sum exp(z_draft - md) = dd * exp(m - md); when the draft maximum lies so far below the row's that the shared terms lost
+    // their precision (never with real logits), the sum is taken again relative to md (block-uniform branch)
+    float sd;
+    if (m - md < 60.f) {
+        sd = dd * sf_exp(m - md);
+    } else {
+        float t = 0.f;
+        for (int j = tid; j < D8; j += nt) {
+            SfRaw8<T> raw;
+            raw.ld(x + j * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t += sf_exp_fast(raw.at(i) - md);
+        }
+        sd = sf_block_sum(t, red);
+        sf_syncthreads();
+    }
+    const float inv = 1.0f / sd;
+    // draft softmax (torch.softmax: exp(x - max) / sum): Vd contiguous logits, still in L2 from the pass above
+    float* tp = target_p_pad + pr * (long)Vd;
+    float ts = 0.f;
+    constexpr int GU = 2;
+    int j = tid;
+    for (; j + (GU - 1) * nt < D8; j += GU * nt) {
+        SfRaw8<T> raw[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) raw[u].ld(x + (j + u * nt) * 8);
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            float pv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { pv[i] = sf_exp_fast(raw[u].at(i) - md) * inv; ts += pv[i]; }
+            SfVec8<float>::st(tp + (j + u * nt) * 8, pv);
+        }
+    }
+    for (; j < D8; j += nt) {
+        SfRaw8<T> raw;
+        raw.ld(x + j * 8);
+        float pv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { pv[i] = sf_exp_fast(raw.at(i) - md) * inv; ts += pv[i]; }
+        SfVec8<float>::st(tp + j * 8, pv);
+    }
+    ts = sf_block_sum(ts, red);
+    if (tid == 0) {
+        pod_scale_pad[pr] = sd * sf_exp(md - lse_full);
+        tsum_pad[pr] = ts;
+        ids_pad[pr] = (long long)am.i;
+        pos_mask_pad[pr] = (t2d[am.i] ? 1 : 0) * loss_mask_pad[pr];
+    }
+}
+
 }  // namespace
 
 extern "C" int sf_ce_fused(void* logits, int dtype, long ld, int rows, int V, const float* target, int S, int Spad,
@@ -500,4 +658,24 @@ extern "C" int sf_teacher_reduce(const void* z, int dtype, long ldz, int rows, i
     else
         SF_CHECK_ARG(false, "sf_teacher_reduce: dtype");
     return sf_check_launch("sf_teacher_reduce");
+}
+
+extern "C" int sf_teacher_reduce_perm(const void* z, int dtype, long ldz, int rows, int Vz, int Vt, int Vd, const int* perm,
+                                      const unsigned char* t2d, const float* part, int nparts, long part_stride,
+                                      const int* loss_mask_pad, int S, int Spad, float* target_p_pad, float* pod_scale_pad,
+                                      float* tsum_pad, long long* ids_pad, int* pos_mask_pad, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && Vt > 0 && Vd > 0 && Vd % 8 == 0 && Vz >= Vd && Vz <= Vt && S > 0 && Spad >= S, "sf_teacher_reduce_perm: bad shape");
+    SF_CHECK_ARG(ldz % 8 == 0 && perm && t2d, "sf_teacher_reduce_perm: ldz must be a multiple of 8; perm / t2d required");
+    SF_CHECK_ARG(nparts >= 0 && (nparts == 0 || (part && part_stride >= nparts && ((size_t)part & 15) == 0)), "sf_teacher_reduce_perm: bad partials");
+    SF_CHECK_ARG(nparts > 0 || Vz == Vt, "sf_teacher_reduce_perm: columns past Vz need partials");
+    if (rows == 0) return 0;
+    if (dtype == SF_BF16)
+        SF_LAUNCH((teacher_reduce_perm_kernel<sf_bf16>), dim3(rows), dim3(256), 0, stream, (const sf_bf16*)z, ldz, Vz, Vd, perm, t2d,
+                  (const sf_v4f*)part, nparts, part_stride, loss_mask_pad, S, Spad, target_p_pad, pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad);
+    else if (dtype == SF_F32)
+        SF_LAUNCH((teacher_reduce_perm_kernel<float>), dim3(rows), dim3(256), 0, stream, (const float*)z, ldz, Vz, Vd, perm, t2d,
+                  (const sf_v4f*)part, nparts, part_stride, loss_mask_pad, S, Spad, target_p_pad, pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad);
+    else
+        SF_CHECK_ARG(false, "sf_teacher_reduce_perm: dtype");
+    return sf_check_launch("sf_teacher_reduce_perm");
 }

@@ -89,6 +89,18 @@ template <typename T> SF_DEVICE void sf_pin(T&) {}
 SF_DEVICE float sf_pair_max(float v) { return fmaxf(v, sfemu::shfl_xor(v, 32)); }
 SF_DEVICE float sf_pair_sum(float v) { return v + sfemu::shfl_xor(v, 32); }
 SF_DEVICE int sf_wave_id() { return sfemu::wave_index(); }
+template <int MASK> SF_DEVICE void sf_xor_pair(float x, float& a, float& b) {
+    const float o = sfemu::shfl_xor(x, MASK);
+    const bool up = (sfemu::lane_id() & MASK) != 0;
+    a = up ? o : x;
+    b = up ? x : o;
+}
+template <int MASK> SF_DEVICE void sf_xor_pair(int x, int& a, int& b) {
+    const int o = sfemu::shfl_xor(x, MASK);
+    const bool up = (sfemu::lane_id() & MASK) != 0;
+    a = up ? o : x;
+    b = up ? x : o;
+}
 SF_DEVICE sf_v4s sf_ds_read_tr16(const void* l) { return sfemu::ds_read_tr16_b64(l); }
 SF_DEVICE bool sf_all(bool pred) {
     int v = pred ? 1 : 0;
@@ -171,6 +183,24 @@ SF_DEVICE sf_v16f sf_mfma32(sf_v8s a, sf_v8s b, sf_v16f c) {
 // (first ACTIVE lane != lane 0) -- observed on gfx950 when a select between two source
 // pointers was lowered to two exec-masked loads.
 SF_DEVICE int sf_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+// (a, b) = (x of the lane with bit MASK clear, x of the lane with it set) of the lane pair {l, l ^ MASK}, MASK = 16 or 32: the SAME
+// ordered pair on both lanes.  gfx950's v_permlane16_swap / v_permlane32_swap exchange 16-lane rows / wave halves between two
+// registers in the VALU -- no LDS crossbar round trip (ds_bpermute + lgkmcnt wait: ~100 cycles each in a one-wave-per-SIMD epilogue).
+template <int MASK> SF_DEVICE void sf_xor_pair(float x, float& a, float& b) {
+    static_assert(MASK == 16 || MASK == 32, "row / half exchanges only");
+    // inline asm, not __builtin_amdgcn_permlane{16,32}_swap: hipcc (ROCm 7.2) treats the two float results of the builtin as equal
+    // when both operands are one value and folds every comparison between them (reproduced in a ten-line kernel: the swaps stay in
+    // the ISA, their second result is dead).  s_nop 1: the VALU-write -> permlane-swap hazard the compiler would have padded.
+    a = x;
+    b = x;
+    if constexpr (MASK == 32) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+template <int MASK> SF_DEVICE void sf_xor_pair(int x, int& a, int& b) {
+    float fa, fb;
+    sf_xor_pair<MASK>(__builtin_bit_cast(float, x), fa, fb);
+    a = __builtin_bit_cast(int, fa); b = __builtin_bit_cast(int, fb);
+}
 SF_DEVICE bool sf_all(bool pred) { return __all(pred ? 1 : 0) != 0; }
 // ds_read_b64_tr_b16: per 16-lane group, lane i passes the address of 8-byte piece i of a 4x16 bf16 block
 // (piece i = row i/4, columns 4*(i%4)..+3; any row stride) and receives column i (rows 0..3).  Verified on

@@ -276,6 +276,28 @@ class Eagle3Engine:
         N, hd = src.shape[0], self.cfg.head_dim
         dst.unflatten(1, (n, hd)).copy_(src.view(N, n, self.hdp)[:, :, :hd])
 
+    def _permuted_teacher_head(self, w: torch.Tensor):
+        """(perm, W[perm], ascending?): the frozen teacher head with its ROWS reordered so that the logits of the draft sub-vocabulary come
+        out of the head GEMM first and contiguous (perm[j] = j + d2t[j], then every other vocabulary entry in ascending order).
+        Built once per head weight (a 1 GB copy at Llama-3 dims: nothing against 288 GB) -- the target model is frozen
+        (target_head.py:60-66).  (None, w, False) when the vocabulary mapping is not a clean injection (then the natural layout is used)."""
+        key = (w.data_ptr(), tuple(w.shape), w._version, self.model.d2t._version, self.model.t2d._version)
+        if getattr(self, "_thead_key", None) != key:
+            Vt, Vd = w.shape[0], self.cfg.draft_vocab_size
+            cols = torch.arange(Vd, device=self.dev) + self.model.d2t.to(self.dev)
+            t2d = self.model.t2d.to(self.dev).bool()
+            ok = (Vd % 8 == 0 and Vt < (1 << 24) and t2d.numel() == Vt and int(cols.min()) >= 0 and int(cols.max()) < Vt
+                  and int(t2d.sum()) == Vd and bool(t2d[cols].all()) and int(torch.unique(cols).numel()) == Vd)
+            if ok:
+                rest = torch.nonzero(~t2d).flatten()
+                perm = torch.cat([cols, rest])
+                ordered = Vd < 2 or bool((cols[1:] > cols[:-1]).all())      # (`rest` is ascending by construction)
+                self._thead = (perm.to(torch.int32).contiguous(), w.index_select(0, perm).contiguous(), ordered)
+            else:
+                self._thead = (None, w, False)
+            self._thead_key = key
+        return self._thead
+
     def _refresh_weight_transposes(self):
         """W^T images for the dgrad GEMMs (NT form); rebuilt only after an optimizer step."""
         if self._wt_version == self.weights_version:
@@ -363,14 +385,22 @@ class Eagle3Engine:
             Vt = target_head_weight.shape[0]
             cb = max(1, self.teacher_rows // S)
             zbuf = self._carve("teacher_z", min(cb, B) * S, Vt, invalidate=False)   # scratch: no cached view aliases it
+            perm, head, ordered = self._permuted_teacher_head(target_head_weight)
+            # per-block partials of the columns the head GEMM reduces instead of storing (only when ties inside a block resolve
+            # to the lowest ORIGINAL index by column order alone, i.e. the mapping is ascending)
+            part = self._carve("teacher_part", min(cb, B) * S, (Vt - Vd + 127) // 128, 4, dtype=torch.float32, invalidate=False) if ordered else None
             for b0 in range(0, B, cb):
                 nb = min(cb, B - b0)
                 z = zbuf[: nb * S]
-                ops.gemm_nt(th[b0:b0 + nb].reshape(nb * S, Ht), target_head_weight, z)
-                ops.teacher_reduce(z, Vd=Vd, d2t=self._d2t, t2d_u8=self._t2d_u8, loss_mask_pad=b["lm"][b0:b0 + nb], S=S,
-                                   Spad=Spad, target_p_pad=b["tp"][b0:b0 + nb], pod_scale_pad=b["pod"][b0:b0 + nb],
-                                   tsum_pad=b["tsum"][b0:b0 + nb], ids_pad=b["tids"][b0:b0 + nb],
-                                   pos_mask_pad=b["pm"][b0:b0 + nb])
+                out = dict(loss_mask_pad=b["lm"][b0:b0 + nb], S=S, Spad=Spad, target_p_pad=b["tp"][b0:b0 + nb],
+                           pod_scale_pad=b["pod"][b0:b0 + nb], tsum_pad=b["tsum"][b0:b0 + nb], ids_pad=b["tids"][b0:b0 + nb],
+                           pos_mask_pad=b["pm"][b0:b0 + nb])
+                if perm is not None:     # columns of z: the draft sub-vocabulary first, in draft order
+                    vz, nparts = ops.gemm_nt_teacher(th[b0:b0 + nb].reshape(nb * S, Ht), head, z, part, Vd=Vd)
+                    ops.teacher_reduce_perm(z[:, :vz], Vt=Vt, Vd=Vd, perm=perm, t2d_u8=self._t2d_u8, part=part, nparts=nparts, **out)
+                else:
+                    ops.gemm_nt(th[b0:b0 + nb].reshape(nb * S, Ht), head, z)
+                    ops.teacher_reduce(z, Vd=Vd, d2t=self._d2t, t2d_u8=self._t2d_u8, **out)
 
         # ---- fc (optionally 3x RMSNorm first): llama3_eagle.py:1762-1770
         if c.fc_norm:

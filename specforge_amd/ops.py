@@ -132,6 +132,42 @@ def teacher_reduce(z: torch.Tensor, *, Vd: int, d2t, t2d_u8, loss_mask_pad, S: i
                                    _p(pos_mask_pad), _stream()), "sf_teacher_reduce")
 
 
+def gemm_nt_teacher(a: torch.Tensor, w_perm: torch.Tensor, z: torch.Tensor, part: Optional[torch.Tensor], *, Vd: int):
+    """z = a @ w_perm.T for the row-permuted teacher head.  Returns (Vz, nparts): the first Vz columns of z were stored, the
+    rest left as ``nparts`` per-128-column-block partials in ``part`` [>= rows, part_stride >= nparts, 4] (nparts = 0: all stored)."""
+    import ctypes
+    L = _lib.lib()
+    M, K = a.shape
+    Vt = w_perm.shape[0]
+    assert z.shape[0] >= M and z.shape[1] >= Vt and a.dtype == w_perm.dtype == z.dtype == torch.bfloat16
+    stride = 0
+    if part is not None:
+        assert part.dtype == torch.float32 and part.dim() == 3 and part.shape[2] == 4 and part.is_contiguous()
+        assert part.shape[0] >= M and part.shape[1] >= (Vt - Vd + 127) // 128
+        stride = part.shape[1]
+    vz, npart = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(L.sf_gemm_nt_teacher(_p(a), _rowmajor(a), _p(w_perm), _rowmajor(w_perm), M, Vt, K, Vd, _p(z), _rowmajor(z), _p(part),
+                                    stride, ctypes.byref(vz), ctypes.byref(npart), _stream()), "sf_gemm_nt_teacher")
+    return vz.value, npart.value
+
+
+def teacher_reduce_perm(z: torch.Tensor, *, Vt: int, Vd: int, perm, t2d_u8, loss_mask_pad, S: int, Spad: int, target_p_pad,
+                        pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad, part=None, nparts: int = 0):
+    """teacher_reduce for logits with permuted columns (draft sub-vocabulary first; column c = vocabulary entry perm[c]).
+    ``part`` [>= rows, part_stride, 4] fp32, ``nparts`` blocks per row in use: per-column-block partials of the columns z does not hold
+    (sf_gemm_nt_teacher)."""
+    L = _lib.lib()
+    rows, Vz = z.shape
+    assert perm.dtype == torch.int32 and perm.numel() == Vt
+    part_stride = 0
+    if nparts:
+        assert part is not None and part.shape[0] >= rows and part.shape[1] >= nparts and part.is_contiguous()
+        part_stride = part.shape[1]
+    _lib.check(L.sf_teacher_reduce_perm(_p(z), _dt(z), _rowmajor(z), rows, Vz, Vt, Vd, _p(perm), _p(t2d_u8), _p(part) if nparts else None, nparts,
+                                        part_stride, _p(loss_mask_pad), S, Spad, _p(target_p_pad), _p(pod_scale_pad),
+                                        _p(tsum_pad), _p(ids_pad), _p(pos_mask_pad), _stream()), "sf_teacher_reduce_perm")
+
+
 def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, y: torch.Tensor, rstd: Optional[torch.Tensor], *,
                 ids_pad=None, S: int = 1, Spad: int = 1, off: int = 0, rows: Optional[int] = None):
     L = _lib.lib()

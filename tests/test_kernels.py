@@ -300,6 +300,98 @@ def test_teacher_reduce(backend, dtype, Vt, Vd):
     assert float((tp_pad.cpu()[:, S:] - 1.0 / Vd).abs().max()) == 0    # padded tail untouched
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Vt,Vd", [(640, 64), (1000, 96), (2056, 512)])
+def test_teacher_reduce_perm(backend, dtype, Vt, Vd):
+    """logits with permuted columns (draft sub-vocabulary first): the same targets as the reference's _compute_target_p on the
+    natural layout; ties in the argmax -- inside the draft block, inside the rest, across the two -- go to the lowest ORIGINAL index"""
+    B, S, T = 2, 12, 3
+    Spad = S + T
+    g = torch.Generator().manual_seed(13)
+    z = (torch.randn(B * S, Vt, generator=g) * 3).to(dtype)
+    t2d, d2t = O.make_vocab_mapping(Vt, Vd, seed=2)
+    cols = torch.arange(Vd) + d2t
+    rest = torch.nonzero(~t2d.bool()).flatten()
+    top = lambda r: z[r].float().max().to(dtype) + 1
+    z[2, rest[5]] = z[2, cols[3]] = top(2)                   # across the two blocks
+    z[3, rest[1]] = z[3, rest[40]] = top(3)                  # inside the rest
+    z[4, cols[7]] = z[4, cols[2]] = top(4)                   # inside the draft block
+    z[5, cols[Vd - 1]] = z[5, rest[0]] = top(5)
+    z[6, cols] -= 200                                        # every draft logit far below the row maximum: the exact-sum branch
+    loss_mask = (torch.rand(B, S, generator=g) > 0.2).long()
+    tp, tpod, ids, pm = O.compute_target_p(z.view(B, S, Vt), t2d, loss_mask[..., None])
+    perm = torch.cat([cols, rest])
+    zp = z[:, perm].contiguous()
+    d = lambda t: t.to(backend)
+    lm_pad = torch.zeros(B, Spad, dtype=torch.int32)
+    lm_pad[:, :S] = loss_mask.int()
+    tp_pad = torch.full((B, Spad, Vd), 1.0 / Vd, device=backend)
+    pod = torch.zeros(B, Spad, device=backend)
+    tsum = torch.zeros(B, Spad, device=backend)
+    ids_pad = torch.zeros(B, Spad, dtype=torch.int64, device=backend)
+    pm_pad = torch.zeros(B, Spad, dtype=torch.int32, device=backend)
+    ops.teacher_reduce_perm(d(zp), Vt=Vt, Vd=Vd, perm=d(perm.to(torch.int32)), t2d_u8=d(t2d.to(torch.uint8)), loss_mask_pad=d(lm_pad),
+                            S=S, Spad=Spad, target_p_pad=tp_pad, pod_scale_pad=pod, tsum_pad=tsum, ids_pad=ids_pad, pos_mask_pad=pm_pad)
+    assert torch.equal(ids_pad.cpu()[:, :S], ids)                       # bit-exact
+    assert torch.equal(pm_pad.cpu()[:, :S, None], pm.int())            # bit-exact
+    torch.testing.assert_close(tp_pad.cpu()[:, :S], tp, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(tp_pad.cpu()[:, :S] * pod.cpu()[:, :S, None], tpod, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(tsum.cpu()[:, :S], tp.sum(-1), rtol=1e-5, atol=1e-6)
+    assert float((tp_pad.cpu()[:, S:] - 1.0 / Vd).abs().max()) == 0    # padded tail untouched
+
+
+@pytest.mark.parametrize("M,Vt,Vd,K", [(512, 1000, 256, 512),     # reduced range 256 .. 999: 6 blocks, the last one partly past Vt
+                                       (300, 1408, 200, 576),     # ragged rows, Vd not a multiple of 256, Vt a multiple of 128 only
+                                       (256, 512, 512, 512)])     # Vz == Vt: nothing to reduce, everything stored
+def test_gemm_nt_teacher_matches_the_stored_logits(backend, M, Vt, Vd, K):
+    """the head GEMM with the reduction epilogue + teacher_reduce_perm over (stored draft columns, partials) == the same GEMM
+    storing every logit + teacher_reduce_perm over the full rows: ids / position mask bit-exact, probabilities to fp32 rounding"""
+    B, S, T = 1, M, 2
+    Spad = S + T
+    g = torch.Generator().manual_seed(17)
+    x = _rand((M, K), torch.bfloat16, 1)
+    w = (_rand((Vt, K), torch.bfloat16, 2) * 0.25).to(torch.bfloat16)
+    t2d, d2t = O.make_vocab_mapping(Vt, Vd, seed=3)
+    cols = torch.arange(Vd) + d2t
+    perm = torch.cat([cols, torch.nonzero(~t2d.bool()).flatten()])
+    wp = w[perm].contiguous()
+    if Vd + 300 < Vt:     # two identical, dominant columns in different reduced blocks: a tie for the argmax on about half the rows
+        wp[Vd + 40] = (wp[Vd + 40].float() * 3).to(torch.bfloat16)
+        wp[Vd + 300] = wp[Vd + 40]
+    d = lambda t: t.to(backend)
+    lm_pad = torch.ones(B, Spad, dtype=torch.int32)
+    res = []
+    for fused in (False, True):
+        z = torch.full((M, Vt), 9.0, dtype=torch.bfloat16, device=backend)
+        part = torch.full((M + 3, (Vt - Vd + 127) // 128 + 2, 4), -7.0, device=backend) if fused else None
+        vz, nparts = ops.gemm_nt_teacher(d(x), d(wp), z, part, Vd=Vd)
+        if nparts:        # (a GPU takes the reduction epilogue for chip-filling shapes only; the interpreter for every long-K shape)
+            assert fused and vz == (Vd + 255) // 256 * 256 and nparts == (Vt - vz + 127) // 128
+            assert float((z[:, vz:].float() - 9.0).abs().max()) == 0.0          # the reduced columns are never written
+        else:
+            assert vz == Vt
+        if backend == "cpu":   # (= the interpreter)
+            assert bool(nparts) == (fused and Vt > (Vd + 255) // 256 * 256)
+        o = dict(target_p_pad=torch.zeros(B, Spad, Vd, device=backend), pod_scale_pad=torch.zeros(B, Spad, device=backend),
+                 tsum_pad=torch.zeros(B, Spad, device=backend), ids_pad=torch.zeros(B, Spad, dtype=torch.int64, device=backend),
+                 pos_mask_pad=torch.zeros(B, Spad, dtype=torch.int32, device=backend))
+        ops.teacher_reduce_perm(z[:, :vz], Vt=Vt, Vd=Vd, perm=d(perm.to(torch.int32)), t2d_u8=d(t2d.to(torch.uint8)), loss_mask_pad=d(lm_pad),
+                                S=S, Spad=Spad, part=part, nparts=nparts, **o)
+        res.append({k: v.cpu() for k, v in o.items()})
+    a, f = res
+    assert torch.equal(a["ids_pad"], f["ids_pad"]) and torch.equal(a["pos_mask_pad"], f["pos_mask_pad"])
+    torch.testing.assert_close(f["target_p_pad"], a["target_p_pad"], rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(f["pod_scale_pad"], a["pod_scale_pad"], rtol=1e-4, atol=1e-8)
+    # ... and against the reference restatement on the natural layout (logits rounded to bf16 as TargetHead does)
+    zn = (x.float() @ w.float().t())
+    zn_p = (x.float() @ wp.float().t()).to(torch.bfloat16)
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(Vt)
+    tp, tpod, ids, pm = O.compute_target_p(zn_p[:, inv].view(B, S, Vt), t2d, lm_pad[:, :S, None].long())
+    same = float((f["ids_pad"][:, :S] == ids).float().mean())
+    assert same >= 0.99, same                                                    # (accumulation-order near-ties of the bf16 rounding)
+    del zn
+
+
 # ------------------------------------------------------------------ RMSNorm
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("R,H", [(20, 128), (33, 896), (19, 4096), (5, 7168)])   # 1 / 1 / 2 / 4 vectors per thread

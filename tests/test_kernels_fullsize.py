@@ -122,6 +122,46 @@ def test_gemm_nt_swiglu_fwd_headline_shape():
     assert all(torch.equal(o, act) for o in runs)          # run-to-run bit-identical
 
 
+def test_gemm_nt_teacher_headline_chunk():
+    """the teacher chunk of the headline step (4096 x 128256 x 4096, Vd 32000): the head GEMM with the reduction epilogue (draft
+    columns stored, 752 column blocks reduced) + teacher_reduce_perm vs the same GEMM storing every logit"""
+    from oracle import eagle3_oracle as O
+    M, Vt, Vd, K, S, T = 4096, 128256, 32000, 4096, 2048, 7
+    B, Spad = M // S, S + T
+    x, w = _randn((M, K), 1), _randn((Vt, K), 2, scale=4.0 / math.sqrt(K))
+    t2d, d2t = O.make_vocab_mapping(Vt, Vd, seed=1)
+    t2d, d2t = t2d.to(DEV), d2t.to(DEV)
+    perm = torch.cat([torch.arange(Vd, device=DEV) + d2t, torch.nonzero(~t2d).flatten()])
+    wp = w[perm].contiguous()
+    wp[Vd + 5000] = wp[Vd + 77]                      # identical columns in different reduced blocks
+    lm = torch.ones(B, Spad, dtype=torch.int32, device=DEV)
+    res = []
+    for fused in (False, True):
+        z = torch.full((M, Vt), 9.0, dtype=torch.bfloat16, device=DEV)
+        part = torch.empty((M, (Vt - Vd + 127) // 128, 4), device=DEV) if fused else None
+        vz, nparts = ops.gemm_nt_teacher(x, wp, z, part, Vd=Vd)
+        assert (vz, nparts) == ((32000, 752) if fused else (Vt, 0))
+        if fused:
+            assert float((z[:, vz:].float() - 9.0).abs().max()) == 0.0
+        o = dict(target_p_pad=torch.zeros(B, Spad, Vd, device=DEV), pod_scale_pad=torch.zeros(B, Spad, device=DEV),
+                 tsum_pad=torch.zeros(B, Spad, device=DEV), ids_pad=torch.zeros(B, Spad, dtype=torch.int64, device=DEV),
+                 pos_mask_pad=torch.zeros(B, Spad, dtype=torch.int32, device=DEV))
+        ops.teacher_reduce_perm(z[:, :vz], Vt=Vt, Vd=Vd, perm=perm.to(torch.int32), t2d_u8=t2d.to(torch.uint8), loss_mask_pad=lm, S=S,
+                                Spad=Spad, part=part, nparts=nparts, **o)
+        res.append(o)
+        if not fused:     # the stored logits against fp32 torch, and the ids against torch.argmax on the natural layout
+            inv = torch.empty_like(perm); inv[perm] = torch.arange(Vt, device=DEV)
+            want = torch.empty(M, dtype=torch.int64, device=DEV)
+            for m0 in range(0, M, 1024):
+                want[m0:m0 + 1024] = z[m0:m0 + 1024][:, inv].float().argmax(dim=-1)
+            assert torch.equal(o["ids_pad"][:, :S].reshape(-1), want)
+    a, f = res
+    assert torch.equal(a["ids_pad"], f["ids_pad"]) and torch.equal(a["pos_mask_pad"], f["pos_mask_pad"])
+    torch.testing.assert_close(f["target_p_pad"], a["target_p_pad"], rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(f["pod_scale_pad"], a["pod_scale_pad"], rtol=2e-5, atol=1e-9)
+    torch.testing.assert_close(f["tsum_pad"], a["tsum_pad"], rtol=1e-6, atol=0)
+
+
 def test_gemm_nt_rowadd_headline_shape():
     M, N, K, S, T = 16384, 6144, 4096, 2048, 7
     B, Spad = M // S, S + T
