@@ -64,6 +64,8 @@ class KernelTimer:
             "gemm_nt": ("gemm_nt", lambda a, k: 2.0 * a[0].shape[0] * a[1].shape[0] * a[0].shape[1]),
             "gemm_nt_swiglu_bwd": ("gemm_nt_swiglu_bwd", lambda a, k: 2.0 * a[0].shape[0] * a[1].shape[0] * a[0].shape[1]),
             "gemm_nt_rowadd": ("gemm_nt_rowadd", lambda a, k: 2.0 * a[0].shape[0] * a[1].shape[0] * a[0].shape[1]),
+            "gemm_nt_swiglu_fwd": ("gemm_nt_swiglu_fwd", lambda a, k: 2.0 * a[0].shape[0] * a[1].shape[0] * a[0].shape[1]),
+            "gemm_nt_teacher": ("gemm_nt_teacher", lambda a, k: 2.0 * a[0].shape[0] * a[1].shape[0] * a[0].shape[1]),
             "gemm_tn": ("gemm_tn", lambda a, k: 2.0 * a[0].shape[1] * a[1].shape[1] * a[0].shape[0]),
             # attention: matmuls of B*nh*hd*S^2/2 MACs each: forward 2, dQ 3, dK/dV 4 (each product once)
             "attn_fwd": ("attn_fwd", lambda a, k: 4.0 * self._attn_units(k)),
@@ -78,6 +80,9 @@ class KernelTimer:
             "adamw_step": ("adamw_step", lambda a, k: 28.0 * a[0].numel()),
             #   teacher reduce: one bf16 read of the logits chunk + target_p fp32 write
             "teacher_reduce": ("teacher_reduce", lambda a, k: el(a[0]) + 4.0 * a[0].shape[0] * k["Vd"]),
+            #   ... on the permuted head: the stored (draft) logits + 16 B per reduced 128-column block + the probabilities
+            "teacher_reduce_perm": ("teacher_reduce_perm", lambda a, k: 2.0 * a[0].numel() + 16.0 * a[0].shape[0] * k.get("nparts", 0)
+                                    + 4.0 * a[0].shape[0] * k["Vd"]),
         }
         for name, (attr, work) in fam.items():
             orig = getattr(ops, attr)
@@ -321,6 +326,9 @@ def main():
         kernels = {
             "gemm_nt_swiglu_bwd": kern("gemm_nt_swiglu_bwd", "TFLOP/s", PEAK_BF16_TFLOPS, what="2MNK; d(SwiGLU) in the epilogue"),
             "gemm_nt_rowadd": kern("gemm_nt_rowadd", "TFLOP/s", PEAK_BF16_TFLOPS, what="2MNK; fp32 row addend (hoisted embedding half of QKV)"),
+            "gemm_nt_swiglu_fwd": kern("gemm_nt_swiglu_fwd", "TFLOP/s", PEAK_BF16_TFLOPS, what="2MNK, N = 2I; SwiGLU forward in the epilogue (gate|up and act stored)"),
+            "gemm_nt_teacher": kern("gemm_nt_teacher", "TFLOP/s", PEAK_BF16_TFLOPS,
+                                    what="2MNK, N = Vt; columns past the draft sub-vocabulary reduced in the epilogue (max / sum-exp / argmax per 128-column block), not stored"),
             "gemm_tn": kern("gemm_tn", "TFLOP/s", PEAK_BF16_TFLOPS, what="2MNK, K = T*N token rows (deferred weight gradients; split-K reduce included)"),
             "attn_fwd": kern("attn_fwd", "TFLOP/s", PEAK_BF16_TFLOPS, what="4 B nh hd S^2/2 (diagonal branches not counted)"),
             "attn_bwd_dq": kern("attn_bwd_dq", "TFLOP/s", PEAK_BF16_TFLOPS, what="6 B nh hd S^2/2"),
@@ -329,6 +337,8 @@ def main():
                              what=f"per logit: 2 B read + 2 B gradient written in place + 4 B soft target on the {density:.2f} of rows with a position mask"),
             "adamw_step": kern("adamw_step", "GB/s", PEAK_HBM_GBS, what="28 B per parameter"),
             "teacher_reduce": kern("teacher_reduce", "GB/s", PEAK_HBM_GBS, what="2 B per target logit read + 4 B per draft-vocabulary probability written"),
+            "teacher_reduce_perm": kern("teacher_reduce_perm", "GB/s", PEAK_HBM_GBS,
+                                        what="2 B per STORED (draft) logit + 16 B per reduced column block + 4 B per draft-vocabulary probability written"),
         }
         fus = kernels["gemm_nt_swiglu_bwd"] or {}
         # the step as a whole against the MFMA roofline: SURVEY 8d's F_draft = 3 * (T * F_step + 2 * 3Ht * H) per token
