@@ -128,6 +128,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) gemm_nt_kernel(GemmArgs p) {
 
 int sf_gemm_nt_256_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, void* stream);
 int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, void* stream);
+int sf_gemm_nt_128_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, void* stream);
 // tools build only (-DSF_ABLATE): SF_GEMM_TILE=128 pins the 128x128 kernel
 static bool sf_gemm_use_256() {
     static const bool use = sf_knob("SF_GEMM_TILE", 256) != 128;
@@ -153,13 +154,18 @@ static int sf_gemm_dispatch(const void* A, long lda, const void* B, long ldb, in
         return sf_gemm_nt_256w4_launch(A, lda, B, ldb, K, e, c_dtype, stream);
     if (K % 64 == 0 && K >= 64 && M >= 192 && N >= 192 && sf_gemm_use_256())
         return sf_gemm_nt_256_launch(A, lda, B, ldb, K, e, c_dtype, stream);
+    return sf_gemm_nt_128_launch(A, lda, B, ldb, K, e, c_dtype, stream);
+}
+
+// the 128 x 128 kernel (any shape; also the tail launch of the 4-wave kernel's peeled last round, sf_gemm256w4.hip)
+int sf_gemm_nt_128_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, void* stream) {
     GemmArgs p;
     p.A = (const sf_bf16*)A; p.lda = lda;
     p.B = (const sf_bf16*)B; p.ldb = ldb;
     p.e = e;
-    p.M = M; p.N = N; p.K = K;
-    p.tiles_m = (M + BM - 1) / BM;
-    p.tiles_n = (N + BN - 1) / BN;
+    p.M = e.M; p.N = e.N; p.K = K;
+    p.tiles_m = (e.M + BM - 1) / BM;
+    p.tiles_n = (e.N + BN - 1) / BN;
     const long nblk = (long)p.tiles_m * p.tiles_n;
     SF_CHECK_ARG(nblk < (1L << 31), "sf_gemm_nt: grid too large");
     if (c_dtype == SF_F32)

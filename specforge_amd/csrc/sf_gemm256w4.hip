@@ -1,6 +1,8 @@
 // Launcher of the 4-wave NT GEMM (kernel: sf_gemm256w4_kernel.h; instantiations: sf_gemm256w4_i*.hip).
 #include "sf_gemm256w4_kernel.h"
 
+int sf_gemm_nt_128_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, void* stream);
+
 // launched by sf_gemm_nt (sf_gemm.hip) when the shape qualifies
 int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype,
                             void* stream) {
@@ -14,7 +16,29 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     p.tiles_n = (N + TN - 1) / TN;
     p.gm = sf_knob("SF_GEMM_GM", 4);
     if (p.gm < 1) p.gm = 1;
-    const long nblk = (long)p.tiles_m * p.tiles_n;
+    long nblk = (long)p.tiles_m * p.tiles_n;
+    // The last, partly filled round of the persistent walk: lm_head forward (16384 x 32000: 8000 tiles) leaves 64 tiles for a 32nd
+    // round on 256 CUs -- 192 CUs idle for a whole tile time (2.3 % of the launch).  When the remainder is a whole number of
+    // COLUMN tiles and small (<= a quarter of the CUs), those columns are peeled off: the persistent kernel walks an exact number of
+    // rounds and the peeled columns run as 128 x 128 tiles (4 x the workgroups, a quarter of the work each: one short round of the
+    // generic kernel, measured 0.050 ms against the 0.098 ms round it replaces; tools/tail_bench.py).
+    if (!p.e.Cadd && !p.e.sw_gu && !p.e.sw_dgu && !p.e.red_part && sf_knob("SF_GEMM_PEEL", 1)) {
+        const long cus = sf_w4_grid(1L << 30);
+        const long rem = nblk % cus;
+        if (nblk > cus && rem != 0 && rem * 4 <= cus && rem % p.tiles_m == 0 && rem / p.tiles_m < p.tiles_n) {
+            const int t = (int)(rem / p.tiles_m);               // column tiles to peel
+            const int n_main = (p.tiles_n - t) * TN;
+            SfGemmEpi et = e;
+            et.N = N - n_main;
+            et.C = c_dtype == SF_F32 ? (void*)((float*)e.C + n_main) : (void*)((sf_bf16*)e.C + n_main);
+            if (e.R) et.R = e.R + n_main;
+            if (int st = sf_gemm_nt_128_launch(A, lda, (const sf_bf16*)B + (long)n_main * ldb, ldb, K, et, c_dtype, stream)) return st;
+            p.e.N = n_main;
+            p.N = n_main;
+            p.tiles_n -= t;
+            nblk = (long)p.tiles_m * p.tiles_n;
+        }
+    }
     // the 32-bit per-lane byte offsets of the buffer-descriptor DMA cover one 256-row tile of either operand
     SF_CHECK_ARG(256L * lda * 2 < (1L << 31) && 256L * ldb * 2 < (1L << 31), "sf_gemm_nt: row stride too large for the 256-tile kernel");
     if (p.e.Cadd) SF_CHECK_ARG(p.e.alpha == 1.0f, "sf_gemm_nt_rowadd: the 4-wave kernel needs alpha == 1");

@@ -31,7 +31,9 @@ def _rand(shape, dtype, seed, scale=1.0):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (64, 48, 288), (257, 384, 512), (256, 256, 64),
                                    (520, 264, 192), (300, 200, 128), (300, 260, 640), (256, 512, 64 * 11),
                                    (200, 8456, 512),   # N > 8192: the A-first plan of the 4-wave kernel
-                                   (1100, 608, 512)])  # 5 x 3 tiles: workgroups of the persistent kernel take 2 tiles (interior + edge)
+                                   (1100, 608, 512),   # 5 x 3 tiles: workgroups of the persistent kernel take 2 tiles (interior + edge)
+                                   (512, 1280, 512),   # interpreter (8 "CUs"): 2 x 5 tiles = 1 round + 2 -> the last column tile is peeled
+                                   (512, 1200, 512)])  # ... and a ragged peeled tile (176 columns)
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_nt(backend, M, N, K, out_dtype):
     a = _rand((M, K), torch.bfloat16, 1)
@@ -114,6 +116,23 @@ def test_gemm_nt_epilogues(backend):
     ops.gemm_nt(_dev(backend, a), _dev(backend, b), wide[:, 8:8 + N])
     torch.testing.assert_close(wide[:, 8:8 + N].float().cpu(), ref, rtol=2e-2, atol=0.25)
     assert float(wide[:, :8].abs().max()) == 0 and float(wide[:, 8 + N:].abs().max()) == 0
+
+
+def test_gemm_nt_peeled_last_round_epilogues(backend):
+    """the peeled column tile of a partly filled last round (interpreter: 2 x 5 tiles on 8 "CUs") carries the same epilogue:
+    residual after the rounding (bf16), alpha / beta (fp32)"""
+    M, N, K = 512, 1280, 512
+    a, b = _rand((M, K), torch.bfloat16, 3), _rand((N, K), torch.bfloat16, 4)
+    res = _rand((M, N), torch.bfloat16, 5)
+    c0 = _rand((M, N), torch.float32, 6)
+    ref = a.float() @ b.float().t()
+    out = c0.clone().to(backend)
+    ops.gemm_nt(_dev(backend, a), _dev(backend, b), out, alpha=0.5, beta=2.0)
+    torch.testing.assert_close(out.cpu(), 0.5 * ref + 2.0 * c0, rtol=1e-3, atol=3e-2)
+    outb = torch.empty((M, N), dtype=torch.bfloat16, device=backend)
+    ops.gemm_nt(_dev(backend, a), _dev(backend, b), outb, residual=_dev(backend, res))
+    expect = (ref.to(torch.bfloat16) + res).float()
+    torch.testing.assert_close(outb.float().cpu(), expect, rtol=2e-2, atol=0.5)
 
 
 # ------------------------------------------------------------------ fused CE
