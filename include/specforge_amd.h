@@ -201,10 +201,13 @@ int sf_cast_from_f32(const float* in, long ldin, void* out, int dtype, long ldou
 int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, const void* v0, const void* const* kd,
                 const void* const* vd, int ndiag, const int* kv_len, void* o, long ldo, float* lse, int B, int S,
                 int nh, int nkv, int hd, float scale, void* stream);
+/* dk_last / dv_last (ABI 4, optional, both or neither): the sums of the LAST branch of the list (kd[ndiag-1]: the branch of the TTT
+ * step whose backward this is -- no later launch adds to it) leave as bf16 [B*S, nkv*hd] (row stride ld_last) instead of going back
+ * to dkd / dvd[ndiag-1] in fp32: the cast of the finished gradient happens where its last term is added. */
 int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo, const void* dout, long lddo,
                     const void* const* kd, const void* const* vd, float* const* dkd, float* const* dvd, long ldk,
                     long lddk, int ndiag, const float* lse, float* delta, float* dq_init, int B, int S, int nh,
-                    int nkv, int hd, float scale, void* stream);
+                    int nkv, int hd, float scale, void* dk_last, void* dv_last, long ld_last, void* stream);
 int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long lddo, const void* k0, long ldk, const void* v0,
                    long ldv, const int* kv_len, const float* lse, const float* delta,
                    const float* dq_init, void* dq, long lddq, int B, int S, int nh, int nkv, int hd, float scale,

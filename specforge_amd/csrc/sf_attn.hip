@@ -268,6 +268,8 @@ struct AttnBwdPreArgs {
     float* delta;       // [B, nh, S]
     float* dq_init;     // [B*S, nh*hd] fp32, written when ndiag > 0
     int dq_accumulate;  // this launch handles a later chunk of diagonals: dq_init += instead of =
+    int last;           // index (in this launch) of the diagonal whose sums are FINAL after this launch, or -1: they leave as bf16
+    sf_bf16* dk_last; sf_bf16* dv_last; long ld_last;   // ... to dk_last / dv_last [B*S, nkv*hd] instead of back to dkd / dvd
     int B, S, nh, nkv, hd;
     float scale;
 };
@@ -370,8 +372,14 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_pre_kernel(AttnBwdPreArgs p) {
                     SfVec8<float>::ld(p.dvd[i] + idx, c);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { a[e] += dk[i][e]; c[e] += dv[i][e]; }
-                    SfVec8<float>::st(p.dkd[i] + idx, a);
-                    SfVec8<float>::st(p.dvd[i] + idx, c);
+                    if (i == p.last) {   // every TTT step that reads this branch has contributed: round once, write the gradient
+                        const long oi = (long)row * p.ld_last + g * HD + d0;
+                        SfVec8<sf_bf16>::st(p.dk_last + oi, a);
+                        SfVec8<sf_bf16>::st(p.dv_last + oi, c);
+                    } else {
+                        SfVec8<float>::st(p.dkd[i] + idx, a);
+                        SfVec8<float>::st(p.dvd[i] + idx, c);
+                    }
                 }
         }
     }
@@ -558,10 +566,13 @@ extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, co
 extern "C" int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo, const void* dout, long lddo,
                                const void* const* kd, const void* const* vd, float* const* dkd, float* const* dvd,
                                long ldk, long lddk, int ndiag, const float* lse, float* delta, float* dq_init, int B,
-                               int S, int nh, int nkv, int hd, float scale, void* stream) {
+                               int S, int nh, int nkv, int hd, float scale, void* dk_last, void* dv_last, long ld_last,
+                               void* stream) {
     SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_pre: bad shape");
     SF_CHECK_ARG(ndiag >= 0 && ndiag <= kMaxDiag, "sf_attn_bwd_pre: at most 32 diagonal branches");
     SF_CHECK_ARG(ndiag == 0 || dq_init, "sf_attn_bwd_pre: dq_init required with diagonal branches");
+    SF_CHECK_ARG((!dk_last && !dv_last) || (dk_last && dv_last && ndiag > 0 && ld_last % 8 == 0),
+                 "sf_attn_bwd_pre: dk_last / dv_last come together, need a diagonal branch and 16-byte aligned rows");
     SF_CHECK_ARG(hd == 64 || hd == 128, "head_dim must be 64 or 128");
     SF_CHECK_ARG(ldq % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldk % 8 == 0 && lddk % 4 == 0,
                  "sf_attn_bwd_pre: strides must be multiples of 8 (16-byte row segments)");
@@ -581,6 +592,8 @@ extern "C" int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo,
         }
         p.ldk = ldk; p.lddk = lddk; p.ndiag = n > 0 ? n : 0;
         p.lse = lse; p.delta = delta; p.dq_init = dq_init; p.dq_accumulate = lo > 0;
+        p.last = (dk_last && lo + n == ndiag) ? n - 1 : -1;
+        p.dk_last = (sf_bf16*)dk_last; p.dv_last = (sf_bf16*)dv_last; p.ld_last = ld_last;
         p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.hd = hd; p.scale = scale;
         SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_pre_kernel<HD, chunk>), grid, dim3(256), 0, stream, p));
     }

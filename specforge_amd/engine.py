@@ -570,16 +570,20 @@ class Eagle3Engine:
                 self._pad_heads(b["do"], nh, b["dop"])
                 q, o_k, do, dq_out = b["qp"][k], b["op"][k], b["dop"], b["dqp"]
                 k0, v0, kd, vd = b["kp"][0], b["vp"][0], b["kp"][1:k + 1], b["vp"][1:k + 1]
+            # (K_k / V_k receive their last contribution here -- steps k..T-1 have all run: for k >= 1 their gradients leave the
+            # kernel as bf16, straight into the dqkv slot)
+            fin = k > 0 and self.hdp == hd
             ops.attn_bwd_pre(q, o_k, do, kd, vd, b["dk"][1:k + 1], b["dv"][1:k + 1], b["lse"][k], b["delta"],
-                             b["dq_init"] if k > 0 else None, B=B, S=S, nh=nh, nkv=nkv, hd=self.hdp, scale=scale)
+                             b["dq_init"] if k > 0 else None, B=B, S=S, nh=nh, nkv=nkv, hd=self.hdp, scale=scale,
+                             dk_last=dqkv[:, kcol] if fin else None, dv_last=dqkv[:, vcol] if fin else None)
             ops.attn_bwd_dq(q, do, k0, v0, b["kvlen"], b["lse"][k], b["delta"], b["dq_init"] if k > 0 else None, dq_out,
                             B=B, S=S, nh=nh, nkv=nkv, hd=self.hdp, scale=scale)
             ops.attn_bwd_dkv(q, do, k0, v0, b["kvlen"], b["lse"][k], b["delta"], b["dk"][0], b["dv"][0], B=B, S=S, nh=nh,
                              nkv=nkv, hd=self.hdp, scale=scale)
-            # K_k / V_k have now received every contribution (steps k..T-1)
             if self.hdp == hd:
-                ops.cast_from_f32(b["dk"][k], dqkv[:, kcol])
-                ops.cast_from_f32(b["dv"][k], dqkv[:, vcol])
+                if k == 0:      # block 0's keys: the dK/dV kernel of this step added the last term
+                    ops.cast_from_f32(b["dk"][0], dqkv[:, kcol])
+                    ops.cast_from_f32(b["dv"][0], dqkv[:, vcol])
             else:
                 self._unpad_heads(b["dqp"], nh, dqkv[:, :nh * hd])
                 self._unpad_heads(b["dk"][k], nkv, dqkv[:, kcol])

@@ -333,13 +333,20 @@ def attn_fwd(q, k0, v0, kd: List[torch.Tensor], vd: List[torch.Tensor], kv_len, 
                              _p(kv_len), _p(o), _rowmajor(o), _p(lse), B, S, nh, nkv, hd, scale, _stream()), "sf_attn_fwd")
 
 
-def attn_bwd_pre(q, o, dout, kd, vd, dkd, dvd, lse, delta, dq_init, *, B, S, nh, nkv, hd, scale):
+def attn_bwd_pre(q, o, dout, kd, vd, dkd, dvd, lse, delta, dq_init, *, B, S, nh, nkv, hd, scale, dk_last=None, dv_last=None):
+    """``dk_last`` / ``dv_last`` (bf16 [B*S, nkv*hd] views, optional): the finished sums of the LAST branch of the list leave there,
+    rounded once, instead of going back to dkd[-1] / dvd[-1] in fp32"""
     L = _lib.lib()
     ldk = _rowmajor(kd[0]) if kd else 0
     lddk = _rowmajor(dkd[0]) if dkd else 0
+    ld_last = 0
+    if dk_last is not None:
+        assert dv_last is not None and dk_last.dtype == dv_last.dtype == torch.bfloat16 and _rowmajor(dk_last) == _rowmajor(dv_last)
+        ld_last = _rowmajor(dk_last)
     _lib.check(L.sf_attn_bwd_pre(_p(q), _rowmajor(q), _p(o), _rowmajor(o), _p(dout), _rowmajor(dout), _ptr_array(kd),
                                  _ptr_array(vd), _ptr_array(dkd), _ptr_array(dvd), ldk, lddk, len(kd), _p(lse), _p(delta),
-                                 _p(dq_init), B, S, nh, nkv, hd, scale, _stream()), "sf_attn_bwd_pre")
+                                 _p(dq_init), B, S, nh, nkv, hd, scale, _p(dk_last), _p(dv_last), ld_last, _stream()),
+               "sf_attn_bwd_pre")
 
 
 def attn_bwd_dq(q, dout, k0, v0, kv_len, lse, delta, dq_init, dq, *, B, S, nh, nkv, hd, scale):

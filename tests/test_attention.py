@@ -97,6 +97,25 @@ def test_ttt_attention_fwd_bwd(backend, hd, B, S, nh, nkv, lengths, nsteps):
     for b, L in enumerate(lengths):
         assert float(dk_acc[0].view(B, S, -1)[b, L:].abs().max() if L < S else 0.0) == 0.0
         assert float(dv_acc[0].view(B, S, -1)[b, L:].abs().max() if L < S else 0.0) == 0.0
+    # the finished-gradient form: the last branch's sums (old fp32 value + this launch's terms) leave as bf16, rounded once,
+    # and its fp32 accumulators are not written -- bit-identical to accumulating in fp32 and casting afterwards
+    if nsteps > 1:
+        g = torch.Generator().manual_seed(77)
+        seed_k = [torch.randn(N, nkv * hd, generator=g).to(backend) for _ in range(nsteps)]
+        seed_v = [torch.randn(N, nkv * hd, generator=g).to(backend) for _ in range(nsteps)]
+        acc_k, acc_v = [t.clone() for t in seed_k], [t.clone() for t in seed_v]
+        ops.attn_bwd_pre(qv, o, dout, kview[1:], vview[1:], acc_k[1:], acc_v[1:], lse, delta, torch.zeros_like(dq_init), B=B, S=S,
+                         nh=nh, nkv=nkv, hd=hd, scale=scale)
+        fin_k, fin_v = [t.clone() for t in seed_k], [t.clone() for t in seed_v]
+        wide = torch.full((N, 2 * nkv * hd + 16), 3.0, dtype=torch.bfloat16, device=backend)     # strided bf16 outputs
+        ok, ov = wide[:, 8:8 + nkv * hd], wide[:, 8 + nkv * hd:8 + 2 * nkv * hd]
+        ops.attn_bwd_pre(qv, o, dout, kview[1:], vview[1:], fin_k[1:], fin_v[1:], lse, delta, torch.zeros_like(dq_init), B=B, S=S,
+                         nh=nh, nkv=nkv, hd=hd, scale=scale, dk_last=ok, dv_last=ov)
+        assert torch.equal(ok.cpu(), acc_k[-1].to(torch.bfloat16).cpu()) and torch.equal(ov.cpu(), acc_v[-1].to(torch.bfloat16).cpu())
+        assert torch.equal(fin_k[-1].cpu(), seed_k[-1].cpu()) and torch.equal(fin_v[-1].cpu(), seed_v[-1].cpu())   # untouched
+        for i in range(1, nsteps - 1):
+            assert torch.equal(fin_k[i].cpu(), acc_k[i].cpu()) and torch.equal(fin_v[i].cpu(), acc_v[i].cpu())
+        assert float((wide[:, :8].float() - 3.0).abs().max()) == 0.0 and float((wide[:, 8 + 2 * nkv * hd:].float() - 3.0).abs().max()) == 0.0
     # accumulation semantics: a second backward call adds into the fp32 buffers
     before = dk_acc[0].clone()
     ops.attn_bwd_dkv(qv, dout, kview[0], vview[0], kv_len, lse, delta, dk_acc[0], dv_acc[0], B=B, S=S, nh=nh,
