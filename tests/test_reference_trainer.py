@@ -154,6 +154,59 @@ def test_reference_trainer_fit_reproduces_the_reference_run(ref, golden_dir, tmp
     assert "replicated_optimizer_state" in state and "fp32_params" in state["replicated_optimizer_state"]
 
 
+def test_reference_evaluator_runs_over_the_hip_strategy(ref, golden_dir, tmp_path):
+    """the reference's own eval pass (TrainerController.evaluate_configured -> eval/evaluator.py Evaluator.run, controller.py:779-817)
+    over the HIP strategy in eval mode == the same pass over the pure reference model on the same feature files: every eval/* metric"""
+    from specforge.algorithms.builtin import builtin_algorithm_registry
+    from specforge.algorithms.eagle3.model import OnlineEagle3Model as RefOnline
+    from specforge.launch import build_offline_runtime
+    from specforge.modeling.auto import AutoDraftModel, AutoDraftModelConfig
+    from specforge.modeling.target.target_head import TargetHead
+    from specforge_amd.eagle3 import OnlineEagle3Model
+    from specforge_amd.training import BF16Optimizer
+
+    blob = torch.load(os.path.join(golden_dir, "loss_curve_tiny.pt"), weights_only=False)
+    c = blob["cfg"]
+    dj, feat, td, vp = _write_run_dir(str(tmp_path), blob, ref.DRAFT_ARCHITECTURE)
+    dj_ref = os.path.join(str(tmp_path), "draft_ref.json")
+    cfgj = json.load(open(dj))
+    cfgj["architectures"] = ["LlamaForCausalLMEagle3"]
+    json.dump(cfgj, open(dj_ref, "w"))
+    common = dict(hidden_states_path=feat, eval_hidden_states_path=feat, eval_interval=1000, ttt_length=c["ttt"], max_len=c["max_len"],
+                  batch_size=c["batch_size"], max_steps=1, total_steps=c["steps"], num_epochs=1, seed=c["seed"], log_interval=1,
+                  logger=lambda m, s: None)
+    res = {}
+    for kind in ("ref", "hip"):
+        (ref.uninstall if kind == "ref" else ref.install)()     # the pure run must see the reference's own backend / optimizer
+        ref.draft_class()                                        # (registers the HIP draft architecture; idempotent)
+        draft = AutoDraftModel.from_config(AutoDraftModelConfig.from_file(dj_ref if kind == "ref" else dj), attention_backend="sdpa",
+                                           torch_dtype=torch.bfloat16)
+        draft.load_state_dict(blob["init_state"], strict=True)
+        draft.freeze_embedding()
+        head = TargetHead.from_pretrained(td, lm_head_key="lm_head.weight")
+        if kind == "ref":
+            model = RefOnline(draft_model=draft, length=c["ttt"], attention_backend="sdpa")
+            alg = builtin_algorithm_registry().resolve("eagle3")
+            from specforge.optimizer import BF16Optimizer as RefOpt      # (bound after uninstall())
+            opt = lambda m: RefOpt(m, lr=c["lr"], max_grad_norm=c["max_grad_norm"], warmup_ratio=c["warmup_ratio"], total_steps=c["steps"])
+        else:
+            model = OnlineEagle3Model(draft_model=draft, length=c["ttt"], attention_backend="sdpa")
+            alg = ref.registry().resolve(ref.ALGORITHM_NAME)
+            opt = lambda m: BF16Optimizer(m, lr=c["lr"], max_grad_norm=c["max_grad_norm"], warmup_ratio=c["warmup_ratio"], total_steps=c["steps"])
+        trainer = build_offline_runtime(algorithm=alg, draft_model=model, target_head=head, optimizer_factory=opt, run_id=f"eval-{kind}",
+                                        output_dir=os.path.join(str(tmp_path), f"out-{kind}"), **common)
+        res[kind] = trainer._controller.evaluate_configured()
+        assert model.training                       # evaluate() restores the training mode it found
+    want, got = res["ref"], res["hip"]
+    assert want and set(got) == set(want) and any(k.startswith("eval/") for k in want)
+    flat = lambda x: [float(y) for y in x] if isinstance(x, (list, tuple)) else [float(x)]
+    for k, v in want.items():
+        vs, gs = flat(v), flat(got[k])
+        assert len(vs) == len(gs), k
+        for a, g in zip(vs, gs):
+            assert abs(g - a) <= 2e-2 * max(1.0, abs(a)), (k, g, a)
+
+
 def test_cli_train_path_and_sglang_export_round_trip(ref, golden_dir, tmp_path):
     """the SAME run YAML / draft JSON a reference run would use (strategy ``eagle3``, ``LlamaForCausalLMEagle3``)"""
     import yaml

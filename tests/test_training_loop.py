@@ -28,9 +28,12 @@ def test_loss_decreases_on_a_fixed_batch(backend, golden_dir, lk):
     T = 3
     eagle = OnlineEagle3Model(model, length=T, lk_loss_type=lk, kl_scale=0.7, kl_decay=1.0).train()
     strat = Eagle3TrainStrategy(eagle, target_head=TargetHead(blob["head_w"].to(torch.bfloat16).to(backend)))
-    be = HipDPTrainingBackend(optimizer_factory=lambda m: BF16Optimizer(m, lr=3e-3, max_grad_norm=1.0, total_steps=40,
-                                                                        warmup_ratio=0.1))
-    be.prepare_model(eagle)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")      # offload_master (optimizer.py:25-35) is accepted: a placement option, same update
+        be = HipDPTrainingBackend(optimizer_factory=lambda m: BF16Optimizer(m, lr=3e-3, max_grad_norm=1.0, total_steps=40,
+                                                                            warmup_ratio=0.1, offload_master=lk is None))
+        be.prepare_model(eagle)
     b = blob["batch"]
     batch = TrainBatch(dict(input_ids=b["input_ids"], attention_mask=b["attention_mask"], loss_mask=b["loss_mask"],
                             hidden_state=b["hidden_state"].to(backend), target=b["target"].to(backend)),
