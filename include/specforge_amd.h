@@ -98,6 +98,13 @@ int sf_ce_lk_grad(void* logits, int dtype, long ld, int rows, int V, const float
  * replacement of the .sum()/.mean() reductions in eagle3/model.py:161-190. */
 int sf_reduce_sum(const float* in, long n, int nsegments, float* out, float scale, void* stream);
 
+/* The per-TTT-step metric scalars (eagle3/model.py:161-190; strategies/base.py:237-304) in one launch (ABI 4): met [T, 3] = the
+ * per-step sums {row loss, correct, acceptance} (sf_reduce_sum of sf_ce_fused's row outputs); masks are the zero-padded
+ * [B, Spad] arrays, step k reads them at offset k.  out [T, 8] = {ploss = loss_sum / (B S), acc_correct, acc_denom =
+ * max(count(loss_mask), 1e-6), acc, acceptance_rate = accept_sum / max(count(position_mask), 1e-8), that denominator, B S, ploss again}. */
+int sf_eagle3_metrics(const float* met, const int* loss_mask_pad, const int* pos_mask_pad, int B, int S, int Spad, int T, float* out,
+                      void* stream);
+
 /* ---- teacher soft targets from target logits ---------------------------------------------
  * replaces specforge/algorithms/eagle3/model.py:487-501 (_compute_target_p): argmax id
  * (lowest index on ties), position_mask = t2d[id]*loss_mask, target_p = softmax over the

@@ -31,6 +31,7 @@ _SIGS = {
     "sf_ce_lk_grad": (c_int, [P, c_int, c_long, c_int, c_int, P, c_int, c_int, c_int, P, P, P, c_int, c_float, c_float,
                               c_float, c_float, P, P, P]),
     "sf_reduce_sum": (c_int, [P, c_long, c_int, P, c_float, P]),
+    "sf_eagle3_metrics": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "sf_teacher_reduce": (c_int, [P, c_int, c_long, c_int, c_int, c_int, P, P, P, c_int, c_int, P, P, P, P, P, P]),
     "sf_gemm_nt_teacher": (c_int, [P, c_long, P, c_long, c_int, c_int, c_int, c_int, P, c_long, P, c_long, P, P, P]),
     "sf_teacher_reduce_perm": (c_int, [P, c_int, c_long, c_int, c_int, c_int, c_int, P, P, P, c_int, c_long, P, c_int, c_int, P, P, P, P,

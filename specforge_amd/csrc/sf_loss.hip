@@ -292,6 +292,41 @@ SF_GLOBAL void reduce_sum_kernel(const float* in_all, long n, float* out, float 
     if (tid == 0) out[blockIdx.x] = (float)(part[0] * (double)scale);
 }
 
+// The per-TTT-step metric scalars of Eagle3TrainStrategy.forward_loss in ONE launch (they were ~40 tiny ATen kernels per step):
+// workgroup k counts the loss / position mask of step k (the masks shifted by k: offsets into the zero-padded [B, S+T] arrays) and
+// forms  ploss = row_loss_sum / (B S),  acc = correct / max(count_lm, 1e-6),  acceptance = accept_sum / max(count_pm, 1e-8)  with the
+// same fp32 operations torch used (counts of 0/1 are exact in fp32; one IEEE division each)   (eagle3/model.py:161-190)
+SF_GLOBAL void eagle3_metrics_kernel(const float* met, const int* lm_pad, const int* pm_pad, int B, int S, int Spad, float* out) {
+    SF_SHARED int cnt[2][256];
+    const int k = (int)blockIdx.x, tid = (int)threadIdx.x;
+    int nl = 0, np = 0;
+    for (long i = tid; i < (long)B * S; i += 256) {
+        const long b = i / S, idx = b * Spad + (i - b * S) + k;
+        nl += lm_pad[idx] != 0;
+        np += pm_pad[idx] != 0;
+    }
+    cnt[0][tid] = nl;
+    cnt[1][tid] = np;
+    sf_syncthreads();
+    for (int sft = 128; sft >= 1; sft >>= 1) {
+        if (tid < sft) { cnt[0][tid] += cnt[0][tid + sft]; cnt[1][tid] += cnt[1][tid + sft]; }
+        sf_syncthreads();
+    }
+    if (tid == 0) {
+        const float n = (float)((long)B * S);
+        const float denom = fmaxf((float)cnt[0][0], 1e-6f), pden = fmaxf((float)cnt[1][0], 1e-8f);
+        float* o = out + (long)k * 8;
+        o[0] = met[k * 3 + 0] / n;          // ploss
+        o[1] = met[k * 3 + 1];              // acc_correct
+        o[2] = denom;                       // acc_denom
+        o[3] = met[k * 3 + 1] / denom;      // acc
+        o[4] = met[k * 3 + 2] / pden;       // acceptance rate
+        o[5] = pden;
+        o[6] = n;                           // metric_loss_denom
+        o[7] = o[0];                        // metric_loss (its own element: the caller hands out views)
+    }
+}
+
 // ------------------------------------------------------------ teacher reduce
 // One row of teacher logits z[Vt] -> argmax id, position mask, softmax over the draft
 // sub-vocabulary (target_p), and pod_scale = sum_d exp(z_d - logsumexp(z)) / so that
@@ -678,4 +713,11 @@ extern "C" int sf_teacher_reduce_perm(const void* z, int dtype, long ldz, int ro
     else
         SF_CHECK_ARG(false, "sf_teacher_reduce_perm: dtype");
     return sf_check_launch("sf_teacher_reduce_perm");
+}
+
+extern "C" int sf_eagle3_metrics(const float* met, const int* loss_mask_pad, const int* pos_mask_pad, int B, int S, int Spad, int T,
+                                 float* out, void* stream) {
+    SF_CHECK_ARG(B > 0 && S > 0 && T >= 1 && Spad >= S + T - 1 && met && loss_mask_pad && pos_mask_pad && out, "sf_eagle3_metrics: bad args");
+    SF_LAUNCH(eagle3_metrics_kernel, dim3((unsigned)T), dim3(256), 0, stream, met, loss_mask_pad, pos_mask_pad, B, S, Spad, out);
+    return sf_check_launch("sf_eagle3_metrics");
 }

@@ -77,6 +77,7 @@ class Eagle3Engine:
         self._max_cached_shapes = 16
         self._regrown = False
         self._active = None                          # the shape whose constants are currently laid down
+        self._pos_default = None                     # the (B, S) whose default position ids 0..S-1 sit in the shared `pos` buffer
         self._wt_version = -1
         self.weights_version = 0          # bumped by the optimizer after every step
         self.micro_in_window = 0          # micro-steps accumulated into flat.grad since the last optimizer step
@@ -113,6 +114,7 @@ class Eagle3Engine:
             if invalidate:               # cached views of other shapes may alias the freed storage
                 self._views.clear()
                 self._active = None
+                self._pos_default = None
                 self._regrown = True
             self._arena[name] = torch.empty(max(n, 1), dtype=dtype, device=self.dev)
         return self._arena[name][:n].view(*shape)
@@ -362,12 +364,16 @@ class Eagle3Engine:
                 b["cos_rows"][k].copy_(self.cos[idx, cols])
                 b["sin_rows"][k].copy_(self.sin[idx, cols])
             b["pos"].copy_(torch.arange(N, device=self.dev))                                  # row r reads table row r
+            self._pos_default = None
         elif position_ids is None:
-            b["pos"].copy_(torch.arange(S, device=self.dev).repeat(B))
+            if self._pos_default != (B, S):      # 0..S-1 per sample: laid down once per shape, not every step
+                b["pos"].copy_(torch.arange(S, device=self.dev).repeat(B))
+                self._pos_default = (B, S)
         else:
             if position_ids.dim() != 2:
                 raise ValueError("position_ids must be [batch, seq_length] (three-axis ids need rope_type 'mrope')")
             b["pos"].copy_(position_ids.reshape(-1))
+            self._pos_default = None
         if self._t2d_u8 is None or self._t2d_u8.device != self.dev:
             self._t2d_u8 = self.model.t2d.to(self.dev).to(torch.uint8).contiguous()
             self._d2t = self.model.d2t.to(self.dev).contiguous()
@@ -482,9 +488,24 @@ class Eagle3Engine:
         self._fwd_state = (B, S) if train else None
         # ---- metrics (tiny integer-mask sums; eagle3/model.py:161-190, core/lk_loss.py:43-80)
         met = b["metrics"]
-        lm_f, pm_f = b["lm"].float(), b["pm"].float()
         out = dict(plosses=[], acces=[], acceptance_rates=[], acc_corrects=[], acc_denoms=[], metric_losses=[],
                    metric_loss_denoms=[])
+        if lk is None:          # one launch for all 7 x T scalars (the lists are 0-dim views of a fresh [T, 8] tensor)
+            ms = torch.empty(T, 8, dtype=torch.float32, device=self.dev)
+            ops.eagle3_metrics(met, b["lm"], b["pm"], ms, B=B, S=S, Spad=Spad, T=T)
+            for k in range(T):
+                r = ms[k]
+                out["plosses"].append(r[0])
+                out["acc_corrects"].append(r[1])
+                out["acc_denoms"].append(r[2])
+                out["acces"].append(r[3])
+                out["acceptance_rates"].append(r[4])
+                out["metric_losses"].append(r[7])
+                out["metric_loss_denoms"].append(r[6])
+            out["target_token_ids"] = b["tids"][:, :S]
+            out["position_mask"] = b["pm"][:, :S]
+            return out
+        lm_f, pm_f = b["lm"].float(), b["pm"].float()
         for k in range(T):
             denom = lm_f[:, k:k + S].sum().clamp_min(1e-6)
             pden = pm_f[:, k:k + S].sum().clamp_min(1e-8)

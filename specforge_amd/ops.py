@@ -121,6 +121,16 @@ def reduce_sum(inp: torch.Tensor, n: int, nseg: int, out: torch.Tensor, scale: f
     return out
 
 
+def eagle3_metrics(met: torch.Tensor, loss_mask_pad: torch.Tensor, pos_mask_pad: torch.Tensor, out: torch.Tensor, *, B: int, S: int,
+                   Spad: int, T: int):
+    """out[k] = {ploss, acc_correct, acc_denom, acc, acceptance_rate, pos_denom, B*S, ploss} of TTT step k"""
+    L = _lib.lib()
+    assert met.dtype == out.dtype == torch.float32 and met.is_contiguous() and out.is_contiguous()
+    assert loss_mask_pad.dtype == pos_mask_pad.dtype == torch.int32 and loss_mask_pad.is_contiguous() and pos_mask_pad.is_contiguous()
+    assert met.numel() >= 3 * T and out.numel() >= 8 * T and loss_mask_pad.shape == pos_mask_pad.shape == (B, Spad)
+    _lib.check(L.sf_eagle3_metrics(_p(met), _p(loss_mask_pad), _p(pos_mask_pad), B, S, Spad, T, _p(out), _stream()), "sf_eagle3_metrics")
+
+
 def teacher_reduce(z: torch.Tensor, *, Vd: int, d2t, t2d_u8, loss_mask_pad, S: int, Spad: int, target_p_pad,
                    pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad, row0: int = 0):
     """rows of z are tokens row0 .. row0+rows (row index b*S+s)."""
