@@ -52,7 +52,6 @@ def _run(cmd):
 # online softmax.  Infinities keep their meaning (the causal mask is -inf).
 EXTRA_FLAGS = {"sf_attn.hip": ["-fno-honor-nans"], "sf_attn_dkv.hip": ["-fno-honor-nans"]}
 
-
 def _build(lib, objdir, compile_cmd, link_cmd, force=False):
     os.makedirs(objdir, exist_ok=True)
     deps = _deps()

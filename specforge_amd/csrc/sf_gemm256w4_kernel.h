@@ -565,16 +565,22 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                 for (int i = 0; i < 8; ++i) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
-                        sf_v4s og, ou, oa;
+                        // (pairs packed by one v_cvt_pk_bf16_f32 each; the activation from the ROUNDED gate / up, like swiglu_fwd_kernel)
+                        const sf_v4f ga = acc[i][2 * jj], ua = acc[i][2 * jj + 1];
+                        sf_v2u og, ou, oa;
+                        float av[4];
+                        og[0] = sf_pack2_bf16(ga[0], ga[1]); og[1] = sf_pack2_bf16(ga[2], ga[3]);
+                        ou[0] = sf_pack2_bf16(ua[0], ua[1]); ou[1] = sf_pack2_bf16(ua[2], ua[3]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            og[e] = (short)sf_f2bf(acc[i][2 * jj][e]);
-                            ou[e] = (short)sf_f2bf(acc[i][2 * jj + 1][e]);
-                            oa[e] = (short)sf_f2bf(sf_swiglu_fwd_elem<sf_bf16>(sf_bf2f((sf_bf16)og[e]), sf_bf2f((sf_bf16)ou[e])));
+                            const float g = __builtin_bit_cast(float, (e & 1) ? (og[e >> 1] & 0xffff0000u) : (og[e >> 1] << 16));
+                            const float u = __builtin_bit_cast(float, (e & 1) ? (ou[e >> 1] & 0xffff0000u) : (ou[e >> 1] << 16));
+                            av[e] = sf_swiglu_fwd_elem<sf_bf16>(g, u);
                         }
-                        *reinterpret_cast<sf_v4s*>(st + r * kStageRow3 + jj * 32 + q * 8) = og;
-                        *reinterpret_cast<sf_v4s*>(st + r * kStageRow3 + 128 + jj * 32 + q * 8) = ou;
-                        *reinterpret_cast<sf_v4s*>(st + r * kStageRow3 + 256 + jj * 32 + q * 8) = oa;
+                        oa[0] = sf_pack2_bf16(av[0], av[1]); oa[1] = sf_pack2_bf16(av[2], av[3]);
+                        *reinterpret_cast<sf_v2u*>(st + r * kStageRow3 + jj * 32 + q * 8) = og;
+                        *reinterpret_cast<sf_v2u*>(st + r * kStageRow3 + 128 + jj * 32 + q * 8) = ou;
+                        *reinterpret_cast<sf_v2u*>(st + r * kStageRow3 + 256 + jj * 32 + q * 8) = oa;
                     }
                     sf_wave_lockstep();
 #pragma unroll
@@ -588,17 +594,22 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                     sf_wave_lockstep();
                 }
             } else {
+            // (UNIT: alpha == 1, every GEMM of the training step -- its own copy of the loop: a per-value select costs more than the multiply)
+            auto tile_out = [&](auto UNIT) SF_INLINE_LAMBDA {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
+                w4_fence();   // keeps the AGPR -> VGPR copies of m-tile i + 1 out of m-tile i: hoisted, all 256 of them fill the VGPR
+                              // file and the four staging reads below share one register quad (read, wait, store, four times)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     sf_v4f v;
                     if constexpr (ADD == 1) v = acc[i][j] + ad[i & 1][j];   // (alpha == 1 is enforced by the launcher)
+                    else if constexpr (decltype(UNIT)::value) v = acc[i][j];
                     else v = acc[i][j] * alpha;
-                    sf_v4s o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (short)sf_f2bf(v[e]);
-                    *reinterpret_cast<sf_v4s*>(st + r * kStageRow + j * 32 + q * 8) = o;
+                    sf_v2u o;
+                    o[0] = sf_pack2_bf16(v[0], v[1]);
+                    o[1] = sf_pack2_bf16(v[2], v[3]);
+                    *reinterpret_cast<sf_v2u*>(st + r * kStageRow + j * 32 + q * 8) = o;
                 }
                 if constexpr (ADD == 1) { if (i + 2 < 8) addend_rows(i + 2, ad[i & 1]); }
                 sf_wave_lockstep();
@@ -632,14 +643,17 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                         *reinterpret_cast<sf_v8s*>(op + p.N) = ou;
                     }
                 } else {
+                    sf_v8s d[4];                             // rows 4*s4 + q of this m-tile, 16 bytes at column 8*r: four reads in
+#pragma unroll                                                 // flight, then the four stores (one read-wait-store chain per row serialises)
+                    for (int s4 = 0; s4 < 4; ++s4) d[s4] = *reinterpret_cast<const sf_v8s*>(st + (4 * s4 + q) * kStageRow + r * 16);
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {         // rows 4*s4 + q of this m-tile, 16 bytes at column 8*r
-                        const sf_v8s d = *reinterpret_cast<const sf_v8s*>(st + (4 * s4 + q) * kStageRow + r * 16);
-                        *reinterpret_cast<sf_v8s*>(cbase + (long)(i * 16 + 4 * s4) * p.e.ldc) = d;
-                    }
+                    for (int s4 = 0; s4 < 4; ++s4) *reinterpret_cast<sf_v8s*>(cbase + (long)(i * 16 + 4 * s4) * p.e.ldc) = d[s4];
                 }
                 sf_wave_lockstep();
             }
+            };
+            if (ADD == 0 && p.e.alpha != 1.0f) tile_out(std::false_type{});
+            else tile_out(std::true_type{});
             }
             newer = 32;   // (the fused forms issue 48 stores / 64 stores + 64 loads: more, which is the safe direction)
         }
