@@ -629,18 +629,20 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
                         const sf_v8s d = *reinterpret_cast<const sf_v8s*>(st + (4 * s4 + q) * kStageRow + r * 16);
-                        sf_v8s og, ou;
+                        float dg[8], du[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            float dg, du;
+                        for (int e = 0; e < 8; ++e)
                             sf_swiglu_bwd_elem<sf_bf16>(sf_bf2f((sf_bf16)gq[s4][e]), sf_bf2f((sf_bf16)uq[s4][e]),
-                                                        sf_bf2f((sf_bf16)d[e]), dg, du);
-                            og[e] = (short)sf_f2bf(dg);
-                            ou[e] = (short)sf_f2bf(du);
+                                                        sf_bf2f((sf_bf16)d[e]), dg[e], du[e]);
+                        sf_v4i og, ou;                       // (pairs by one v_cvt_pk_bf16_f32 each)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            og[e] = (int)sf_pack2_bf16(dg[2 * e], dg[2 * e + 1]);
+                            ou[e] = (int)sf_pack2_bf16(du[2 * e], du[2 * e + 1]);
                         }
                         sf_bf16* op = p.e.sw_dgu + (row0 + 4 * s4) * p.e.sw_lddgu + col;
-                        *reinterpret_cast<sf_v8s*>(op) = og;
-                        *reinterpret_cast<sf_v8s*>(op + p.N) = ou;
+                        *reinterpret_cast<sf_v4i*>(op) = og;
+                        *reinterpret_cast<sf_v4i*>(op + p.N) = ou;
                     }
                 } else {
                     sf_v8s d[4];                             // rows 4*s4 + q of this m-tile, 16 bytes at column 8*r: four reads in

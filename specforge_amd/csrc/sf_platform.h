@@ -13,6 +13,7 @@ typedef short sf_v8s __attribute__((ext_vector_type(8)));   // 8 x bf16 bits
 typedef short sf_v4s __attribute__((ext_vector_type(4)));   // 4 x bf16 bits
 typedef float sf_v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int sf_v2u __attribute__((ext_vector_type(2)));   // 4 x bf16 bits as two packed dwords
+typedef int sf_v4i __attribute__((ext_vector_type(4)));
 typedef float sf_v16f __attribute__((ext_vector_type(16)));
 typedef unsigned short sf_bf16;  // raw bf16 bits
 
@@ -237,7 +238,6 @@ SF_DEVICE void sf_glds16_opaque(const void* g, void* l) {
 // Buffer-descriptor LDS-DMA as inline asm (both properties at once: scalar K advance AND invisible to the compiler's
 // LDS ordering).  The descriptor is assembled by hand: {base[31:0], base[47:32] (stride 0), num_records = 2^31-1,
 // DST_SEL/format word 0x00020000}; every field must be wave-uniform.
-typedef int sf_v4i __attribute__((ext_vector_type(4)));
 struct SfBufRaw { sf_v4i w; };
 SF_DEVICE SfBufRaw sf_make_buf_raw(const void* base) {
     const unsigned long long a = (unsigned long long)base;

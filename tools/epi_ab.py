@@ -48,3 +48,15 @@ for rnd in range(7):
         if rnd: res[which].append(ms)
 n, o = statistics.median(res["new"]), statistics.median(res["old"])
 print(json.dumps(dict(shape="gate|up + SwiGLU fwd", new_ms=round(n, 4), old_ms=round(o, 4), gain_pct=round(100 * (o - n) / o, 2))))
+
+# fused down-dgrad + d(SwiGLU)
+dy = torch.randn(M, K, device="cuda").to(torch.bfloat16); wd = (torch.randn(I, K, device="cuda") / 64).to(torch.bfloat16)
+guv = torch.randn(M, 2 * I, device="cuda").to(torch.bfloat16); dgu = torch.empty_like(guv); scr = torch.empty(M, I, device="cuda", dtype=torch.bfloat16)
+res = {"new": [], "old": []}
+for rnd in range(7):
+    for which in (("new", "old") if rnd % 2 else ("old", "new")):
+        use(which == "old")
+        ms = timed(lambda: ops.gemm_nt_swiglu_bwd(dy, wd, guv, dgu, scr))
+        if rnd: res[which].append(ms)
+n, o = statistics.median(res["new"]), statistics.median(res["old"])
+print(json.dumps(dict(shape="down dgrad + d(SwiGLU)", new_ms=round(n, 4), old_ms=round(o, 4), gain_pct=round(100 * (o - n) / o, 2))))
