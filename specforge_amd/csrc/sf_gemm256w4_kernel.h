@@ -595,11 +595,28 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                 }
             } else {
             // (UNIT: alpha == 1, every GEMM of the training step -- its own copy of the loop: a per-value select costs more than the multiply)
+            // d(SwiGLU) form: gate / up of m-tile i + 1 are requested before m-tile i is staged and converted -- with the lean staging
+            // code the loads of an m-tile issued at its top were not back when its d(act) segment was (1.56 -> 1.76 ms per launch)
+            sf_v8s gq[2][4], uq[2][4];
+            auto gu_load = [&](int i, int bufi) SF_INLINE_LAMBDA {
+                const long row0 = mc + wr * 128 + i * 16 + q;
+                const int col = nc + wc * 128 + r * 8;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const sf_bf16* gp = p.e.sw_gu + (row0 + 4 * s4) * p.e.sw_ldgu + col;
+                    gq[bufi][s4] = *reinterpret_cast<const sf_v8s*>(gp);
+                    uq[bufi][s4] = *reinterpret_cast<const sf_v8s*>(gp + p.N);
+                }
+            };
+            if constexpr (ADD == 2) gu_load(0, 0);
             auto tile_out = [&](auto UNIT) SF_INLINE_LAMBDA {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                w4_fence();   // keeps the AGPR -> VGPR copies of m-tile i + 1 out of m-tile i: hoisted, all 256 of them fill the VGPR
-                              // file and the four staging reads below share one register quad (read, wait, store, four times)
+                if constexpr (ADD == 2) { if (i + 1 < 8) gu_load(i + 1, (i + 1) & 1); }
+                // keeps the AGPR -> VGPR copies of m-tile i + 1 out of m-tile i: hoisted, all 256 of them fill the VGPR file and the four
+                // staging reads below share one register quad (read, wait, store, four times).  Not in the d(SwiGLU) form: its m-tiles
+                // load gate / up, and a fence keeps the next m-tile's loads from being issued under this one's stores (+0.2 ms per launch)
+                if constexpr (ADD != 2) w4_fence();
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     sf_v4f v;
@@ -619,20 +636,13 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                     // bf16 roundings are those of swiglu_bwd_kernel on the stored d(act)
                     const long row0 = mc + wr * 128 + i * 16 + q;
                     const int col = nc + wc * 128 + r * 8;
-                    sf_v8s gq[4], uq[4];
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const sf_bf16* gp = p.e.sw_gu + (row0 + 4 * s4) * p.e.sw_ldgu + col;
-                        gq[s4] = *reinterpret_cast<const sf_v8s*>(gp);
-                        uq[s4] = *reinterpret_cast<const sf_v8s*>(gp + p.N);
-                    }
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
                         const sf_v8s d = *reinterpret_cast<const sf_v8s*>(st + (4 * s4 + q) * kStageRow + r * 16);
                         float dg[8], du[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            sf_swiglu_bwd_elem<sf_bf16>(sf_bf2f((sf_bf16)gq[s4][e]), sf_bf2f((sf_bf16)uq[s4][e]),
+                            sf_swiglu_bwd_elem<sf_bf16>(sf_bf2f((sf_bf16)gq[i & 1][s4][e]), sf_bf2f((sf_bf16)uq[i & 1][s4][e]),
                                                         sf_bf2f((sf_bf16)d[e]), dg[e], du[e]);
                         sf_v4i og, ou;                       // (pairs by one v_cvt_pk_bf16_f32 each)
 #pragma unroll
