@@ -76,13 +76,15 @@ class KernelTimer:
             #   that carry a position mask (counted from the mask the launch is given)
             #   (recorded per element; summary() applies  4 + 4 * mask density  bytes -- no device read-back per launch)
             "ce_fused": ("ce_fused", lambda a, k: float(a[0].numel())),
+            #   ... with the soft target re-formed from the teacher's stored bf16 draft logits: 4 + 2 * mask density bytes per element
+            "ce_fused_zt": ("ce_fused_zt", lambda a, k: float(a[0].numel())),
             #   AdamW: grad bf16 r, master / m / v fp32 r+w, param bf16 w = 28 B per parameter
             "adamw_step": ("adamw_step", lambda a, k: 28.0 * a[0].numel()),
             #   teacher reduce: one bf16 read of the logits chunk + target_p fp32 write
             "teacher_reduce": ("teacher_reduce", lambda a, k: el(a[0]) + 4.0 * a[0].shape[0] * k["Vd"]),
             #   ... on the permuted head: the stored (draft) logits + 16 B per reduced 128-column block + the probabilities
             "teacher_reduce_perm": ("teacher_reduce_perm", lambda a, k: 2.0 * a[0].numel() + 16.0 * a[0].shape[0] * k.get("nparts", 0)
-                                    + 4.0 * a[0].shape[0] * k["Vd"]),
+                                    + (4.0 * a[0].shape[0] * k["Vd"] if k.get("target_p_pad") is not None else 0.0)),
         }
         for name, (attr, work) in fam.items():
             orig = getattr(ops, attr)
@@ -166,6 +168,8 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="run the gradient collectives even at world size 1 (RCCL path on a 1-GPU box)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (launcher smoke test)")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: all ranks on cuda:0 (with --dist-backend gloo)")
+    ap.add_argument("--materialise-targets", action="store_true",
+                    help="A/B: write the fp32 soft targets [B, S+T, Vd] instead of re-forming them in the fused CE from the teacher's draft logits")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -217,6 +221,7 @@ def main():
     backend = HipDPTrainingBackend(optimizer_factory=lambda m: BF16Optimizer(m, lr=1e-4, max_grad_norm=0.5, total_steps=10_000),
                                    single_collective=args.dp_single, force_collectives=args.force_dp)
     backend.prepare_model(eagle)
+    eagle.engine.materialise_soft_targets = args.materialise_targets
     batches = [TrainBatch(make_batch(cfg, B, S, dev, 100 + rank * 10 + i), {"target_repr": "hidden_state"}) for i in range(2)]
 
     def timed(strategy, nsteps, timer=None):
@@ -335,10 +340,12 @@ def main():
             "attn_bwd_dkv": kern("attn_bwd_dkv", "TFLOP/s", PEAK_BF16_TFLOPS, what="8 B nh hd S^2/2 (each product once)"),
             "ce_fused": kern("ce_fused", "GB/s", PEAK_HBM_GBS, scale=4.0 + 4.0 * density,
                              what=f"per logit: 2 B read + 2 B gradient written in place + 4 B soft target on the {density:.2f} of rows with a position mask"),
+            "ce_fused_zt": kern("ce_fused_zt", "GB/s", PEAK_HBM_GBS, scale=4.0 + 2.0 * density,
+                                what=f"per logit: 2 B read + 2 B gradient written in place + 2 B of the teacher's stored draft logit on the {density:.2f} of rows with a position mask (target_p re-formed, never materialised)"),
             "adamw_step": kern("adamw_step", "GB/s", PEAK_HBM_GBS, what="28 B per parameter"),
             "teacher_reduce": kern("teacher_reduce", "GB/s", PEAK_HBM_GBS, what="2 B per target logit read + 4 B per draft-vocabulary probability written"),
             "teacher_reduce_perm": kern("teacher_reduce_perm", "GB/s", PEAK_HBM_GBS,
-                                        what="2 B per STORED (draft) logit + 16 B per reduced column block + 4 B per draft-vocabulary probability written"),
+                                        what="2 B per STORED (draft) logit + 16 B per reduced column block (+ 4 B per draft-vocabulary probability when target_p is materialised)"),
         }
         fus = kernels["gemm_nt_swiglu_bwd"] or {}
         # the step as a whole against the MFMA roofline: SURVEY 8d's F_draft = 3 * (T * F_step + 2 * 3Ht * H) per token
@@ -363,7 +370,7 @@ def main():
                          "gemm_ms_per_step": gemm_ms / st},
             # every other hot kernel of the step, same method (HIP events on the launch stream over the timed region)
             "kernels": {k: v for k, v in kernels.items() if v is not None},
-            "roofline_hbm": kernels["ce_fused"],
+            "roofline_hbm": kernels["ce_fused_zt"] or kernels["ce_fused"],
             "draft_fwd_bwd": {"tflops_per_gpu": draft_tflops, "frac_of_mfma_peak": draft_tflops / PEAK_BF16_TFLOPS,
                               "flop_per_token": f_draft, "formula": "SURVEY 8d F_draft = 3 (T F_step + 2 * 3Ht * H)"},
             "final_loss": loss,

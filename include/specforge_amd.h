@@ -89,6 +89,15 @@ int sf_ce_fused(void* logits, int dtype, long ld, int rows, int V, const float* 
  * the KL mean factor 1/(B*S); accept_sum / mask_sum are device scalars: sum_r pos_mask_r*accept_r
  * (third output of sf_ce_fused, reduced) and sum_r pos_mask_r over the rows of this step.
  * Masked rows get zero gradient; ties of torch.minimum split the gradient evenly as torch does. */
+/* sf_ce_fused with the soft target given as the teacher's stored draft logits (ABI 4): zt [B*S, ldzt] bf16 in NATURAL token rows,
+ * zmd_pad / zinv_pad [B, Spad] from sf_teacher_reduce_perm; row r = b*S+s of TTT step `off` uses target_p[j] = exp(zt[b*S+s+off][j] -
+ * zmd) * zinv -- the expression the teacher kernel evaluates when it writes target_p, so results are bit-identical to sf_ce_fused on
+ * that array; 2 bytes per element instead of 4, and [B, S, Vd] fp32 is never written or read.  tsum_pad is required. */
+int sf_ce_fused_zt(void* logits, int dtype, long ld, int rows, int V, const void* zt, long ldzt, const float* zmd_pad,
+                   const float* zinv_pad, int S, int Spad, int off, const int* pos_mask_pad, const int* loss_mask_pad,
+                   const long long* tgt_ids_pad, const float* pod_scale_pad, const float* tsum_pad, const long long* d2t,
+                   float grad_scale, int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred,
+                   void* stream);
 int sf_ce_lk_grad(void* logits, int dtype, long ld, int rows, int V, const float* target, int S, int Spad, int off,
                   const int* pos_mask_pad, const float* pod_scale_pad, const float* tsum_pad, int lk_mode,
                   float kl_scale, float kl_decay, float step_scale, float kl_row_scale, const float* accept_sum,
@@ -120,11 +129,14 @@ int sf_teacher_reduce(const void* z, int dtype, long ldz, int rows, int Vt, int 
  * draft softmax reads Vd contiguous logits instead of gathering them through d2t.  Same outputs as sf_teacher_reduce (argmax in
  * original indices, lowest original index on ties).  z holds the first Vz >= Vd permuted columns; the columns from Vz on, if any,
  * arrive as `nparts` per-column-block partials {max, sum exp(z - max), argmax column, -} per row, block q of row r at
- * part[(r * part_stride + q) * 4] (written by sf_gemm_nt_teacher: those logits are never stored). */
+ * part[(r * part_stride + q) * 4] (written by sf_gemm_nt_teacher: those logits are never stored).
+ * zmd_pad / zinv_pad (optional, together): the row's draft maximum and 1 / sum exp(z_draft - max) at padded index b*Spad+s, i.e.
+ * target_p[j] = exp(z[j] - zmd) * zinv.  With them target_p_pad may be NULL: the probabilities are then never materialised and
+ * sf_ce_fused_zt re-forms them from the stored draft logits. */
 int sf_teacher_reduce_perm(const void* z, int dtype, long ldz, int rows, int Vz, int Vt, int Vd, const int* perm,
                            const unsigned char* t2d, const float* part, int nparts, long part_stride, const int* loss_mask_pad,
                            int S, int Spad, float* target_p_pad, float* pod_scale_pad, float* tsum_pad, long long* ids_pad,
-                           int* pos_mask_pad, void* stream);
+                           int* pos_mask_pad, float* zmd_pad, float* zinv_pad, void* stream);
 
 /* The teacher head GEMM for that layout (TargetHead.forward, target_head.py:93-101, on the row-permuted weight Wp [Vt, K]):
  * z = A . Wp^T in bf16.  With `part` given and a chip-filling shape, only the first *vz_out = roundup(Vd, 256) columns of z are
@@ -134,6 +146,9 @@ int sf_teacher_reduce_perm(const void* z, int dtype, long ldz, int rows, int Vz,
  * *nparts_out = 0.  z needs room for Vt columns either way.  Feed both to sf_teacher_reduce_perm (ABI 4). */
 int sf_gemm_nt_teacher(const void* A, long lda, const void* Wp, long ldw, int M, int Vt, int K, int Vd, void* z, long ldz, float* part,
                        long part_stride, int* vz_out, int* nparts_out, void* stream);
+/* 1 when sf_gemm_nt_teacher (given `part`) takes the reduced form for this shape: z then only needs roundup(Vd, 256) columns (ldz may be
+ * that narrow), e.g. the rows of a persistent [tokens, roundup(Vd, 256)] array of teacher draft logits that sf_ce_fused_zt reads. */
+int sf_gemm_nt_teacher_reduces(int M, int Vt, int K, int Vd);
 
 /* ---- RMSNorm (+frozen-embedding gather) ---------------------------------------------------
  * replaces llama3_eagle.py:1561-1567 (LlamaRMSNorm.forward), 1759-1760 (embed_input_ids) and

@@ -35,7 +35,10 @@ _SIGS = {
     "sf_teacher_reduce": (c_int, [P, c_int, c_long, c_int, c_int, c_int, P, P, P, c_int, c_int, P, P, P, P, P, P]),
     "sf_gemm_nt_teacher": (c_int, [P, c_long, P, c_long, c_int, c_int, c_int, c_int, P, c_long, P, c_long, P, P, P]),
     "sf_teacher_reduce_perm": (c_int, [P, c_int, c_long, c_int, c_int, c_int, c_int, P, P, P, c_int, c_long, P, c_int, c_int, P, P, P, P,
-                                       P, P]),
+                                       P, P, P, P]),
+    "sf_gemm_nt_teacher_reduces": (c_int, [c_int, c_int, c_int, c_int]),
+    "sf_ce_fused_zt": (c_int, [P, c_int, c_long, c_int, c_int, P, c_long, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_float, c_int, P, P,
+                               P, P, P]),
     "sf_rmsnorm_fwd": (c_int, [P, c_int, c_long, P, c_int, c_int, c_int, P, c_float, c_int, c_int, P, c_long, P, P]),
     "sf_rmsnorm_bwd_workspace_floats": (c_long, [c_int, c_int]),
     "sf_rmsnorm_bwd": (c_int, [P, c_int, c_long, P, c_long, P, c_int, c_int, c_int, P, P, c_int, c_int, P, c_long, P,

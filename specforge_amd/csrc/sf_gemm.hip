@@ -275,10 +275,25 @@ extern "C" int sf_gemm_nt_swiglu_fwd(const void* A, long lda, const void* Wgu, l
 // sf_teacher_reduce_perm).  When the chip-filling kernel takes the shape and `part` is given, only the first *vz_out =
 // roundup(Vd, 256) columns are stored; every later 128-column block of a row leaves as one {max, sum exp, argmax column, 0} record
 // in `part` (*nparts_out blocks, row-major: block q of row r at part[(r * part_stride + q) * 4]).  Otherwise all Vt columns are stored and *nparts_out = 0.  z must have room for Vt columns.
+// 1 when sf_gemm_nt_teacher (given `part`) takes the reduced form for this shape -- then z only needs roundup(Vd, 256) columns
+extern "C" int sf_gemm_nt_teacher_reduces(int M, int Vt, int K, int Vd) {
+#ifdef SF_EMU
+    const bool big = K >= 512;
+#else
+    const bool big = (long)((M + 255) / 256) * ((Vt + 255) / 256) >= 256 && K >= 512;
+#endif
+    static const int fuse = sf_knob("SF_GEMM_TEACHER_FUSE", 1);
+    const int vz = (Vd + 255) / 256 * 256;
+    return (fuse && big && Vd > 0 && vz < Vt && K % 64 == 0 && M >= 192 && sf_gemm_use_256()) ? 1 : 0;
+}
+
 extern "C" int sf_gemm_nt_teacher(const void* A, long lda, const void* Wp, long ldw, int M, int Vt, int K, int Vd, void* z, long ldz,
                                   float* part, long part_stride, int* vz_out, int* nparts_out, void* stream) {
     if (int st = sf_gemm_check(lda, ldw, ldz, 0, M, Vt, K, SF_BF16, nullptr)) return st;
-    SF_CHECK_ARG(Vd > 0 && Vd <= Vt && ldz >= Vt && vz_out && nparts_out, "sf_gemm_nt_teacher: bad shape / missing outputs");
+    const bool will_reduce = part && sf_gemm_nt_teacher_reduces(M, Vt, K, Vd) && part_stride >= (Vt - (Vd + 255) / 256 * 256 + 127) / 128 &&
+                             ((size_t)part & 15) == 0;
+    SF_CHECK_ARG(Vd > 0 && Vd <= Vt && vz_out && nparts_out && (ldz >= Vt || (will_reduce && ldz >= (Vd + 255) / 256 * 256)),
+                 "sf_gemm_nt_teacher: bad shape / missing outputs (z narrower than Vt columns needs the reduced form: sf_gemm_nt_teacher_reduces)");
     *vz_out = Vt;
     *nparts_out = 0;
     if (M == 0) return 0;
@@ -291,9 +306,9 @@ extern "C" int sf_gemm_nt_teacher(const void* A, long lda, const void* Wp, long 
 #else
     const bool big = (long)((M + 255) / 256) * ((Vt + 255) / 256) >= 256 && K >= 512;
 #endif
-    static const int fuse = sf_knob("SF_GEMM_TEACHER_FUSE", 1);
     const int vz = (Vd + 255) / 256 * 256;
-    if (fuse && part && big && vz < Vt && K % 64 == 0 && M >= 192 && part_stride >= (Vt - vz + 127) / 128 && ((size_t)part & 15) == 0 && sf_gemm_use_256()) {
+    (void)big;
+    if (will_reduce) {
         e.red_part = part; e.red_stride = part_stride; e.red_n0 = vz;
         *vz_out = vz;
         *nparts_out = (Vt - vz + 127) / 128;

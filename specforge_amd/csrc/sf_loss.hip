@@ -12,6 +12,7 @@
 // + dlogits 2*V (bf16, written in place) = 8*V bytes.
 #include "sf_api_internal.h"
 #include "sf_util.h"
+#include <type_traits>
 
 namespace {
 
@@ -46,12 +47,17 @@ SF_DEVICE void md_merge(float& m, float& d, float m2, float d2) {
 // (the TTT shift of step `off`: specforge/algorithms/eagle3/model.py:364-433 slices
 // target_p[:, idx:idx+S] and shifts ids/masks left with zero fill -- zero-padded tails
 // make the shift an offset).
-template <typename T>
+// ZT = 1: the soft target is not read as fp32 probabilities but formed on the fly from the teacher's stored draft logits,
+// p_j = exp(zt[row'][j] - zmd) * zinv with row' = b*S + s + off (NATURAL rows: a row with a position mask has s + off < S) and
+// (zmd, zinv) = the row's draft maximum and 1 / sum-exp from sf_teacher_reduce_perm -- the expression that kernel uses when it
+// writes target_p, so both forms give the same bits; 2 bytes per element instead of 4, and [B, S, Vd] fp32 is never written.
+template <typename T, int ZT = 0>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2)
 ce_fused_kernel(T* logits, long ld, int V, const float* target, int S, int Spad, int off,
                 const int* pos_mask_pad, const int* loss_mask_pad, const long long* tgt_ids_pad,
                 const float* pod_scale_pad, const float* tsum_pad, const long long* d2t, float grad_scale,
-                int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred) {
+                int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred,
+                const sf_bf16* zt = nullptr, long ldzt = 0, const float* zmd_pad = nullptr, const float* zinv_pad = nullptr) {
     SF_SHARED float red[32];
     SF_SHARED int redi[16];
     const int r = (int)blockIdx.x;
@@ -121,27 +127,34 @@ ce_fused_kernel(T* logits, long ld, int V, const float* target, int S, int Spad,
         am = am_pick(am, ArgMax{red[16 + i], redi[i]});
     }
     const float lse = m + sf_log(d);
-    const int pm = pos_mask_pad[pr];
+    const int pm = (ZT && s + off >= S) ? 0 : pos_mask_pad[pr];     // (ZT: padded positions have no teacher row; their mask is 0 anyway)
 
     float loss = 0.f, acc_min = 0.f;
     if (pm != 0) {
-        const float* tp = target + pr * (long)V;
+        const float* tp = ZT ? nullptr : target + pr * (long)V;
+        const sf_bf16* zr = ZT ? zt + ((long)b * S + s + off) * ldzt : nullptr;
+        const float zmd = ZT ? zmd_pad[pr] : 0.f, zinv = ZT ? zinv_pad[pr] : 0.f;
         const float podc = pod_scale_pad ? pod_scale_pad[pr] : 0.f;
         float tsum;
         if (tsum_pad) {
             tsum = tsum_pad[pr];
-        } else {  // drop-in LogSoftmaxLoss: sum of the target row (core/loss.py:113-170 pass 1)
+        } else {  // drop-in LogSoftmaxLoss: sum of the target row (core/loss.py:113-170 pass 1)   (never with ZT: its launcher requires tsum)
             float t = 0.f;
-            for (int j = tid; j < V; j += nt) t += tp[j];
+            for (int j = tid; j < V; j += nt) t += ZT ? 0.f : tp[j];
             tsum = sf_block_sum(t, red);
             sf_syncthreads();
         }
         const float gs = grad_scale * (float)pm;
-        auto chunk2 = [&](int c, const SfRaw8<T>& raw, const SfRaw8<float>& praw) {
+        using PRaw = std::conditional_t<ZT != 0, SfRaw8<sf_bf16>, SfRaw8<float>>;
+        auto pld = [&](PRaw& pr8, int c) {
+            if constexpr (ZT) pr8.ld(zr + c * 8);
+            else pr8.ld(tp + c * 8);
+        };
+        auto chunk2 = [&](int c, const SfRaw8<T>& raw, const PRaw& praw) {
             float g[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float pi = praw.at(i);
+                const float pi = ZT ? sf_exp_fast(praw.at(i) - zmd) * zinv : praw.at(i);
                 float lp = raw.at(i) - lse;
                 float sm = sf_exp_fast(lp);
                 loss -= pi * lp;
@@ -153,24 +166,24 @@ ce_fused_kernel(T* logits, long ld, int V, const float* target, int S, int Spad,
         int c = tid;
         for (; c + (PU - 1) * nt < V8; c += PU * nt) {
             SfRaw8<T> raw[PU];
-            SfRaw8<float> praw[PU];
+            PRaw praw[PU];
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 raw[u].ld(x + (c + u * nt) * 8);
-                praw[u].ld(tp + (c + u * nt) * 8);
+                pld(praw[u], c + u * nt);
             }
 #pragma unroll
             for (int u = 0; u < PU; ++u) chunk2(c + u * nt, raw[u], praw[u]);
         }
         for (; c < V8; c += nt) {
             SfRaw8<T> raw;
-            SfRaw8<float> praw;
+            PRaw praw;
             raw.ld(x + c * 8);
-            praw.ld(tp + c * 8);
+            pld(praw, c);
             chunk2(c, raw, praw);
         }
         for (int j = V8 * 8 + tid; j < V; j += nt) {
-            float v = SfElem<T>::ld(x + j), p = tp[j];
+            float v = SfElem<T>::ld(x + j), p = ZT ? sf_exp_fast(sf_bf2f(zr[j]) - zmd) * zinv : tp[j];
             float lp = v - lse, sm = sf_exp_fast(lp);
             loss -= p * lp;
             acc_min += fminf(p * podc, sm);
@@ -481,7 +494,8 @@ template <typename T>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2)
 teacher_reduce_perm_kernel(const T* z, long ldz, int Vz, int Vd, const int* perm, const unsigned char* t2d, const sf_v4f* part,
                            int nparts, long part_stride, const int* loss_mask_pad, int S, int Spad, float* target_p_pad,
-                           float* pod_scale_pad, float* tsum_pad, long long* ids_pad, int* pos_mask_pad) {
+                           float* pod_scale_pad, float* tsum_pad, long long* ids_pad, int* pos_mask_pad, float* zmd_pad,
+                           float* zinv_pad) {
     SF_SHARED float red[40];
     SF_SHARED int redi[16];
     const int r = (int)blockIdx.x;
@@ -594,7 +608,9 @@ teacher_reduce_perm_kernel(const T* z, long ldz, int Vz, int Vd, const int* perm
     }
     const float inv = 1.0f / sd;
     // draft softmax (torch.softmax: exp(x - max) / sum): Vd contiguous logits, still in L2 from the pass above
-    float* tp = target_p_pad + pr * (long)Vd;
+    // (target_p_pad == NULL: the probabilities are not materialised -- sf_ce_fused_zt re-forms them from the stored logits with
+    // (md, inv) below; their sum is still taken here, over the same values in the same per-lane order)
+    float* tp = target_p_pad ? target_p_pad + pr * (long)Vd : nullptr;
     float ts = 0.f;
     constexpr int GU = 2;
     int j = tid;
@@ -607,7 +623,7 @@ teacher_reduce_perm_kernel(const T* z, long ldz, int Vz, int Vd, const int* perm
             float pv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) { pv[i] = sf_exp_fast(raw[u].at(i) - md) * inv; ts += pv[i]; }
-            SfVec8<float>::st(tp + (j + u * nt) * 8, pv);
+            if (tp) SfVec8<float>::st(tp + (j + u * nt) * 8, pv);
         }
     }
     for (; j < D8; j += nt) {
@@ -616,10 +632,11 @@ teacher_reduce_perm_kernel(const T* z, long ldz, int Vz, int Vd, const int* perm
         float pv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { pv[i] = sf_exp_fast(raw.at(i) - md) * inv; ts += pv[i]; }
-        SfVec8<float>::st(tp + j * 8, pv);
+        if (tp) SfVec8<float>::st(tp + j * 8, pv);
     }
     ts = sf_block_sum(ts, red);
     if (tid == 0) {
+        if (zmd_pad) { zmd_pad[pr] = md; zinv_pad[pr] = inv; }
         pod_scale_pad[pr] = sd * sf_exp(md - lse_full);
         tsum_pad[pr] = ts;
         ids_pad[pr] = (long long)am.i;
@@ -698,7 +715,10 @@ extern "C" int sf_teacher_reduce(const void* z, int dtype, long ldz, int rows, i
 extern "C" int sf_teacher_reduce_perm(const void* z, int dtype, long ldz, int rows, int Vz, int Vt, int Vd, const int* perm,
                                       const unsigned char* t2d, const float* part, int nparts, long part_stride,
                                       const int* loss_mask_pad, int S, int Spad, float* target_p_pad, float* pod_scale_pad,
-                                      float* tsum_pad, long long* ids_pad, int* pos_mask_pad, void* stream) {
+                                      float* tsum_pad, long long* ids_pad, int* pos_mask_pad, float* zmd_pad, float* zinv_pad,
+                                      void* stream) {
+    SF_CHECK_ARG((zmd_pad != nullptr) == (zinv_pad != nullptr) && (target_p_pad || zmd_pad),
+                 "sf_teacher_reduce_perm: zmd_pad / zinv_pad come together; without target_p_pad they are required");
     SF_CHECK_ARG(rows >= 0 && Vt > 0 && Vd > 0 && Vd % 8 == 0 && Vz >= Vd && Vz <= Vt && S > 0 && Spad >= S, "sf_teacher_reduce_perm: bad shape");
     SF_CHECK_ARG(ldz % 8 == 0 && perm && t2d, "sf_teacher_reduce_perm: ldz must be a multiple of 8; perm / t2d required");
     SF_CHECK_ARG(nparts >= 0 && (nparts == 0 || (part && part_stride >= nparts && ((size_t)part & 15) == 0)), "sf_teacher_reduce_perm: bad partials");
@@ -706,10 +726,12 @@ extern "C" int sf_teacher_reduce_perm(const void* z, int dtype, long ldz, int ro
     if (rows == 0) return 0;
     if (dtype == SF_BF16)
         SF_LAUNCH((teacher_reduce_perm_kernel<sf_bf16>), dim3(rows), dim3(256), 0, stream, (const sf_bf16*)z, ldz, Vz, Vd, perm, t2d,
-                  (const sf_v4f*)part, nparts, part_stride, loss_mask_pad, S, Spad, target_p_pad, pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad);
+                  (const sf_v4f*)part, nparts, part_stride, loss_mask_pad, S, Spad, target_p_pad, pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad,
+                  zmd_pad, zinv_pad);
     else if (dtype == SF_F32)
         SF_LAUNCH((teacher_reduce_perm_kernel<float>), dim3(rows), dim3(256), 0, stream, (const float*)z, ldz, Vz, Vd, perm, t2d,
-                  (const sf_v4f*)part, nparts, part_stride, loss_mask_pad, S, Spad, target_p_pad, pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad);
+                  (const sf_v4f*)part, nparts, part_stride, loss_mask_pad, S, Spad, target_p_pad, pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad,
+                  zmd_pad, zinv_pad);
     else
         SF_CHECK_ARG(false, "sf_teacher_reduce_perm: dtype");
     return sf_check_launch("sf_teacher_reduce_perm");
@@ -720,4 +742,25 @@ extern "C" int sf_eagle3_metrics(const float* met, const int* loss_mask_pad, con
     SF_CHECK_ARG(B > 0 && S > 0 && T >= 1 && Spad >= S + T - 1 && met && loss_mask_pad && pos_mask_pad && out, "sf_eagle3_metrics: bad args");
     SF_LAUNCH(eagle3_metrics_kernel, dim3((unsigned)T), dim3(256), 0, stream, met, loss_mask_pad, pos_mask_pad, B, S, Spad, out);
     return sf_check_launch("sf_eagle3_metrics");
+}
+
+extern "C" int sf_ce_fused_zt(void* logits, int dtype, long ld, int rows, int V, const void* zt, long ldzt, const float* zmd_pad,
+                              const float* zinv_pad, int S, int Spad, int off, const int* pos_mask_pad, const int* loss_mask_pad,
+                              const long long* tgt_ids_pad, const float* pod_scale_pad, const float* tsum_pad, const long long* d2t,
+                              float grad_scale, int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred,
+                              void* stream) {
+    SF_CHECK_ARG(rows >= 0 && V > 0 && S > 0 && Spad >= S && off >= 0 && off + S <= Spad && rows % S == 0, "sf_ce_fused_zt: bad shape");
+    SF_CHECK_ARG(dtype == SF_BF16 || dtype == SF_F32, "sf_ce_fused_zt: dtype");
+    SF_CHECK_ARG(ld % 8 == 0 && V % 8 == 0 && ldzt % 8 == 0 && ldzt >= V, "sf_ce_fused_zt: ld, ldzt and V must be multiples of 8");
+    SF_CHECK_ARG(zt && zmd_pad && zinv_pad && tsum_pad && pos_mask_pad, "sf_ce_fused_zt: teacher logits, their row scalars and tsum are required");
+    if (rows == 0) return 0;
+    if (dtype == SF_BF16)
+        SF_LAUNCH((ce_fused_kernel<sf_bf16, 1>), dim3(rows), dim3(256), 0, stream, (sf_bf16*)logits, ld, V, (const float*)nullptr, S, Spad,
+                  off, pos_mask_pad, loss_mask_pad, tgt_ids_pad, pod_scale_pad, tsum_pad, d2t, grad_scale, write_grad,
+                  row_loss, row_correct, row_accept, row_pred, (const sf_bf16*)zt, ldzt, zmd_pad, zinv_pad);
+    else
+        SF_LAUNCH((ce_fused_kernel<float, 1>), dim3(rows), dim3(256), 0, stream, (float*)logits, ld, V, (const float*)nullptr, S, Spad,
+                  off, pos_mask_pad, loss_mask_pad, tgt_ids_pad, pod_scale_pad, tsum_pad, d2t, grad_scale, write_grad,
+                  row_loss, row_correct, row_accept, row_pred, (const sf_bf16*)zt, ldzt, zmd_pad, zinv_pad);
+    return sf_check_launch("sf_ce_fused_zt");
 }

@@ -78,6 +78,9 @@ class Eagle3Engine:
         self._regrown = False
         self._active = None                          # the shape whose constants are currently laid down
         self._pos_default = None                     # the (B, S) whose default position ids 0..S-1 sit in the shared `pos` buffer
+        self._tp_state = None                        # (B, S, storage) whose constant tails the materialised soft targets carry
+        self._soft = None                            # ("tp", tensor) | ("zt", (zd, zmd, zinv)): the last forward's soft-target form
+        self.materialise_soft_targets = False        # True: always write target_p [B, S+T, Vd] fp32 (A/B and inspection)
         self._wt_version = -1
         self.weights_version = 0          # bumped by the optimizer after every step
         self.micro_in_window = 0          # micro-steps accumulated into flat.grad since the last optimizer step
@@ -146,7 +149,7 @@ class Eagle3Engine:
         """the parts of the (shared) storage whose value the kernels rely on without writing it: padded tails of the
         teacher arrays (eagle3/model.py:445-484: 1/Vd, 0, 0), zero pad rows of the K-concatenated stashes"""
         Vd, T = self.cfg.draft_vocab_size, self.T
-        b["tp"][:, S:].fill_(1.0 / Vd)
+        self._tp_state = None      # (the shared `tp` storage, if any, was laid out for another shape: _target_p refills its tails)
         b["tsum"][:, S:].fill_(float(torch.full((Vd,), 1.0 / Vd).sum()))
         for nm in ("pod", "tids", "pm", "lm", "ids"):
             b[nm].zero_()
@@ -186,7 +189,10 @@ class Eagle3Engine:
         cv = self._carve
         b = dict(N=N, Spad=Spad)
         # teacher targets (padded tails are constants: 1/Vd, 0, 0 -- eagle3/model.py:445-484)
-        b["tp"] = cv("tp", B, Spad, Vd, dtype=f32)
+        # (the [B, Spad, Vd] fp32 soft targets are carved on demand (_target_p): the usual path never materialises them -- the fused
+        # CE re-forms them from the teacher's stored draft logits (teacher_zd) and the per-row (max, 1 / sum-exp) below)
+        b["zmd"] = cv("zmd", B, Spad, dtype=f32)
+        b["zinv"] = cv("zinv", B, Spad, dtype=f32)
         b["pod"] = cv("pod", B, Spad, dtype=f32)
         b["tsum"] = cv("tsum", B, Spad, dtype=f32)
         b["tids"] = cv("tids", B, Spad, dtype=i64)
@@ -267,6 +273,26 @@ class Eagle3Engine:
         # (+ 4096 floats at the tail: pace-keeping counters of sf_gemm_tn)
         b["tn_ws"] = cv("tn_ws", 2 * max(H * I, self.QW * H) + 4096, dtype=f32)
         return b
+
+    def _target_p(self, b, B: int, S: int) -> torch.Tensor:
+        """the materialised soft targets [B, S+T, Vd] fp32 (constant 1/Vd tails, eagle3/model.py:445-484) for the paths that need them:
+        online ``target_logits``, LK objectives, vocabulary mappings the permuted head cannot take, shapes too small for the reduced GEMM"""
+        Vd = self.cfg.draft_vocab_size
+        tp = self._carve("tp", B, S + self.T, Vd, dtype=torch.float32, invalidate=False)     # (never cached in a view dict)
+        if self._tp_state != (B, S, tp.data_ptr()):
+            tp[:, S:].fill_(1.0 / Vd)
+            self._tp_state = (B, S, tp.data_ptr())
+        self._soft = ("tp", tp)
+        return tp
+
+    def soft_targets(self, B: int, S: int) -> torch.Tensor:
+        """target_p [B, S, Vd] fp32 of the last forward, materialised from whichever form it used (inspection / tests)"""
+        kind, v = self._soft
+        if kind == "tp":
+            return v[:, :S]
+        zd, zmd, zinv = v
+        Vd = self.cfg.draft_vocab_size
+        return torch.exp(zd[:B * S, :Vd].float().view(B, S, Vd) - zmd[:, :S, None]) * zinv[:, :S, None]
 
     def _pad_heads(self, src: torch.Tensor, n: int, dst: torch.Tensor) -> None:
         """[N, n*hd] (any row stride) -> the first hd columns of each head of dst [N, n*hdp]; the pad columns stay zero"""
@@ -381,31 +407,51 @@ class Eagle3Engine:
         self._last_hs = hs
 
         # ---- teacher: target logits (chunked GEMM, bf16 like TargetHead.forward) -> soft targets
+        zt = None        # (zd, zmd, zinv) when the soft targets stay un-materialised (see below); else b["tp"] holds them
         if target_logits is not None:
             z = target_logits.reshape(N, -1)
             ops.teacher_reduce(z, Vd=Vd, d2t=self._d2t, t2d_u8=self._t2d_u8, loss_mask_pad=b["lm"], S=S, Spad=Spad,
-                               target_p_pad=b["tp"], pod_scale_pad=b["pod"], tsum_pad=b["tsum"], ids_pad=b["tids"],
+                               target_p_pad=self._target_p(b, B, S), pod_scale_pad=b["pod"], tsum_pad=b["tsum"], ids_pad=b["tids"],
                                pos_mask_pad=b["pm"])
         else:
             th = target_hidden.reshape(B, S, Ht)
             Vt = target_head_weight.shape[0]
             cb = max(1, self.teacher_rows // S)
-            zbuf = self._carve("teacher_z", min(cb, B) * S, Vt, invalidate=False)   # scratch: no cached view aliases it
             perm, head, ordered = self._permuted_teacher_head(target_head_weight)
             # per-block partials of the columns the head GEMM reduces instead of storing (only when ties inside a block resolve
             # to the lowest ORIGINAL index by column order alone, i.e. the mapping is ascending)
             part = self._carve("teacher_part", min(cb, B) * S, (Vt - Vd + 127) // 128, 4, dtype=torch.float32, invalidate=False) if ordered else None
-            for b0 in range(0, B, cb):
-                nb = min(cb, B - b0)
+            chunks = [(b0, min(cb, B - b0)) for b0 in range(0, B, cb)]
+            # The usual case -- every chunk takes the reduced head GEMM, no LK objective: the GEMM writes the draft logits of its rows
+            # straight into a persistent [N, roundup(Vd, 256)] bf16 array, the reduce kernel adds (max, 1 / sum-exp) per row, and the
+            # fused CE of each TTT step re-forms target_p from them.  [B, S, Vd] fp32 (2.1 GB at the headline shape, written once and
+            # read by 7 steps) does not exist; the scratch for a chunk's full-vocabulary logits neither.
+            if (part is not None and self.lk_loss_type is None and not self.materialise_soft_targets
+                    and all(ops.gemm_nt_teacher_reduces(nb * S, Vt, Ht, Vd) for _, nb in chunks)):
+                Vz = (Vd + 255) // 256 * 256
+                zd = self._carve("teacher_zd", N, Vz, invalidate=False)
+                zt = (zd, b["zmd"], b["zinv"])
+                self._soft = ("zt", zt)
+            else:
+                zbuf = self._carve("teacher_z", min(cb, B) * S, Vt, invalidate=False)   # scratch: no cached view aliases it
+            for b0, nb in chunks:
+                out = dict(loss_mask_pad=b["lm"][b0:b0 + nb], S=S, Spad=Spad, pod_scale_pad=b["pod"][b0:b0 + nb],
+                           tsum_pad=b["tsum"][b0:b0 + nb], ids_pad=b["tids"][b0:b0 + nb], pos_mask_pad=b["pm"][b0:b0 + nb])
+                x = th[b0:b0 + nb].reshape(nb * S, Ht)
+                if zt is not None:
+                    z = zd[b0 * S:(b0 + nb) * S]
+                    vz, nparts = ops.gemm_nt_teacher(x, head, z, part, Vd=Vd)
+                    assert vz == Vz and nparts > 0
+                    ops.teacher_reduce_perm(z, Vt=Vt, Vd=Vd, perm=perm, t2d_u8=self._t2d_u8, part=part, nparts=nparts, target_p_pad=None,
+                                            zmd_pad=b["zmd"][b0:b0 + nb], zinv_pad=b["zinv"][b0:b0 + nb], **out)
+                    continue
                 z = zbuf[: nb * S]
-                out = dict(loss_mask_pad=b["lm"][b0:b0 + nb], S=S, Spad=Spad, target_p_pad=b["tp"][b0:b0 + nb],
-                           pod_scale_pad=b["pod"][b0:b0 + nb], tsum_pad=b["tsum"][b0:b0 + nb], ids_pad=b["tids"][b0:b0 + nb],
-                           pos_mask_pad=b["pm"][b0:b0 + nb])
+                out["target_p_pad"] = self._target_p(b, B, S)[b0:b0 + nb]
                 if perm is not None:     # columns of z: the draft sub-vocabulary first, in draft order
-                    vz, nparts = ops.gemm_nt_teacher(th[b0:b0 + nb].reshape(nb * S, Ht), head, z, part, Vd=Vd)
+                    vz, nparts = ops.gemm_nt_teacher(x, head, z, part, Vd=Vd)
                     ops.teacher_reduce_perm(z[:, :vz], Vt=Vt, Vd=Vd, perm=perm, t2d_u8=self._t2d_u8, part=part, nparts=nparts, **out)
                 else:
-                    ops.gemm_nt(th[b0:b0 + nb].reshape(nb * S, Ht), head, z)
+                    ops.gemm_nt(x, head, z)
                     ops.teacher_reduce(z, Vd=Vd, d2t=self._d2t, t2d_u8=self._t2d_u8, **out)
 
         # ---- fc (optionally 3x RMSNorm first): llama3_eagle.py:1762-1770
@@ -467,10 +513,13 @@ class Eagle3Engine:
                 ln = b["h"][k + 1]
             ops.gemm_nt(ln, f.view("lm_head.weight"), logits)
             # loss + d(logits) in place + accuracy + acceptance; ploss_k = mean over ALL B*S rows
-            ops.ce_fused(logits, b["tp"], S=S, Spad=Spad, off=k, pos_mask_pad=b["pm"], loss_mask_pad=b["lm"],
-                         tgt_ids_pad=b["tids"], pod_scale_pad=b["pod"], tsum_pad=b["tsum"], d2t=self._d2t,
-                         grad_scale=(self.decay ** k) / N, write_grad=train and lk is None, row_loss=b["rows"][0],
-                         row_correct=b["rows"][1], row_accept=b["rows"][2])
+            ce_kw = dict(S=S, Spad=Spad, off=k, pos_mask_pad=b["pm"], loss_mask_pad=b["lm"], tgt_ids_pad=b["tids"], pod_scale_pad=b["pod"],
+                         tsum_pad=b["tsum"], d2t=self._d2t, grad_scale=(self.decay ** k) / N, write_grad=train and lk is None,
+                         row_loss=b["rows"][0], row_correct=b["rows"][1], row_accept=b["rows"][2])
+            if zt is not None:
+                ops.ce_fused_zt(logits, zt[0], zt[1], zt[2], **ce_kw)
+            else:
+                ops.ce_fused(logits, self._soft[1], **ce_kw)
             ops.reduce_sum(b["rows"], N, 3, b["metrics"][k], 1.0)
             if lk is not None:
                 # LK objectives (core/lk_loss.py:83-99): the step loss needs the masked MEANS over all rows, so the
@@ -478,7 +527,7 @@ class Eagle3Engine:
                 ra = b["rows"][2]
                 b["lk_logsum"][k] = torch.where(ra > 0, torch.log(ra), torch.zeros_like(ra)).sum()
                 if train:
-                    ops.ce_lk_grad(logits, b["tp"], S=S, Spad=Spad, off=k, pos_mask_pad=b["pm"],
+                    ops.ce_lk_grad(logits, self._soft[1], S=S, Spad=Spad, off=k, pos_mask_pad=b["pm"],
                                    pod_scale_pad=b["pod"], tsum_pad=b["tsum"], lk_loss_type=lk, kl_scale=self.kl_scale,
                                    kl_decay=self.kl_decay, step_scale=self.decay ** k, kl_row_scale=1.0 / N,
                                    accept_sum=b["metrics"][k][2:3], mask_sum=b["msum"][k:k + 1])

@@ -100,6 +100,21 @@ def ce_fused(logits: torch.Tensor, target_pad: torch.Tensor, *, S: int, Spad: in
                              _p(row_pred), _stream()), "sf_ce_fused")
 
 
+def ce_fused_zt(logits: torch.Tensor, zt: torch.Tensor, zmd_pad: torch.Tensor, zinv_pad: torch.Tensor, *, S: int, Spad: int, off: int,
+                pos_mask_pad, loss_mask_pad, tgt_ids_pad=None, pod_scale_pad=None, tsum_pad, d2t=None, grad_scale: float = 1.0,
+                write_grad: bool = True, row_loss, row_correct, row_accept, row_pred=None):
+    """ce_fused with the soft target re-formed from the teacher's stored draft logits ``zt`` [B*S, >= V] (natural rows) and the
+    per-row (max, 1 / sum-exp) of teacher_reduce_perm"""
+    L = _lib.lib()
+    rows, V = logits.shape
+    assert zt.dtype == torch.bfloat16 and zt.shape[0] >= rows and zt.shape[1] >= V
+    assert zmd_pad.dtype == zinv_pad.dtype == torch.float32 and zmd_pad.is_contiguous() and zinv_pad.is_contiguous()
+    _lib.check(L.sf_ce_fused_zt(_p(logits), _dt(logits), _rowmajor(logits), rows, V, _p(zt), _rowmajor(zt), _p(zmd_pad), _p(zinv_pad), S,
+                                Spad, off, _p(pos_mask_pad), _p(loss_mask_pad), _p(tgt_ids_pad), _p(pod_scale_pad), _p(tsum_pad), _p(d2t),
+                                grad_scale, 1 if write_grad else 0, _p(row_loss), _p(row_correct), _p(row_accept), _p(row_pred),
+                                _stream()), "sf_ce_fused_zt")
+
+
 def ce_lk_grad(logits: torch.Tensor, target_pad: torch.Tensor, *, S: int, Spad: int, off: int, pos_mask_pad, pod_scale_pad,
                tsum_pad=None, lk_loss_type: str, kl_scale: float, kl_decay: float, step_scale: float, kl_row_scale: float,
                accept_sum: torch.Tensor, mask_sum: torch.Tensor):
@@ -149,7 +164,7 @@ def gemm_nt_teacher(a: torch.Tensor, w_perm: torch.Tensor, z: torch.Tensor, part
     L = _lib.lib()
     M, K = a.shape
     Vt = w_perm.shape[0]
-    assert z.shape[0] >= M and z.shape[1] >= Vt and a.dtype == w_perm.dtype == z.dtype == torch.bfloat16
+    assert z.shape[0] >= M and a.dtype == w_perm.dtype == z.dtype == torch.bfloat16      # (z narrower than Vt: the C side checks)
     stride = 0
     if part is not None:
         assert part.dtype == torch.float32 and part.dim() == 3 and part.shape[2] == 4 and part.is_contiguous()
@@ -161,8 +176,12 @@ def gemm_nt_teacher(a: torch.Tensor, w_perm: torch.Tensor, z: torch.Tensor, part
     return vz.value, npart.value
 
 
+def gemm_nt_teacher_reduces(M: int, Vt: int, K: int, Vd: int) -> bool:
+    return bool(_lib.lib().sf_gemm_nt_teacher_reduces(M, Vt, K, Vd))
+
+
 def teacher_reduce_perm(z: torch.Tensor, *, Vt: int, Vd: int, perm, t2d_u8, loss_mask_pad, S: int, Spad: int, target_p_pad,
-                        pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad, part=None, nparts: int = 0):
+                        pod_scale_pad, tsum_pad, ids_pad, pos_mask_pad, part=None, nparts: int = 0, zmd_pad=None, zinv_pad=None):
     """teacher_reduce for logits with permuted columns (draft sub-vocabulary first; column c = vocabulary entry perm[c]).
     ``part`` [>= rows, part_stride, 4] fp32, ``nparts`` blocks per row in use: per-column-block partials of the columns z does not hold
     (sf_gemm_nt_teacher)."""
@@ -175,7 +194,8 @@ def teacher_reduce_perm(z: torch.Tensor, *, Vt: int, Vd: int, perm, t2d_u8, loss
         part_stride = part.shape[1]
     _lib.check(L.sf_teacher_reduce_perm(_p(z), _dt(z), _rowmajor(z), rows, Vz, Vt, Vd, _p(perm), _p(t2d_u8), _p(part) if nparts else None, nparts,
                                         part_stride, _p(loss_mask_pad), S, Spad, _p(target_p_pad), _p(pod_scale_pad),
-                                        _p(tsum_pad), _p(ids_pad), _p(pos_mask_pad), _stream()), "sf_teacher_reduce_perm")
+                                        _p(tsum_pad), _p(ids_pad), _p(pos_mask_pad), _p(zmd_pad), _p(zinv_pad), _stream()),
+               "sf_teacher_reduce_perm")
 
 
 def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, y: torch.Tensor, rstd: Optional[torch.Tensor], *,

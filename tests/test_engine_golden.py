@@ -211,6 +211,62 @@ def test_sequence_length_not_a_multiple_of_8(backend, B, S, lengths):
     assert max(worst.values()) <= 5e-2, worst
 
 
+def test_unmaterialised_soft_targets_equal_the_materialised_path(backend):
+    """A shape the reduced teacher-head GEMM takes (>= 192 rows, target hidden size 512, Vt past roundup(Vd, 256)): the engine keeps
+    the teacher's draft logits + (max, 1 / sum-exp) per row and the fused CE re-forms target_p from them; [B, S, Vd] fp32 never exists.
+    Same micro-step with that path switched off (materialised target_p): every metric and every gradient bit for bit; ids vs the oracle."""
+    from specforge_amd import ops
+    kw = dict(hidden_size=64, intermediate_size=96, num_attention_heads=2, num_key_value_heads=1, vocab_size=640,
+              draft_vocab_size=256, head_dim=64, target_hidden_size=512, max_position_embeddings=128, rms_norm_eps=1e-5)
+    B, S, T = 2, 96, 2
+    oc = O.DraftConfig(**kw)
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(8)
+    params = {k: (v.float() * 4).to(bf) if v.dim() > 1 else (1 + 0.1 * torch.randn(v.shape, generator=g)).to(bf)
+              for k, v in O.init_params(oc, seed=7).items()}
+    embed = (torch.randn(640, 64, generator=g) * 0.5).to(bf)
+    head_w = (torch.randn(640, 512, generator=g) * 0.2).to(bf)
+    t2d, d2t = O.make_vocab_mapping(640, 256, seed=5)
+    batch = O.make_batch(oc, B, S, seed=9, dtype=bf, lengths=[S, 71])
+
+    def run(materialise):
+        model = LlamaForCausalLMEagle3(DraftConfig(**kw), device=backend)
+        sd = dict(params)
+        sd["embed_tokens.weight"], sd["t2d"], sd["d2t"] = embed, t2d, d2t
+        model.load_state_dict(sd)
+        eagle = OnlineEagle3Model(model, length=T).train()
+        strat = Eagle3TrainStrategy(eagle, target_head=TargetHead(head_w.to(backend)))
+        orig = ops.gemm_nt_teacher_reduces
+        if materialise:
+            ops.gemm_nt_teacher_reduces = lambda *a: False
+        try:
+            out = strat.forward_loss(TrainBatch(dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"],
+                                                     loss_mask=batch["loss_mask"], hidden_state=batch["hidden_state"].to(backend),
+                                                     target=batch["target"].to(backend)), {"target_repr": "hidden_state"}))
+            out.loss.backward()
+        finally:
+            ops.gemm_nt_teacher_reduces = orig
+        kind = eagle.engine._soft[0]
+        mets = {k: torch.stack(v).float().cpu() for k, v in out.metrics.items() if isinstance(v, list)}
+        return kind, mets, eagle.engine.flat.grad.clone().cpu(), eagle.last_artifacts["target_token_ids"].cpu(), \
+            eagle.engine.soft_targets(B, S).cpu()
+
+    kind_a, met_a, grad_a, ids_a, tp_a = run(False)
+    kind_b, met_b, grad_b, ids_b, tp_b = run(True)
+    if str(backend) == "cpu":          # (the interpreter takes the reduced GEMM for every long-K shape; a GPU only for chip-filling ones)
+        assert (kind_a, kind_b) == ("zt", "tp")
+    assert torch.equal(ids_a, ids_b) and torch.equal(grad_a, grad_b)
+    for k in met_a:
+        assert torch.equal(met_a[k], met_b[k]), k
+    torch.testing.assert_close(tp_a, tp_b, rtol=1e-6, atol=1e-9)         # (torch.exp vs the kernels' v_exp_f32 in the inspection helper)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.eagle3_forward(p, oc, embed_weight=embed, target_head_weight=head_w, t2d=t2d, d2t=d2t, input_ids=batch["input_ids"],
+                           attention_mask=batch["attention_mask"], loss_mask=batch["loss_mask"],
+                           hidden_state=batch["hidden_state"], target_hidden=batch["target"], ttt_length=T)
+    assert float((ids_a == ref.target_token_ids).float().mean()) >= 0.98          # (bf16 accumulation-order near-ties of the head GEMM)
+    torch.testing.assert_close(met_a["plosses"], torch.stack([x.detach().float() for x in ref.plosses]), rtol=3e-2, atol=3e-2)
+
+
 def test_variable_length_batches_share_one_arena(backend, golden_dir):
     """the collator pads every batch to its own longest sample, so real data brings a new (B, S)
     almost every step.  All shapes run inside the storage reserved for the largest one -- HBM does not grow -- and a

@@ -53,10 +53,12 @@ def test_llama3_8b_seq2048_invariants():
     assert torch.isfinite(g1.float()).all()
 
     b = eng._buffers(B, S)
-    tp = b["tp"][:, :S]
+    assert eng._soft[0] == "zt"                      # the headline path never materialises [B, S, Vd] fp32 soft targets
+    tp = eng.soft_targets(B, S)
     torch.testing.assert_close(tp.sum(-1), torch.ones(B, S, device=dev), rtol=1e-4, atol=1e-4)   # distributions
     assert float(tp.min()) >= 0.0
-    assert float((b["tp"][:, S:] - 1.0 / cfg["draft_vocab_size"]).abs().max()) == 0.0          # padded tail = 1/Vd
+    torch.testing.assert_close(b["tsum"][:, :S], tp.sum(-1), rtol=1e-5, atol=1e-6)
+    assert float((b["tsum"][:, S:] - float(torch.full((cfg["draft_vocab_size"],), 1.0 / cfg["draft_vocab_size"]).sum())).abs().max()) == 0.0   # padded tail
     tid, pm, lm = b["tids"][:, :S], b["pm"][:, :S], b["lm"][:, :S]
     assert torch.equal(pm, (t2d.to(dev)[tid].int() * lm))                                          # bit-exact
     assert int(pm[:, :100].sum()) == 0 and int(pm[1, 1499:].sum()) == 0

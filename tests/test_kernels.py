@@ -359,6 +359,54 @@ def test_teacher_reduce_perm(backend, dtype, Vt, Vd):
     assert float((tp_pad.cpu()[:, S:] - 1.0 / Vd).abs().max()) == 0    # padded tail untouched
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ce_fused_from_teacher_logits_equals_materialised_targets(backend, dtype):
+    """sf_ce_fused_zt (soft target re-formed from the teacher's stored draft logits + per-row max / 1/sum-exp) == sf_ce_fused on the
+    target_p array the same teacher kernel writes: losses, in-place gradients, accuracy and acceptance bit for bit, at two TTT offsets"""
+    B, S, T, Vt, Vd = 2, 12, 3, 640, 384
+    Spad = S + T
+    g = torch.Generator().manual_seed(21)
+    zfull = (torch.randn(B * S, Vt, generator=g) * 3).to(torch.bfloat16)
+    t2d, d2t = O.make_vocab_mapping(Vt, Vd, seed=4)
+    perm = torch.cat([torch.arange(Vd) + d2t, torch.nonzero(~t2d.bool()).flatten()])
+    zp = zfull[:, perm].contiguous()
+    d = lambda t: t.to(backend)
+    lm_pad = torch.zeros(B, Spad, dtype=torch.int32)
+    lm_pad[:, :S] = (torch.rand(B, S, generator=g) > 0.2).int()
+    tp = torch.full((B, Spad, Vd), 1.0 / Vd, device=backend)
+    o = dict(pod_scale_pad=torch.zeros(B, Spad, device=backend), tsum_pad=torch.full((B, Spad), 1.0, device=backend),
+             ids_pad=torch.zeros(B, Spad, dtype=torch.int64, device=backend), pos_mask_pad=torch.zeros(B, Spad, dtype=torch.int32, device=backend))
+    zmd, zinv = torch.zeros(B, Spad, device=backend), torch.zeros(B, Spad, device=backend)
+    kw = dict(Vt=Vt, Vd=Vd, perm=d(perm.to(torch.int32)), t2d_u8=d(t2d.to(torch.uint8)), loss_mask_pad=d(lm_pad), S=S, Spad=Spad)
+    ops.teacher_reduce_perm(d(zp), target_p_pad=tp, zmd_pad=zmd, zinv_pad=zinv, **kw, **o)
+    o2 = {k: torch.zeros_like(v) for k, v in o.items()}
+    zmd2, zinv2 = torch.zeros_like(zmd), torch.zeros_like(zinv)
+    ops.teacher_reduce_perm(d(zp), target_p_pad=None, zmd_pad=zmd2, zinv_pad=zinv2, **kw, **o2)      # no materialised probabilities
+    for k in o:
+        assert torch.equal(o[k].cpu()[:, :S], o2[k].cpu()[:, :S]), k
+    assert torch.equal(zmd.cpu(), zmd2.cpu()) and torch.equal(zinv.cpu(), zinv2.cpu())
+    zd = torch.zeros(B * S, Vd + 8, dtype=torch.bfloat16)                                             # the stored draft logits (wider rows)
+    zd[:, :Vd] = zp[:, :Vd]
+    for off in (0, 2):
+        logits = (torch.randn(B * S, Vd, generator=g) * 2).to(dtype)
+        outs = []
+        for form in ("tp", "zt"):
+            x = d(logits.clone())
+            rows = [torch.zeros(B * S, device=backend) for _ in range(3)]
+            pred = torch.zeros(B * S, dtype=torch.int32, device=backend)
+            common = dict(S=S, Spad=Spad, off=off, pos_mask_pad=o["pos_mask_pad"], loss_mask_pad=d(lm_pad), tgt_ids_pad=o["ids_pad"],
+                          pod_scale_pad=o["pod_scale_pad"], tsum_pad=o["tsum_pad"], d2t=d(d2t), grad_scale=0.37, write_grad=True,
+                          row_loss=rows[0], row_correct=rows[1], row_accept=rows[2], row_pred=pred)
+            if form == "tp":
+                ops.ce_fused(x, tp, **common)
+            else:
+                ops.ce_fused_zt(x, d(zd), zmd, zinv, **common)
+            outs.append([x.cpu()] + [r.cpu() for r in rows] + [pred.cpu()])
+        for a, b_ in zip(*outs):
+            assert torch.equal(a, b_)
+        assert float(outs[0][1].abs().sum()) > 0          # (some rows carry a position mask at this offset)
+
+
 @pytest.mark.parametrize("M,Vt,Vd,K", [(512, 1000, 256, 512),     # reduced range 256 .. 999: 6 blocks, the last one partly past Vt
                                        (300, 1408, 200, 576),     # ragged rows, Vd not a multiple of 256, Vt a multiple of 128 only
                                        (256, 512, 512, 512)])     # Vz == Vt: nothing to reduce, everything stored

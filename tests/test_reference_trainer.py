@@ -195,7 +195,10 @@ def test_reference_evaluator_runs_over_the_hip_strategy(ref, golden_dir, tmp_pat
             opt = lambda m: BF16Optimizer(m, lr=c["lr"], max_grad_norm=c["max_grad_norm"], warmup_ratio=c["warmup_ratio"], total_steps=c["steps"])
         trainer = build_offline_runtime(algorithm=alg, draft_model=model, target_head=head, optimizer_factory=opt, run_id=f"eval-{kind}",
                                         output_dir=os.path.join(str(tmp_path), f"out-{kind}"), **common)
-        res[kind] = trainer._controller.evaluate_configured()
+        try:
+            res[kind] = trainer._controller.evaluate_configured()
+        finally:
+            ref.uninstall()
         assert model.training                       # evaluate() restores the training mode it found
     want, got = res["ref"], res["hip"]
     assert want and set(got) == set(want) and any(k.startswith("eval/") for k in want)
@@ -266,6 +269,8 @@ def test_reference_tiny_fixture_head_dim_16_trains_unmodified(ref, tmp_path):
     the zero-padded-heads path of the engine (engine.py), ttt_length 9 on more than 8 diagonal branches."""
     import importlib.util
 
+    ref.uninstall()        # (an earlier test of this process may have left the HIP backend / optimizer bound into the reference's modules:
+    #                         the names imported below, and the first run, must be the PURE reference)
     from specforge.algorithms.builtin import builtin_algorithm_registry
     from specforge.algorithms.eagle3.model import OnlineEagle3Model as RefOnline
     from specforge.launch import build_offline_runtime
