@@ -124,3 +124,31 @@ def test_dkv_register_bank_is_untouched_by_the_compiler():
         # bank = 2 * hd/32 accumulator tiles of 16 + 2 * hd/16 fragments of 4 AGPRs on top of the compiler's VGPRs
         bank = 32 * (hd // 32) + 8 * (hd // 16)
         assert md["vgpr_count"] - bank <= 256 and md["vgpr_count"] <= 512, (name, md["vgpr_count"])
+
+
+@hipcc
+@pytest.mark.parametrize("unit", ["sf_gemm256w4_i%d.hip" % i for i in range(7)])
+def test_nt_gemm_main_loop_is_the_planned_stream_in_every_epilogue_variant(unit):
+    """The 4-wave NT GEMM is compiled once per epilogue form (plain, fp32, row addend, d(SwiGLU), SwiGLU forward, teacher reduction), and
+    hipcc's register allocation of the whole kernel moves with the epilogue code.  Whatever the epilogue: the K loop of every
+    instantiation must be the planned stream -- 128 MFMAs, 32 fragment reads, 16 LDS-DMA pieces (asm), 3 barriers -- with no scratch
+    access, no accumulator copy and no compiler-inserted vmcnt wait inside it."""
+    txt = _asm(unit)
+    ks = _kernels(txt, "gemm_nt_256w4_kernel")
+    assert len(ks) == 2, (unit, list(ks))                        # both operand-order plans
+    for name, (body, md) in ks.items():
+        blocks, cur = [], []
+        for l in body:
+            if re.match(r"^\.LBB\d+_\d+:", l):
+                blocks.append(cur)
+                cur = []
+            cur.append(l)
+        blocks.append(cur)
+        loop = max(blocks, key=lambda b: sum("v_mfma" in x for x in b))
+        ins = [t for t, _ in _compiler_lines(loop)]
+        count = lambda pat: sum(1 for t in ins if re.match(pat, t))
+        assert count(r"v_mfma_f32_16x16x32_bf16") == 128, (name, count(r"v_mfma"))
+        assert count(r"ds_read_b128") == 32 and count(r"buffer_load_dwordx4") == 16 and count(r"s_barrier") == 3, name
+        assert not [t for t in ins if t.startswith("scratch_") or "accvgpr" in t], name
+        assert not [t for t, inasm in _compiler_lines(loop) if not inasm and t.startswith("s_waitcnt") and "vmcnt" in t], name
+        assert len(ins) <= 260, (name, len(ins))                 # 243-245 today: nothing crept into the loop
