@@ -126,13 +126,28 @@ def test_dkv_register_bank_is_untouched_by_the_compiler():
         assert md["vgpr_count"] - bank <= 256 and md["vgpr_count"] <= 512, (name, md["vgpr_count"])
 
 
+_W4_UNITS = ["sf_gemm256w4_i%d.hip" % i for i in range(7)]
+_w4_compiled = []
+
+
+def _compile_w4_units_once():
+    """all seven translation units to ISA concurrently (one at a time they add ~4 minutes to a cold CPU suite)"""
+    if not _w4_compiled:
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 2)) as ex:
+            list(ex.map(_asm, _W4_UNITS))
+        _w4_compiled.append(True)
+
+
 @hipcc
-@pytest.mark.parametrize("unit", ["sf_gemm256w4_i%d.hip" % i for i in range(7)])
+@pytest.mark.parametrize("unit", _W4_UNITS)
 def test_nt_gemm_main_loop_is_the_planned_stream_in_every_epilogue_variant(unit):
     """The 4-wave NT GEMM is compiled once per epilogue form (plain, fp32, row addend, d(SwiGLU), SwiGLU forward, teacher reduction), and
     hipcc's register allocation of the whole kernel moves with the epilogue code.  Whatever the epilogue: the K loop of every
     instantiation must be the planned stream -- 128 MFMAs, 32 fragment reads, 16 LDS-DMA pieces (asm), 3 barriers -- with no scratch
     access, no accumulator copy and no compiler-inserted vmcnt wait inside it."""
+    _compile_w4_units_once()
     txt = _asm(unit)
     ks = _kernels(txt, "gemm_nt_256w4_kernel")
     assert len(ks) == 2, (unit, list(ks))                        # both operand-order plans
