@@ -156,6 +156,11 @@ int sf_gemm_nt_teacher_reduces(int M, int Vt, int K, int Vd);
  * ids_pad != NULL: row r reads x + ids_pad[b*Spad+s+off]*ldx (x is the embedding table). */
 int sf_rmsnorm_fwd(const void* x, int dtype, long ldx, const long long* ids_pad, int S, int Spad, int off,
                    const void* w, float eps, int rows, int H, void* y, long ldy, float* rstd, void* stream);
+/* two norms of the SAME rows with two weight vectors in one pass over x (ABI 4): y1 = w1 * round(x * rstd), y2 = w2 * round(x * rstd);
+ * rstd1 / rstd2 (optional) both receive the row's rstd.  The final norm of TTT step k (llama3_eagle.py:1772-1777) and the hidden_norm of
+ * step k + 1 (1625-1630) read the same hidden state.  Same bits as two sf_rmsnorm_fwd calls. */
+int sf_rmsnorm_fwd2(const void* x, int dtype, long ldx, const void* w1, void* y1, long ldy1, float* rstd1, const void* w2, void* y2,
+                    long ldy2, float* rstd2, float eps, int rows, int H, void* stream);
 long sf_rmsnorm_bwd_workspace_floats(int rows, int H);
 /* dx (optional) = add (optional) + d/dx; dw_acc[H] (optional, fp32) = or += d/dw. */
 int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* x, long ldx, const long long* ids_pad, int S,

@@ -18,10 +18,13 @@ constexpr int kNormVecs = 4;  // 256 threads x 4 x 8 = 8192 columns max
 
 // ------------------------------------------------------------------ RMSNorm
 // y[r, :] = w * round_T(x[r, :] * rstd[r]); optional row gather x_row = table[ids_pad[b*Spad+s+off]]
+// (w2 / y2 / rstd2_out, optional: a SECOND norm of the same row with another weight vector -- the final norm of TTT step k and the
+// hidden_norm of step k + 1 both read h[k+1]; one pass over x, one row statistic, two outputs)
 template <typename T>
 SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2)
 rmsnorm_fwd_kernel(const T* x, long ldx, const long long* ids_pad, int S, int Spad, int off, const T* w, float eps,
-                   int H, T* y, long ldy, float* rstd_out) {
+                   int H, T* y, long ldy, float* rstd_out, const T* w2 = nullptr, T* y2 = nullptr, long ldy2 = 0,
+                   float* rstd2_out = nullptr) {
     SF_SHARED float red[16];
     const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
     const T* xr;
@@ -45,16 +48,24 @@ rmsnorm_fwd_kernel(const T* x, long ldx, const long long* ids_pad, int S, int Sp
     ss = sf_block_sum(ss, red);
     const float rstd = sf_rsqrt(ss / (float)H + eps);
     if (tid == 0 && rstd_out) rstd_out[r] = rstd;
+    if (tid == 0 && rstd2_out) rstd2_out[r] = rstd;
     T* yr = y + (long)r * ldy;
+    T* yr2 = y2 ? y2 + (long)r * ldy2 : nullptr;
 #pragma unroll
     for (int i = 0; i < kNormVecs; ++i) {
         const int col = (tid + i * 256) * 8;
         if (col < H) {
-            float wv[8], o[8];
+            float wv[8], o[8], xh[8];
             SfVec8<T>::ld(w + col, wv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = wv[j] * SfElem<T>::rnd(c[i][j] * rstd);
+            for (int j = 0; j < 8; ++j) { xh[j] = SfElem<T>::rnd(c[i][j] * rstd); o[j] = wv[j] * xh[j]; }
             SfVec8<T>::st(yr + col, o);
+            if (yr2) {   // (uniform)
+                SfVec8<T>::ld(w2 + col, wv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = wv[j] * xh[j];
+                SfVec8<T>::st(yr2 + col, o);
+            }
         }
     }
 }
@@ -374,6 +385,16 @@ extern "C" int sf_rmsnorm_fwd(const void* x, int dtype, long ldx, const long lon
     SF_DISPATCH_T(dtype, SF_LAUNCH((rmsnorm_fwd_kernel<T>), dim3(rows), dim3(256), 0, stream, (const T*)x, ldx, ids_pad, S,
                                    Spad, off, (const T*)w, eps, H, (T*)y, ldy, rstd));
     return sf_check_launch("sf_rmsnorm_fwd");
+}
+
+extern "C" int sf_rmsnorm_fwd2(const void* x, int dtype, long ldx, const void* w1, void* y1, long ldy1, float* rstd1, const void* w2,
+                               void* y2, long ldy2, float* rstd2, float eps, int rows, int H, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && H > 0 && H % 8 == 0 && H <= 256 * 8 * kNormVecs, "sf_rmsnorm_fwd2: H must be a multiple of 8, <= 8192");
+    SF_CHECK_ARG(ldx % 8 == 0 && ldy1 % 8 == 0 && ldy2 % 8 == 0 && w1 && y1 && w2 && y2, "sf_rmsnorm_fwd2: strides must be multiples of 8; both outputs required");
+    if (rows == 0) return 0;
+    SF_DISPATCH_T(dtype, SF_LAUNCH((rmsnorm_fwd_kernel<T>), dim3(rows), dim3(256), 0, stream, (const T*)x, ldx, (const long long*)nullptr, 1,
+                                   1, 0, (const T*)w1, eps, H, (T*)y1, ldy1, rstd1, (const T*)w2, (T*)y2, ldy2, rstd2));
+    return sf_check_launch("sf_rmsnorm_fwd2");
 }
 
 extern "C" long sf_rmsnorm_bwd_workspace_floats(int rows, int H) {

@@ -485,7 +485,8 @@ class Eagle3Engine:
         for k in range(T):
             hn, qkv, pn, act, logits = b["hn"][k], b["qkv"][k], b["pn"][k], b["act"][k], b["logits"][k]
             # q/k/v of cat(input_layernorm(embed(ids<<k)), hidden_norm(h_k))   (llama3_eagle.py:1625-1630)
-            ops.rmsnorm_fwd(b["h"][k], f.view("midlayer.hidden_norm.weight"), eps, hn, b["rstd_h"][k])
+            if k == 0 or not c.norm_output:     # (for k >= 1 the final norm of step k - 1 wrote hn[k] in the same pass over h[k])
+                ops.rmsnorm_fwd(b["h"][k], f.view("midlayer.hidden_norm.weight"), eps, hn, b["rstd_h"][k])
             ops.gemm_nt_rowadd(hn, self.w_qkv[:, H:], qkv, b["epart"], S=S, Spad=Spad, off=k)
             if self.mrope:
                 ops.rope_(qkv, nh + nkv, hd, b["cos_rows"][k], b["sin_rows"][k], b["pos"], 0)
@@ -508,7 +509,11 @@ class Eagle3Engine:
             ops.gemm_nt(act, f.view("midlayer.mlp.down_proj.weight"), b["h"][k + 1], residual=b["h1"][k])
             if c.norm_output:   # compute_logits (llama3_eagle.py:1772-1777)
                 ln = b["ln"][k]
-                ops.rmsnorm_fwd(b["h"][k + 1], f.view("norm.weight"), eps, ln, b["rstd_n"][k])
+                if k + 1 < T:       # ... and the next step's hidden_norm of the same h[k+1]: one pass, one row statistic
+                    ops.rmsnorm_fwd2(b["h"][k + 1], f.view("norm.weight"), ln, b["rstd_n"][k], f.view("midlayer.hidden_norm.weight"),
+                                     b["hn"][k + 1], b["rstd_h"][k + 1], eps)
+                else:
+                    ops.rmsnorm_fwd(b["h"][k + 1], f.view("norm.weight"), eps, ln, b["rstd_n"][k])
             else:
                 ln = b["h"][k + 1]
             ops.gemm_nt(ln, f.view("lm_head.weight"), logits)

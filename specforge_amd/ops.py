@@ -208,6 +208,15 @@ def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, y: torch.Tensor, r
     return y
 
 
+def rmsnorm_fwd2(x: torch.Tensor, w1: torch.Tensor, y1: torch.Tensor, rstd1, w2: torch.Tensor, y2: torch.Tensor, rstd2, eps: float):
+    """y1 = rmsnorm(x; w1), y2 = rmsnorm(x; w2) in one pass over x (same bits as two rmsnorm_fwd calls)"""
+    L = _lib.lib()
+    rows, H = y1.shape
+    assert y2.shape == (rows, H) and w1.numel() == w2.numel() == H and x.dtype == y1.dtype == y2.dtype
+    _lib.check(L.sf_rmsnorm_fwd2(_p(x), _dt(x), _rowmajor(x), _p(w1), _p(y1), _rowmajor(y1), _p(rstd1), _p(w2), _p(y2), _rowmajor(y2),
+                                 _p(rstd2), eps, rows, H, _stream()), "sf_rmsnorm_fwd2")
+
+
 def rmsnorm_bwd_workspace(rows: int, H: int) -> int:
     return int(_lib.lib().sf_rmsnorm_bwd_workspace_floats(rows, H))
 

@@ -320,6 +320,26 @@ def test_teacher_reduce(backend, dtype, Vt, Vd):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,H", [(20, 128), (19, 4096)])
+def test_rmsnorm_fwd2_equals_two_norms(backend, dtype, R, H):
+    x = _rand((R, H), dtype, 1)
+    w1 = (1 + 0.1 * _rand((H,), torch.float32, 2)).to(dtype)
+    w2 = (1 + 0.1 * _rand((H,), torch.float32, 3)).to(dtype)
+    d = lambda t: t.to(backend)
+    ya, yb = torch.empty((R, H), dtype=dtype, device=backend), torch.empty((R, H), dtype=dtype, device=backend)
+    ra, rb = torch.empty(R, device=backend), torch.empty(R, device=backend)
+    ops.rmsnorm_fwd(d(x), d(w1), 1e-5, ya, ra)
+    ops.rmsnorm_fwd(d(x), d(w2), 1e-5, yb, rb)
+    wide = torch.zeros((R, 2 * H + 16), dtype=dtype, device=backend)          # strided outputs
+    y1, y2 = wide[:, :H], wide[:, H + 16:]
+    r1, r2 = torch.empty(R, device=backend), torch.empty(R, device=backend)
+    ops.rmsnorm_fwd2(d(x), d(w1), y1, r1, d(w2), y2, r2, 1e-5)
+    assert torch.equal(y1.cpu(), ya.cpu()) and torch.equal(y2.cpu(), yb.cpu())
+    assert torch.equal(r1.cpu(), ra.cpu()) and torch.equal(r2.cpu(), rb.cpu())
+    assert float(wide[:, H:H + 16].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Vt,Vd", [(640, 64), (1000, 96), (2056, 512)])
 def test_teacher_reduce_perm(backend, dtype, Vt, Vd):
     """logits with permuted columns (draft sub-vocabulary first): the same targets as the reference's _compute_target_p on the
