@@ -57,8 +57,11 @@ def run(seqs, ragged, steps):
     return dict(seqs=seqs, ragged=ragged, steps=steps, ms_per_step=1e3 * el / steps, tokens_per_s=tok / el, final_loss=float(out.loss))
 
 
-res = [run([2048], False, 8),
-       run([2048, 1999, 1873, 2011, 1777, 1931, 2047, 1685], True, 16),     # a new (B, S) every step, nothing a multiple of 64
-       run([2048], False, 8)]
+if "--ragged-only" in sys.argv:      # (for a kernel trace of the ragged steps alone)
+    res = [run([2048, 1999, 1873, 2011, 1777, 1931, 2047, 1685], True, 8)]
+else:
+    res = [run([2048], False, 8),
+           run([2048, 1999, 1873, 2011, 1777, 1931, 2047, 1685], True, 16),     # a new (B, S) every step, nothing a multiple of 64
+           run([2048], False, 8)]
 for r in res:
     print(json.dumps(r))
