@@ -168,6 +168,14 @@ int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* x, long ldx
                    long ldadd, void* dx, long lddx, float* dw_acc, int dw_accumulate, float* workspace,
                    void* stream);
 
+/* Two RMSNorm backwards of the SAME rows x in one pass (ABI 4): dx = d_norm(dy1; w1) + d_norm(dy2; w2) + add (optional), dw1_acc (+)=
+ * d/dw1, dw2_acc (+)= d/dw2 (fp32).  H <= 4096; workspace = 2 x sf_rmsnorm_bwd_workspace_floats(rows, H) floats.  In the TTT sweep the
+ * hidden state of step k feeds the final norm of step k - 1 (llama3_eagle.py:1772-1777) and the hidden_norm of step k (1625-1630): autograd
+ * sums the two input gradients; run apart they read x twice and round the first partial sum to bf16. */
+int sf_rmsnorm_bwd2(const void* dy1, long lddy1, const void* w1, float* dw1_acc, int dw1_accumulate, const void* dy2, long lddy2,
+                    const void* w2, float* dw2_acc, int dw2_accumulate, int dtype, const void* x, long ldx, const float* rstd, int rows,
+                    int H, const void* add, long ldadd, void* dx, long lddx, float* workspace, void* stream);
+
 /* ---- RoPE in place on `nheads` consecutive heads (llama3_eagle.py:133-142; positions
  * position_ids + pos_off as in 718-734); backward = transposed rotation. */
 int sf_rope(void* x, int dtype, long ld, int rows, int nheads, int hd, const void* cos_t, const void* sin_t,

@@ -41,6 +41,7 @@ _SIGS = {
                                P, P, P]),
     "sf_rmsnorm_fwd": (c_int, [P, c_int, c_long, P, c_int, c_int, c_int, P, c_float, c_int, c_int, P, c_long, P, P]),
     "sf_rmsnorm_fwd2": (c_int, [P, c_int, c_long, P, P, c_long, P, P, P, c_long, P, c_float, c_int, c_int, P]),
+    "sf_rmsnorm_bwd2": (c_int, [P, c_long, P, P, c_int, P, c_long, P, P, c_int, c_int, P, c_long, P, c_int, c_int, P, c_long, P, c_long, P, P]),
     "sf_rmsnorm_bwd_workspace_floats": (c_long, [c_int, c_int]),
     "sf_rmsnorm_bwd": (c_int, [P, c_int, c_long, P, c_long, P, c_int, c_int, c_int, P, P, c_int, c_int, P, c_long, P,
                                c_long, P, c_int, P, P]),

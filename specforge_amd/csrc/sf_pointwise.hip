@@ -164,6 +164,88 @@ rmsnorm_bwd_kernel(const T* dy, long lddy, const T* x, long ldx, const long long
     }
 }
 
+// Two norms of the SAME x in one backward pass: dx = d_norm1(dy1; w1) + d_norm2(dy2; w2) + add.  The backward of RMSNorm is linear in
+// g = dy * w for a fixed x, so  dx = rstd * ((g1 + g2) - xhat * mean((g1 + g2) * xhat)) + add;  only the weight gradients stay apart
+// (dw_i += dy_i * xhat).  In the TTT sweep h[k] feeds both the final norm of step k - 1 and the hidden_norm of step k: run apart they
+// read x twice and pass a bf16 intermediate through HBM (and round it once more).  H <= 4096 (NV <= 2: the row groups stay in registers).
+template <typename T, int NV>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2)
+rmsnorm_bwd2_kernel(const T* dy1, long lddy1, const T* w1, const T* dy2, long lddy2, const T* w2, const T* x, long ldx,
+                    const float* rstd_in, int H, int R, int rows_per_block, const T* add, long ldadd, T* dx, long lddx,
+                    float* dw1_partial, float* dw2_partial) {
+    SF_SHARED float red[16];
+    const int tid = (int)threadIdx.x;
+    float dwa1[NV][8], dwa2[NV][8], wv1[NV][8], wv2[NV][8];
+    int colc[NV];
+    bool live[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (tid + i * 256) * 8;
+        live[i] = col < H;
+        colc[i] = live[i] ? col : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dwa1[i][j] = 0.f; dwa2[i][j] = 0.f; wv1[i][j] = 0.f; wv2[i][j] = 0.f; }
+        if (live[i]) { SfVec8<T>::ld(w1 + col, wv1[i]); SfVec8<T>::ld(w2 + col, wv2[i]); }
+    }
+    const int r0 = (int)blockIdx.x * rows_per_block;
+    const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    constexpr int RG = 2;     // rows whose loads are in flight together (see rmsnorm_bwd_kernel)
+    for (int r = r0; r < r1; r += RG) {
+        SfRaw8<T> xg[RG][NV], d1[RG][NV], d2[RG][NV], ag[RG][NV];
+        float rsg[RG];
+#pragma unroll
+        for (int u = 0; u < RG; ++u) {
+            const int rr = r + u < r1 ? r + u : r1 - 1;
+            rsg[u] = rstd_in[rr];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                xg[u][i].ld(x + (long)rr * ldx + colc[i]);
+                d1[u][i].ld(dy1 + (long)rr * lddy1 + colc[i]);
+                d2[u][i].ld(dy2 + (long)rr * lddy2 + colc[i]);
+                if (add) ag[u][i].ld(add + (long)rr * ldadd + colc[i]);   // uniform branch
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RG; ++u) {
+            if (r + u >= r1) break;
+            const float rs = rsg[u];
+            float g[NV][8], xh[NV][8];
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = live[i] ? d1[u][i].at(j) : 0.f, bb = live[i] ? d2[u][i].at(j) : 0.f;
+                    xh[i][j] = SfElem<T>::rnd(xg[u][i].at(j) * rs);
+                    g[i][j] = a * wv1[i][j] + bb * wv2[i][j];
+                    dot += g[i][j] * xh[i][j];
+                    dwa1[i][j] += a * xh[i][j];
+                    dwa2[i][j] += bb * xh[i][j];
+                }
+            }
+            dot = sf_block_sum(dot, red);
+            const float cmean = dot / (float)H;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = rs * (g[i][j] - xh[i][j] * cmean);
+                if (add) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += ag[u][i].at(j);
+                }
+                if (live[i]) SfVec8<T>::st(dx + (long)(r + u) * lddx + colc[i], o);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (live[i]) {
+            SfVec8<float>::st(dw1_partial + (long)blockIdx.x * H + colc[i], dwa1[i]);
+            SfVec8<float>::st(dw2_partial + (long)blockIdx.x * H + colc[i], dwa2[i]);
+        }
+}
+
 // acc[col] (+)= sum_b partial[b][col]   (deterministic: fixed order)
 // 1024 threads = 64 columns x 16 row lanes; lane order of the final sum is fixed.
 SF_GLOBAL void colsum_accum_kernel(const float* partial, int nb, int H, float* acc, int accumulate) {
@@ -421,6 +503,27 @@ extern "C" int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* 
         SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, nb, H, dw_acc,
                   dw_accumulate);
     return sf_check_launch("sf_rmsnorm_bwd");
+}
+
+extern "C" int sf_rmsnorm_bwd2(const void* dy1, long lddy1, const void* w1, float* dw1_acc, int dw1_accumulate, const void* dy2,
+                               long lddy2, const void* w2, float* dw2_acc, int dw2_accumulate, int dtype, const void* x, long ldx,
+                               const float* rstd, int rows, int H, const void* add, long ldadd, void* dx, long lddx,
+                               float* workspace, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && H > 0 && H % 8 == 0 && H <= 4096, "sf_rmsnorm_bwd2: H must be a multiple of 8, <= 4096");
+    SF_CHECK_ARG(lddy1 % 8 == 0 && lddy2 % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && ldadd % 8 == 0, "sf_rmsnorm_bwd2: strides");
+    SF_CHECK_ARG(dy1 && dy2 && w1 && w2 && x && rstd && dx && dw1_acc && dw2_acc && workspace, "sf_rmsnorm_bwd2: missing argument");
+    if (rows == 0) return 0;
+    const int rpb = 16, nb = (rows + rpb - 1) / rpb;
+    float* ws2 = workspace + (long)nb * H;      // (the workspace holds 2 x sf_rmsnorm_bwd_workspace_floats(rows, H))
+#define SF_NORM_BWD2(NV)                                                                                                     \
+    SF_DISPATCH_T(dtype, SF_LAUNCH((rmsnorm_bwd2_kernel<T, NV>), dim3(nb), dim3(256), 0, stream, (const T*)dy1, lddy1, (const T*)w1, \
+                                   (const T*)dy2, lddy2, (const T*)w2, (const T*)x, ldx, rstd, H, rows, rpb, (const T*)add, ldadd,  \
+                                   (T*)dx, lddx, workspace, ws2))
+    if (H <= 2048) { SF_NORM_BWD2(1); } else { SF_NORM_BWD2(2); }
+#undef SF_NORM_BWD2
+    SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, nb, H, dw1_acc, dw1_accumulate);
+    SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)ws2, nb, H, dw2_acc, dw2_accumulate);
+    return sf_check_launch("sf_rmsnorm_bwd2");
 }
 
 extern "C" int sf_rope(void* x, int dtype, long ld, int rows, int nheads, int hd, const void* cos_t, const void* sin_t,

@@ -267,7 +267,7 @@ class Eagle3Engine:
         if self.mrope:
             b["cos_rows"] = [cv(f"cos_rows_{k}", N, hd) for k in range(T)]
             b["sin_rows"] = [cv(f"sin_rows_{k}", N, hd) for k in range(T)]
-        b["nws"] = cv("nws", ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)
+        b["nws"] = cv("nws", 2 * ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)   # (x 2: sf_rmsnorm_bwd2)
         b["nws_e"] = cv("nws_e", ops.rmsnorm_bwd_workspace(Np, H), dtype=f32)
         # fp32 partials for the 2-way split-K of weight-gradient GEMMs whose tile count fills the CUs badly (down, q|k|v)
         # (+ 4096 floats at the tail: pace-keeping counters of sf_gemm_tn)
@@ -615,11 +615,22 @@ class Eagle3Engine:
             return nm[name], acc
 
         dh_next = None
+        # h[k] feeds the final norm of step k - 1 AND the hidden_norm of step k: with the final norm in use (and H <= 4096) the
+        # hidden_norm backward of step k is not run at the end of step k but together with the final-norm backward of step k - 1,
+        # one pass over h[k] (sf_rmsnorm_bwd2): `pending` = (d(hidden_norm output), the residual-stream gradient that joins it)
+        pair = c.norm_output and H <= 4096
+        pending = None
         for k in range(T - 1, -1, -1):
             # final norm + (already taken) lm_head dgrad; residual-stream gradient of step k+1 joins here.
             # dh / dgu / dh1 / dqkv are written straight into their slot of the weight-gradient stash.
             dh, dgu, dh1, dqkv = b["dh"][k], b["dgu"][k], b["dh1"][k], b["dqkv"][k]
-            if c.norm_output:
+            if pending is not None:
+                acc1, a1 = nacc("norm.weight")
+                acc2, a2 = nacc("midlayer.hidden_norm.weight")
+                ops.rmsnorm_bwd2(b["dln"][k], f.view("norm.weight"), acc1, a1, pending[0], f.view("midlayer.hidden_norm.weight"), acc2, a2,
+                                 b["h"][k + 1], b["rstd_n"][k], dx=dh, add=pending[1], workspace=ws)
+                pending = None
+            elif c.norm_output:
                 acc, a = nacc("norm.weight")
                 ops.rmsnorm_bwd(b["dln"][k], b["h"][k + 1], f.view("norm.weight"), b["rstd_n"][k], dx=dh, add=dh_next,
                                 dw_acc=acc, dw_accumulate=a, workspace=ws)
@@ -668,6 +679,9 @@ class Eagle3Engine:
             else:
                 ops.rope_(dqkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k, backward=True)
             ops.gemm_nt(dqkv, self.wqkvT[H:], b["dxh"])                 # hidden half of the QKV dgrad
+            if pair and k > 0:
+                pending = (b["dxh"], dh1)      # consumed at the top of step k - 1, before that step rewrites dxh
+                continue
             dh_prev = b["dh_b"][0]
             acc, a = nacc("midlayer.hidden_norm.weight")
             ops.rmsnorm_bwd(b["dxh"], b["h"][k], f.view("midlayer.hidden_norm.weight"), b["rstd_h"][k],

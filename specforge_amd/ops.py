@@ -231,6 +231,19 @@ def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, rstd: torch.
                                 _p(workspace), _stream()), "sf_rmsnorm_bwd")
 
 
+def rmsnorm_bwd2(dy1: torch.Tensor, w1: torch.Tensor, dw1_acc: torch.Tensor, dw1_accumulate: bool, dy2: torch.Tensor, w2: torch.Tensor,
+                 dw2_acc: torch.Tensor, dw2_accumulate: bool, x: torch.Tensor, rstd: torch.Tensor, *, dx: torch.Tensor, add=None, workspace):
+    """dx = d_norm(dy1; w1) + d_norm(dy2; w2) (+ add) for two RMSNorms of the same rows x; dw*_acc (+)= their weight gradients.
+    workspace: >= 2 * rmsnorm_bwd_workspace(rows, H) floats."""
+    L = _lib.lib()
+    rows, H = dy1.shape[0], w1.numel()
+    assert dy2.shape[0] == rows and w2.numel() == H and workspace.numel() >= 2 * rmsnorm_bwd_workspace(rows, H)
+    _lib.check(L.sf_rmsnorm_bwd2(_p(dy1), _rowmajor(dy1), _p(w1), _p(dw1_acc), 1 if dw1_accumulate else 0, _p(dy2), _rowmajor(dy2), _p(w2),
+                                 _p(dw2_acc), 1 if dw2_accumulate else 0, _dt(dy1), _p(x), _rowmajor(x), _p(rstd), rows, H, _p(add),
+                                 _rowmajor(add) if add is not None else 0, _p(dx), _rowmajor(dx), _p(workspace), _stream()),
+               "sf_rmsnorm_bwd2")
+
+
 def rope_(x: torch.Tensor, nheads: int, hd: int, cos_t: torch.Tensor, sin_t: torch.Tensor, pos_ids: torch.Tensor,
           pos_off: int, backward: bool = False):
     """in place on the first nheads*hd columns of the 2-D view x"""

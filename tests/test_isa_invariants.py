@@ -24,8 +24,10 @@ def _asm(src):
     out = os.path.join(out_dir, src.replace(".hip", ".s"))
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        tmp = f"{out}.{os.getpid()}.tmp"       # (parallel test workers compile the same unit: publish the result atomically)
         subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-I", CSRC, "-ffp-contract=fast",
-                        "-fno-honor-nans", "-w", "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)], check=True)
+                        "-fno-honor-nans", "-w", "-S", "--cuda-device-only", "-o", tmp, os.path.join(CSRC, src)], check=True)
+        os.replace(tmp, out)
     return open(out).read()
 
 

@@ -319,6 +319,42 @@ def test_teacher_reduce(backend, dtype, Vt, Vd):
     assert float((tp_pad.cpu()[:, S:] - 1.0 / Vd).abs().max()) == 0    # padded tail untouched
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("R,H", [(20, 128), (37, 896), (19, 4096)])
+def test_rmsnorm_bwd2_equals_the_sum_of_two_backwards(backend, dtype, tol, R, H):
+    """two norms of the same x: dx = d_norm(dy1; w1) + d_norm(dy2; w2) + add and both weight gradients, against autograd in fp32 and
+    against two sf_rmsnorm_bwd calls (fp32: same value up to summation order; bf16: one rounding fewer than the chained calls)"""
+    x = _rand((R, H), dtype, 1)
+    w1 = (1 + 0.1 * _rand((H,), torch.float32, 2)).to(dtype)
+    w2 = (1 + 0.1 * _rand((H,), torch.float32, 3)).to(dtype)
+    dy1, dy2, add = _rand((R, H), dtype, 4), _rand((R, H), dtype, 5), _rand((R, H), dtype, 6)
+    xr = x.float().clone().requires_grad_(True)
+    w1r, w2r = w1.float().clone().requires_grad_(True), w2.float().clone().requires_grad_(True)
+    (O.rmsnorm(xr, w1r, 1e-5) * dy1.float()).sum().backward()
+    (O.rmsnorm(xr, w2r, 1e-5) * dy2.float()).sum().backward()
+    want_dx = xr.grad + add.float()
+    d = lambda t: t.to(backend)
+    y = torch.empty((R, H), dtype=dtype, device=backend)
+    rstd = torch.empty(R, device=backend)
+    ops.rmsnorm_fwd(d(x), d(w1), 1e-5, y, rstd)
+    ws = torch.empty(2 * ops.rmsnorm_bwd_workspace(R, H), device=backend)
+    dx = torch.empty((R, H), dtype=dtype, device=backend)
+    dw1, dw2 = torch.full((H,), 0.5, device=backend), torch.full((H,), 9.0, device=backend)
+    ops.rmsnorm_bwd2(d(dy1), d(w1), dw1, True, d(dy2), d(w2), dw2, False, d(x), rstd, dx=dx, add=d(add), workspace=ws)
+    gmax = float(want_dx.abs().max())
+    torch.testing.assert_close(dx.float().cpu(), want_dx, rtol=tol, atol=tol * gmax)
+    torch.testing.assert_close(dw1.cpu(), 0.5 + w1r.grad, rtol=max(tol, 1e-4), atol=max(tol, 1e-4) * float(w1r.grad.abs().max()))
+    torch.testing.assert_close(dw2.cpu(), w2r.grad, rtol=max(tol, 1e-4), atol=max(tol, 1e-4) * float(w2r.grad.abs().max()))
+    # the chained form it replaces
+    t1, t2 = torch.empty_like(dx), torch.empty_like(dx)
+    a1, a2 = torch.zeros(H, device=backend), torch.zeros(H, device=backend)
+    ops.rmsnorm_bwd(d(dy2), d(x), d(w2), rstd, dx=t1, add=d(add), dw_acc=a2, dw_accumulate=False, workspace=ws)
+    ops.rmsnorm_bwd(d(dy1), d(x), d(w1), rstd, dx=t2, add=t1, dw_acc=a1, dw_accumulate=False, workspace=ws)
+    torch.testing.assert_close(dx.float().cpu(), t2.float().cpu(), rtol=tol, atol=tol * gmax)
+    torch.testing.assert_close(dw2.cpu(), a2.cpu(), rtol=1e-5, atol=1e-5 * float(a2.abs().max()))
+    torch.testing.assert_close((dw1 - 0.5).cpu(), a1.cpu(), rtol=1e-4, atol=1e-4 * float(a1.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("R,H", [(20, 128), (19, 4096)])
 def test_rmsnorm_fwd2_equals_two_norms(backend, dtype, R, H):
