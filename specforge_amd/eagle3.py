@@ -171,6 +171,7 @@ class Eagle3TrainStrategy:
         self.eagle3_model = eagle3_model
         self.target_head = target_head
         self.ploss_decay = ploss_decay
+        self._stager = None
         if abs(eagle3_model.ploss_decay - ploss_decay) > 1e-12:
             raise ValueError("OnlineEagle3Model.ploss_decay and the strategy's ploss_decay must agree")
 
@@ -182,9 +183,23 @@ class Eagle3TrainStrategy:
         if missing:
             raise ValueError(f"eagle3 strategy: batch lacks {sorted(missing)}")
 
+    def _resident(self, tensors):
+        """The batch on the engine's device.  Batches from the HIP ingest (``reference_plugin.feature_loader_class``,
+        ``ingest.HiddenStateIngest``) already are; a CPU batch (the reference's own loader hands those over and moves them with
+        a blocking pageable ``.to(device)``, strategies/base.py:270-289) goes through a pinned double buffer and a HIP copy
+        stream -- the TTT shift of ``preprocess`` then runs on the device either way."""
+        dev = self.eagle3_model.engine.dev
+        if dev.type != "cuda" or all(v is None or v.is_cuda for v in tensors.values()):
+            return tensors
+        if self._stager is None:
+            from .ingest import PinnedStager
+
+            self._stager = PinnedStager(dev)
+        return self._stager.stage(tensors)
+
     def forward_loss(self, batch, ctx=None) -> StepOutput:
         self.validate_batch(batch)
-        t = batch.tensors
+        t = self._resident(batch.tensors)
         target_repr = getattr(batch, "metadata", {}).get("target_repr")
         kwargs = {}
         if target_repr == "hidden_state":

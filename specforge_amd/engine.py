@@ -384,9 +384,15 @@ class Eagle3Engine:
             if position_ids is None or position_ids.dim() != 3 or tuple(position_ids.shape) != (3, B, S):
                 raise ValueError("rope_type 'mrope' needs position_ids of shape [3, batch, seq_length] (eagle3/model.py:228-242)")
             pos3 = position_ids.to(self.dev).long().reshape(3, N)
+            lo, hi = (int(v) for v in torch.stack((pos3.min(), pos3.max())).tolist())   # one read-back, mrope batches only
+            if lo < 0 or hi + T - 1 >= self.cos.shape[0]:
+                # the reference computes the angles analytically from the ids (llama3_eagle.py:719-733, no limit); this engine
+                # gathers rows of the precomputed table -- ids past it must fail, not rotate by a clamped angle
+                raise ValueError(f"mrope position_ids span [{lo}, {hi}] (+{T - 1} TTT steps) but the RoPE table has {self.cos.shape[0]} "
+                                 "rows (max_position_embeddings + 20): raise max_position_embeddings in the draft config")
             cols = torch.arange(hd, device=self.dev)
             for k in range(T):   # step k rotates at position + k on every axis (llama3_eagle.py:719-733)
-                idx = (pos3 + k).clamp_(max=self.cos.shape[0] - 1)[self._mrope_axis].t()      # [N, hd]
+                idx = (pos3 + k)[self._mrope_axis].t()      # [N, hd]
                 b["cos_rows"][k].copy_(self.cos[idx, cols])
                 b["sin_rows"][k].copy_(self.sin[idx, cols])
             b["pos"].copy_(torch.arange(N, device=self.dev))                                  # row r reads table row r

@@ -122,8 +122,8 @@ def _sample_layout(path: str) -> Optional[Dict[str, tuple]]:
                     data0 = zi.header_offset + 30 + fn_len + extra_len
                     out[name] = (data0 + ref.offset * torch.empty((), dtype=ref.dtype).element_size(), ref.dtype, ref.shape)
             return out
-    except (StopIteration, KeyError, pickle.UnpicklingError, zipfile.BadZipFile, OSError, struct.error):
-        return None
+    except Exception:   # anything unusual about the file (subclassed tensors, odd persistent ids, compressed / encrypted
+        return None     # members, a truncated zip ...) means "not the plain layout": the generic torch.load path reads it
 
 
 def _bytes_view(t: torch.Tensor):
@@ -156,22 +156,42 @@ class _Slot:
         self.released = None    # event on the compute stream: the consumer moved past this slot
 
 
+_LAYOUT_CACHE_MAX = 1 << 16     # entries; a multi-million-file dataset must not grow the cache without bound
+
+
 class HiddenStateIngest:
-    def __init__(self, files: Sequence[str], *, batch_size: int, max_len: int, target_hidden_size: int, device,
+    def __init__(self, files: Sequence[str], *, batch_size: int, max_len: int, target_hidden_size: Optional[int] = None, device="cuda",
                  dp_rank: int = 0, dp_size: int = 1, seed: int = 0, shuffle: bool = True, pad_multiple: int = 1,
                  slots: int = 2, reader_threads: int = 4, direct: bool = True):
+        """``target_hidden_size=None``: taken from the first file read (the reference's loader does not know it either)."""
         self.files = list(files)
         self.B, self.max_len, self.Ht = batch_size, max_len, target_hidden_size
         self.device = torch.device(device)
         self.dp_rank, self.dp_size, self.seed, self.shuffle = dp_rank, dp_size, seed, shuffle
         self.pad_multiple = pad_multiple
         cuda = self.device.type == "cuda"
-        Lcap = (max_len + pad_multiple - 1) // pad_multiple * pad_multiple
-        self._slots = [_Slot(batch_size, Lcap, target_hidden_size, self.device, pin=cuda) for _ in range(max(2, slots))]
+        self._Lcap = (max_len + pad_multiple - 1) // pad_multiple * pad_multiple
+        self._nslots = max(2, slots)
+        self._slots: List[_Slot] = []
         self._copy_stream = torch.cuda.Stream(device=self.device) if cuda else None
         self._direct = bool(direct)
-        self._layouts: Dict[str, Optional[Dict[str, tuple]]] = {}
+        self._layouts: "OrderedDict[str, Optional[Dict[str, tuple]]]" = OrderedDict()
+        self._layout_lock = threading.Lock()
         self._pool = ThreadPoolExecutor(max_workers=max(1, int(reader_threads)), thread_name_prefix="sf-ingest")
+        if target_hidden_size is not None:
+            self._ensure_slots(None)
+
+    def _ensure_slots(self, first_path: Optional[str]) -> None:
+        if self._slots:
+            return
+        if self.Ht is None:
+            lay = self._layout(first_path) if self._direct else None
+            if lay is not None and "hidden_state" in lay:
+                self.Ht = int(lay["hidden_state"][2][-1])
+            else:
+                self.Ht = int(torch.load(first_path, mmap=True, weights_only=True)["hidden_state"].shape[-1])
+        cuda = self.device.type == "cuda"
+        self._slots = [_Slot(self.B, self._Lcap, self.Ht, self.device, pin=cuda) for _ in range(self._nslots)]
 
     def batches_per_epoch(self) -> int:
         n = len(distributed_sampler_indices(len(self.files), dp_rank=self.dp_rank, dp_size=self.dp_size, seed=self.seed,
@@ -181,12 +201,21 @@ class HiddenStateIngest:
     # what each staged tensor is in the file (algorithms/eagle3/data.py:10-27): name in the slot <- name in the file
     _SOURCE = (("hidden_state", "aux_hidden_state"), ("target", "hidden_state"), ("input_ids", "input_ids"), ("loss_mask", "loss_mask"))
 
+    def _layout(self, path: str):
+        with self._layout_lock:
+            if path in self._layouts:
+                return self._layouts[path]
+        lay = _sample_layout(path)
+        with self._layout_lock:
+            self._layouts[path] = lay
+            while len(self._layouts) > _LAYOUT_CACHE_MAX:
+                self._layouts.popitem(last=False)
+        return lay
+
     def _read_direct(self, slot: _Slot, b: int, path: str) -> int:
         """sample -> row b of the slot, straight from the file; returns its (truncated) length, or -1 if the file needs the
-        generic path (not a plain torch zip, other dtypes, unexpected shapes)"""
-        lay = self._layouts.get(path, False)
-        if lay is False:
-            lay = self._layouts[path] = _sample_layout(path)
+        generic path (not a plain torch zip, other dtypes, unexpected shapes, a read that came back short)"""
+        lay = self._layout(path)
         if lay is None or any(src not in lay for _, src in self._SOURCE):
             return -1
         n = None
@@ -194,18 +223,26 @@ class HiddenStateIngest:
         for dst, src in self._SOURCE:
             off, dtype, shape = lay[src]
             buf = slot.h[dst]
-            rows = shape[-2] if len(shape) == 3 else shape[0]
-            feat = shape[-1] if len(shape) == 3 else 1
-            ok = dtype == buf.dtype and (len(shape) == 1 or (len(shape) == 3 and shape[0] == 1 and feat == buf.shape[-1]))
-            if not ok or (n is not None and min(rows, self.max_len) != n):
+            hidden = buf.dim() == 3      # hidden states are [1, S, features] in the file, ids / mask are [S]
+            if dtype != buf.dtype or (hidden and not (len(shape) == 3 and shape[0] == 1 and shape[2] == buf.shape[-1])) \
+                    or (not hidden and len(shape) != 1):
+                return -1
+            rows, feat = (shape[1], shape[2]) if hidden else (shape[0], 1)
+            if n is not None and min(rows, self.max_len) != n:
                 return -1
             n = min(rows, self.max_len)
             plan.append((buf, off, n * feat * buf.element_size()))
         fd = os.open(path, os.O_RDONLY)
         try:
             for buf, off, nbytes in plan:
-                if nbytes and os.preadv(fd, [_bytes_view(buf[b, :n])], off) != nbytes:
-                    raise OSError(f"short read from {path}")
+                if not nbytes:
+                    continue
+                view, done = _bytes_view(buf[b, :n]), 0
+                while done < nbytes:       # preadv may legally return fewer bytes (network / FUSE filesystems, signals)
+                    got = os.preadv(fd, [view[done:]], off + done)
+                    if got <= 0:
+                        return -1          # truncated file: let torch.load produce the error (or read it)
+                    done += got
         finally:
             os.close(fd)
         if n > 0:
@@ -224,8 +261,8 @@ class HiddenStateIngest:
         n = self._read_direct(slot, b, path) if self._direct else -1
         return n if n >= 0 else self._read_generic(slot, b, path)
 
-    def _fill(self, slot: _Slot, idxs: List[int]) -> int:
-        lens = list(self._pool.map(lambda bi: self._read_one(slot, bi[0], self.files[bi[1]]), enumerate(idxs)))
+    def _fill(self, slot: _Slot, paths: Sequence[str]) -> int:
+        lens = list(self._pool.map(lambda bp: self._read_one(slot, bp[0], bp[1]), enumerate(paths)))
         L = max(lens)
         L = (L + self.pad_multiple - 1) // self.pad_multiple * self.pad_multiple
         for b, n in enumerate(lens):          # right-pad with zeros to the longest sample: only the tails are written
@@ -234,22 +271,38 @@ class HiddenStateIngest:
                     buf[b, n:L].zero_()
         return L
 
-    def collate_indices(self, idxs: Sequence[int]) -> Dict[str, torch.Tensor]:
-        """host-side batch of the given samples (normalise + right-pad), as fresh CPU tensors -- what ``epoch`` stages"""
-        slot = _Slot(len(idxs), self._slots[0].h["input_ids"].shape[1], self.Ht, torch.device("cpu"), pin=False)
-        L = self._fill(slot, list(idxs))
+    def collate_paths(self, paths: Sequence[str]) -> Dict[str, torch.Tensor]:
+        """host-side batch of the given sample files (normalise + right-pad), as fresh CPU tensors -- what ``stream`` stages"""
+        self._ensure_slots(paths[0])
+        slot = _Slot(len(paths), self._Lcap, self.Ht, torch.device("cpu"), pin=False)
+        L = self._fill(slot, list(paths))
         return {k: v[:, :L].clone() for k, v in slot.h.items()}
 
+    def collate_indices(self, idxs: Sequence[int]) -> Dict[str, torch.Tensor]:
+        return self.collate_paths([self.files[i] for i in idxs])
+
     def epoch(self, epoch: int = 0) -> Iterator[TrainBatch]:
-        """Yields device-resident batches.  A batch's tensors are views of a staging slot: they stay valid until
-        the NEXT batch is requested (by then the consumer has enqueued all work that reads them; the slot is
-        refilled only after an event on the consumer's stream has passed)."""
+        """One epoch of this rank's shard (``DistributedSampler`` order, ``drop_last`` batches) as device-resident batches."""
         idx = distributed_sampler_indices(len(self.files), dp_rank=self.dp_rank, dp_size=self.dp_size, seed=self.seed,
                                           epoch=epoch, shuffle=self.shuffle)
         groups = [idx[i:i + self.B] for i in range(0, len(idx) - self.B + 1, self.B)]  # drop_last
+        for batch, g in zip(self.stream([[self.files[i] for i in g] for g in groups]), groups):
+            batch.metadata["sample_indices"] = list(g)
+            yield batch
+
+    def stream(self, groups: Sequence[Sequence[str]]) -> Iterator[TrainBatch]:
+        """Device-resident batches of the given groups of sample files, in order (a group may be shorter than ``batch_size``:
+        the reference's eval loader keeps the last partial batch).  A batch's tensors are views of a staging slot: they stay
+        valid until the NEXT batch is requested (by then the consumer has enqueued all work that reads them; the slot is
+        refilled only after an event on the consumer's stream has passed)."""
+        groups = [list(g) for g in groups]
+        if not groups:
+            return
+        self._ensure_slots(groups[0][0])
         nslots = len(self._slots)
         free: "queue.Queue[int]" = queue.Queue()
         ready: "queue.Queue" = queue.Queue()
+        stop = threading.Event()
         for i in range(nslots):
             free.put(i)
 
@@ -257,6 +310,8 @@ class HiddenStateIngest:
             try:
                 for g in groups:
                     si = free.get()
+                    if si is None or stop.is_set():
+                        return
                     slot = self._slots[si]
                     if slot.released is not None:      # the consumer's stream must be past this slot's tensors
                         slot.released.synchronize()
@@ -264,7 +319,7 @@ class HiddenStateIngest:
                     if self._copy_stream is not None:
                         with torch.cuda.stream(self._copy_stream):
                             for k in slot.h:
-                                slot.dview(k, L).copy_(slot.h[k][:, :L], non_blocking=True)
+                                slot.dview(k, L)[:len(g)].copy_(slot.h[k][:len(g), :L], non_blocking=True)
                             slot.copied = torch.cuda.Event()
                             slot.copied.record()
                     ready.put((si, L, g))
@@ -275,24 +330,87 @@ class HiddenStateIngest:
         t = threading.Thread(target=loader, daemon=True)
         t.start()
         prev = None
-        while True:
-            item = ready.get()
-            if prev is not None:  # the consumer asked for the next batch: everything it enqueued on `prev` is ordered before this
+        try:
+            while True:
+                item = ready.get()
+                if prev is not None:  # the consumer asked for the next batch: everything it enqueued on `prev` is ordered before this
+                    if self._copy_stream is not None:
+                        self._slots[prev].released = torch.cuda.Event()
+                        self._slots[prev].released.record()
+                    free.put(prev)
+                    prev = None
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                si, L, g = item
+                slot = self._slots[si]
+                nb = len(g)
                 if self._copy_stream is not None:
-                    self._slots[prev].released = torch.cuda.Event()
-                    self._slots[prev].released.record()
-                free.put(prev)
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            si, L, g = item
-            slot = self._slots[si]
-            if self._copy_stream is not None:
-                torch.cuda.current_stream().wait_event(slot.copied)
-                tensors = {k: slot.dview(k, L) for k in slot.d}
-            else:
-                tensors = {k: v[:, :L].clone() for k, v in slot.h.items()}
-            prev = si
-            yield TrainBatch(tensors, {"target_repr": "hidden_state", "sample_indices": list(g)})
-        t.join()
+                    torch.cuda.current_stream().wait_event(slot.copied)
+                    tensors = {k: slot.dview(k, L)[:nb] for k in slot.d}
+                else:
+                    tensors = {k: v[:nb, :L].clone() for k, v in slot.h.items()}
+                prev = si
+                yield TrainBatch(tensors, {"target_repr": "hidden_state", "sample_files": list(g)})
+        finally:
+            # the consumer may abandon the iterator mid-epoch (max_steps reached): release the loader thread
+            stop.set()
+            if prev is not None and self._copy_stream is not None:
+                self._slots[prev].released = torch.cuda.Event()
+                self._slots[prev].released.record()
+            free.put(None)
+            t.join(timeout=30.0)
+
+
+class PinnedStager:
+    """CPU batch -> HBM without a pageable copy on the compute stream.
+
+    What still arrives as CPU tensors (the reference's own ``FeatureDataLoader`` batches -- strategies/base.py:270-289 moves
+    them with a blocking pageable ``.to(device)`` on the compute stream -- a ``.ckpt.gz`` dataset, an online ``mem://`` store)
+    is copied into one of two pinned slots, sent on a dedicated HIP copy stream, and the compute stream only waits on the
+    copy's event.  The pageable form stalls the host until the previous step has drained and then moves 0.54 GB through the
+    runtime's bounce buffers in front of the step; here the host-side copy runs while the GPU is still busy with the previous
+    step.  A slot is reused only after an event on the consumer's stream has passed (recorded when the next batch is staged)."""
+
+    def __init__(self, device, slots: int = 2):
+        self.device = torch.device(device)
+        assert self.device.type == "cuda"
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._slots = [dict(h={}, d={}, released=None) for _ in range(max(2, slots))]
+        self._next = 0
+        self._prev = None
+
+    @staticmethod
+    def _buf(store, key, t, **kw):
+        n = t.numel()
+        cur = store.get(key)
+        if cur is None or cur.dtype != t.dtype or cur.numel() < n:
+            cur = store[key] = torch.empty(max(n, 1), dtype=t.dtype, **kw)
+        return cur[:n].view(t.shape)
+
+    def stage(self, tensors: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        if self._prev is not None:    # the consumer came back for another batch: its work on the previous one is enqueued
+            ev = torch.cuda.Event()
+            ev.record()
+            self._slots[self._prev]["released"] = ev
+        slot = self._slots[self._next]
+        if slot["released"] is not None:
+            slot["released"].synchronize()
+        out = {}
+        with torch.cuda.stream(self._stream):
+            for k, t in tensors.items():
+                if t is None or t.is_cuda:
+                    out[k] = t
+                    continue
+                t = t.contiguous()
+                h = self._buf(slot["h"], k, t, pin_memory=True)
+                h.copy_(t)
+                d = self._buf(slot["d"], k, t, device=self.device)
+                d.copy_(h, non_blocking=True)
+                out[k] = d
+            done = torch.cuda.Event()
+            done.record()
+        torch.cuda.current_stream().wait_event(done)
+        self._prev, self._next = self._next, (self._next + 1) % len(self._slots)
+        return out

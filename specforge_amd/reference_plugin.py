@@ -17,6 +17,14 @@ executable; nothing else in ``specforge_amd`` imports it).  It provides, each at
   (training/trainer.py:421) -- the one line a maintainer would make injectable; until then the name is rebound to
   ``HipDPTrainingBackend`` in that module.  The configured optimizer factory (training/assembly.py:246-275) is rebound
   to this package's fused ``BF16Optimizer`` with the same arguments.
+* f1  ``feature_loader_class()``: ``Trainer.__init__`` also hard-codes ``FeatureDataLoader(store, refs=..., ...)``
+  (training/trainer.py:145-155).  ``install()`` rebinds that name to a subclass whose refs-mode iteration hands the
+  trainer DEVICE-RESIDENT ``TrainBatch``es staged by ``specforge_amd.ingest`` (pinned double buffer + HIP copy stream;
+  the files' bytes read straight into the pinned slot) -- same refs, same order, same ``seek`` / ``set_epoch`` /
+  ``drop_last`` behaviour (feature_dataloader.py:255-295), tensors bit-identical to the reference's normaliser +
+  collator.  Anything the fast reader does not cover (``.ckpt.gz``, ``mem://`` refs, another algorithm's transform or
+  collator, USP collation) is materialised by the reference's own ``_make_batch`` on a loader thread and staged through
+  the same pinned slots.
 """
 from __future__ import annotations
 
@@ -160,6 +168,105 @@ def registry(override: bool = False):
     return AlgorithmRegistry([r for r in base if r.name != REFERENCE_ALGORITHM] + [registration(override=True)])
 
 
+_loader_cls = {}
+
+
+def _device_for_batches() -> torch.device:
+    """where the trainer's batches must live: the GPU of this rank -- or, under the test suite's SIMT interpreter
+    (which computes on host memory), the CPU"""
+    from . import _lib
+
+    _lib.lib()
+    if _lib.is_emulated():
+        return torch.device("cpu")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def feature_loader_class():
+    """``FeatureDataLoader`` (runtime/data_plane/feature_dataloader.py:92-320) with the refs-mode (offline) iteration on
+    the HIP ingest.  Queue mode (online / streaming) is the reference's own code, untouched."""
+    if "cls" in _loader_cls:
+        return _loader_cls["cls"]
+    import functools
+
+    from specforge.algorithms.eagle3.data import normalize_offline_sample as ref_normalize
+    from specforge.data.utils import DataCollatorWithPadding
+    from specforge.runtime.contracts import TrainBatch as RefTrainBatch
+    from specforge.runtime.data_plane.feature_dataloader import FeatureDataLoader
+
+    from .ingest import HiddenStateIngest, PinnedStager
+
+    class HipFeatureDataLoader(FeatureDataLoader):
+        _ingest = None
+        _stager = None
+
+        def _fast_max_len(self, chunks):
+            """max_len when every batch is plain EAGLE3 offline files through the reference's eagle3 normaliser and
+            padding collator (what ``HiddenStateIngest`` is pinned to, tests/golden/ingest_collate.pt); else None"""
+            t, c = self.per_sample_transform, self.collate_fn
+            if not (isinstance(t, functools.partial) and t.func is ref_normalize and not t.args and set(t.keywords) == {"max_len"}):
+                return None
+            if type(c) is not DataCollatorWithPadding or getattr(c, "sp_degree", 1) != 1 or getattr(c, "ulysses_degree", 1) != 1:
+                return None
+            keys = {"input_ids", "loss_mask", "hidden_state", "aux_hidden_state"}
+            for chunk in chunks:
+                for r in chunk:
+                    u = r.feature_store_uri
+                    if not u.startswith("file://") or u.endswith(".gz") or set(r.feature_keys) != keys \
+                            or any(k != v for k, v in r.feature_keys.items()):
+                        return None
+            return int(t.keywords["max_len"])
+
+        def _iter_refs(self):
+            skip, self._seek_batches = self._seek_batches, 0        # feature_dataloader.py:257-266
+            chunks = []
+            for start in range(skip * self.batch_size, len(self._refs), self.batch_size):
+                chunk = self._refs[start:start + self.batch_size]
+                if self.drop_last and len(chunk) < self.batch_size:
+                    break
+                chunks.append(chunk)
+            if not chunks:
+                return
+            dev = _device_for_batches()
+            max_len = self._fast_max_len(chunks)
+            if max_len is None:
+                yield from self._iter_staged(chunks, dev)
+                return
+            for chunk in chunks:
+                self._validate_refs(chunk)
+            ing = self._ingest
+            if ing is None or ing.B != self.batch_size or ing.max_len != max_len or ing.device != dev:
+                ing = self._ingest = HiddenStateIngest([], batch_size=self.batch_size, max_len=max_len, device=dev)
+            groups = [[r.feature_store_uri[len("file://"):] for r in chunk] for chunk in chunks]
+            for chunk, b in zip(chunks, ing.stream(groups)):
+                yield RefTrainBatch(sample_ids=[r.sample_id for r in chunk], strategy=self.strategy, tensors=b.tensors,
+                                    metadata={"target_repr": chunk[0].metadata.get("target_repr"),
+                                              "ttt_length": chunk[0].metadata.get("ttt_length")})
+
+        def _iter_staged(self, chunks, dev):
+            """the reference's own materialisation (store.get + transform + collate) one batch ahead on a thread, then
+            pinned slot + copy stream instead of the strategy's pageable ``.to(device)``"""
+            from concurrent.futures import ThreadPoolExecutor
+
+            if dev.type != "cuda":
+                for chunk in chunks:
+                    yield self._make_batch(chunk)
+                return
+            if self._stager is None:
+                self._stager = PinnedStager(dev)
+            with ThreadPoolExecutor(max_workers=1, thread_name_prefix="sf-loader") as ex:
+                fut = ex.submit(self._make_batch, chunks[0])
+                for i in range(len(chunks)):
+                    batch = fut.result()
+                    if i + 1 < len(chunks):
+                        fut = ex.submit(self._make_batch, chunks[i + 1])
+                    batch.tensors = self._stager.stage(batch.tensors)
+                    yield batch
+
+    _loader_cls["cls"] = HipFeatureDataLoader
+    return HipFeatureDataLoader
+
+
 class _HipBackendForTrainer(HipDPTrainingBackend):
     """constructor signature of ``FSDPTrainingBackend(parallel_config, *, optimizer_factory)`` (training/backend.py:158-165)"""
 
@@ -169,8 +276,8 @@ class _HipBackendForTrainer(HipDPTrainingBackend):
 
 
 def install(override: bool = False) -> None:
-    """Rebind the constructors the reference hard-codes (module docstring, b3): the trainer's backend and the configured
-    optimizer factory's class; with ``override=True`` also the draft registry entry ``LlamaForCausalLMEagle3``.
+    """Rebind the constructors the reference hard-codes (module docstring, b3 / f1): the trainer's backend, its feature
+    loader and the configured optimizer factory's class; with ``override=True`` also the draft registry entry ``LlamaForCausalLMEagle3``.
     Idempotent; ``uninstall()`` restores everything (e.g. before ``export --to sglang`` materialises the reference's
     own class from the same draft config)."""
     import specforge.optimizer as ref_opt
@@ -180,8 +287,14 @@ def install(override: bool = False) -> None:
     if "backend" not in _installed:
         _installed["backend"] = ref_trainer.FSDPTrainingBackend
         _installed["optimizer"] = ref_opt.BF16Optimizer
+        _installed["loader"] = ref_trainer.FeatureDataLoader
         ref_trainer.FSDPTrainingBackend = _HipBackendForTrainer
         ref_opt.BF16Optimizer = BF16Optimizer   # _ConfiguredOptimizerFactory imports the name at call time (assembly.py:261)
+        ref_trainer.FeatureDataLoader = feature_loader_class()   # trainer.py:145: the offline batches arrive device-resident
+        import specforge.launch as ref_launch
+
+        _installed["eval_loader"] = ref_launch.FeatureDataLoader
+        ref_launch.FeatureDataLoader = feature_loader_class()    # launch.py:276: the offline eval loader
     if override and "draft" not in _installed:
         import specforge.modeling.draft.llama3_eagle  # noqa: F401  (makes sure the reference class is registered first)
 
@@ -200,6 +313,10 @@ def uninstall() -> None:
     if "backend" in _installed:
         ref_trainer.FSDPTrainingBackend = _installed.pop("backend")
         ref_opt.BF16Optimizer = _installed.pop("optimizer")
+        ref_trainer.FeatureDataLoader = _installed.pop("loader")
+        import specforge.launch as ref_launch
+
+        ref_launch.FeatureDataLoader = _installed.pop("eval_loader")
     if "draft" in _installed:
         DRAFT_REGISTRY[REFERENCE_ARCHITECTURE] = _installed.pop("draft")
 

@@ -139,7 +139,10 @@ def test_reference_trainer_fit_reproduces_the_reference_run(ref, golden_dir, tmp
         batch_size=c["batch_size"], max_steps=nsteps, total_steps=c["steps"], num_epochs=2, seed=c["seed"],
         logger=lambda m, s: logged.append((s, m)), log_interval=1)
     assert type(trainer.backend).__name__ == "_HipBackendForTrainer"
+    # f1: the trainer's batches come from the HIP ingest (reference_plugin.feature_loader_class), not the reference's loader
+    assert type(trainer._loader) is ref.feature_loader_class() and trainer._loader._ingest is None
     assert trainer.fit() == nsteps
+    assert trainer._loader._ingest is not None and trainer._loader._stager is None       # ... through the direct reader
     assert [s for s, _ in logged] == list(range(1, nsteps + 1))
     for (s, got), want in zip(logged, blob["logged"]):
         assert {"loss", "acc", "ploss_0", "acc_0", "acceptance_rate_0", "grad_norm", "lr"} <= set(got)   # _reduce_eagle3_metrics ran
@@ -152,6 +155,74 @@ def test_reference_trainer_fit_reproduces_the_reference_run(ref, golden_dir, tmp
     want_keys = [k for k in blob["init_state"] if "embed" not in k]
     assert sorted(state["draft_state_dict"]) == sorted(want_keys)
     assert "replicated_optimizer_state" in state and "fp32_params" in state["replicated_optimizer_state"]
+
+
+def test_plugin_loader_yields_the_reference_loaders_batches(ref, golden_dir, tmp_path):
+    """f1: ``HipFeatureDataLoader`` (what ``install()`` binds in place of ``FeatureDataLoader``, trainer.py:145) against the
+    reference's own loader over the same refs, normaliser and collator -- batch for batch, tensor for tensor, ids and
+    metadata included; ``seek`` / ``set_epoch`` / ``drop_last=False`` (the eval loader keeps the partial batch);
+    a ``.ckpt.gz`` dataset takes the reference's materialisation (staged), with the same result."""
+    import gzip
+    import shutil
+
+    from specforge.launch import _offline_io, _shard_offline_refs
+    from specforge.runtime.data_plane import FeatureDataLoader, LocalFeatureStore
+
+    blob = torch.load(os.path.join(golden_dir, "loss_curve_tiny.pt"), weights_only=False)
+    c = blob["cfg"]
+    dj, feat, td, vp = _write_run_dir(str(tmp_path), blob, ref.DRAFT_ARCHITECTURE)
+    alg = ref.registry().resolve(ref.ALGORITHM_NAME)
+    collate, transform = _offline_io(alg, "text", c["max_len"], ttt_length=c["ttt"], use_usp_preprocess=False)
+    Hip = ref.feature_loader_class()
+
+    def batches(cls, refs, **kw):
+        kw = dict(dict(batch_size=2, collate_fn=collate, per_sample_transform=transform, strategy=alg.name), **kw)
+        return cls(LocalFeatureStore("t"), refs=refs, **kw)
+
+    def same(a, b):
+        assert a.sample_ids == b.sample_ids and a.strategy == b.strategy and a.metadata == b.metadata
+        assert set(a.tensors) == set(b.tensors)
+        for k, v in b.tensors.items():
+            assert a.tensors[k].shape == v.shape and a.tensors[k].dtype == v.dtype and torch.equal(a.tensors[k].cpu(), v), k
+
+    source = alg.providers.offline_for("text").build_reader(feat, run_id="t", ttt_length=c["ttt"], max_len=c["max_len"]).read()
+    for epoch in (0, 1):
+        refs = _shard_offline_refs(source, use_usp_preprocess=False, seed=3, epoch=epoch, dp_rank=0, dp_size=1)
+        want = list(batches(FeatureDataLoader, refs))
+        hip = batches(Hip, refs)
+        got = []
+        for b in hip:                       # a batch is valid until the next is requested: compare inside the loop
+            same(b, want[len(got)])
+            got.append(b.sample_ids)
+        assert len(got) == len(want) > 1 and hip._ingest is not None
+    # seek (resume) + drop_last=False (eval loader: an odd number of refs leaves a partial batch)
+    odd = refs[:5]
+    want = list(batches(FeatureDataLoader, odd, drop_last=False))
+    hip = batches(Hip, odd, drop_last=False)
+    n = 0
+    for b in hip:
+        same(b, want[n])
+        n += 1
+    assert n == 3 and want[-1].tensors["input_ids"].shape[0] == 1
+    hip.seek(2)
+    rest = [b.sample_ids for b in hip]
+    assert rest == [want[2].sample_ids]
+    with pytest.raises(ValueError):
+        hip.seek(4)
+    # .ckpt.gz: not the direct reader's format -> the reference's own _make_batch, same batches
+    gz = os.path.join(str(tmp_path), "gz")
+    os.makedirs(gz)
+    for name in sorted(os.listdir(feat)):
+        with open(os.path.join(feat, name), "rb") as fi, gzip.open(os.path.join(gz, name + ".gz"), "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+    grefs = alg.providers.offline_for("text").build_reader(gz, run_id="t", ttt_length=c["ttt"], max_len=c["max_len"]).read()
+    want = list(batches(FeatureDataLoader, grefs))
+    hip = batches(Hip, grefs)
+    n = 0
+    for b in hip:
+        same(b, want[n])
+        n += 1
+    assert n == len(want) and hip._ingest is None
 
 
 def test_reference_evaluator_runs_over_the_hip_strategy(ref, golden_dir, tmp_path):
