@@ -37,6 +37,24 @@ LLAMA3_8B = dict(hidden_size=4096, intermediate_size=14336, num_attention_heads=
                  max_position_embeddings=2048, rms_norm_eps=1e-5, rope_theta=500000.0,
                  rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
                                    original_max_position_embeddings=8192))
+# The other BASELINE.json configurations (dims from the reference's configs/*.json: qwen3-8b-eagle3.json,
+# qwen3-30B-A3B-eagle3.1.json, deepseek-v3-671b-eagle3.json).  Each entry: model dims + the (batch, seq)
+# its line is quoted on.  `--config X` prints the same line (roofline, kernels, ...) for X; the driver's headline stays llama3-8b.
+QWEN3_8B = dict(hidden_size=4096, intermediate_size=12288, num_attention_heads=32, num_key_value_heads=8, vocab_size=151936,
+                draft_vocab_size=32000, head_dim=128, target_hidden_size=4096, max_position_embeddings=40960, rms_norm_eps=1e-6,
+                rope_theta=1000000.0)
+QWEN3_30B_A3B_EAGLE31 = dict(hidden_size=2048, intermediate_size=12288, num_attention_heads=32, num_key_value_heads=4,
+                             vocab_size=151936, draft_vocab_size=32000, head_dim=128, target_hidden_size=2048,
+                             max_position_embeddings=4096, rms_norm_eps=1e-6, rope_theta=1000000.0, fc_norm=True)
+DEEPSEEK_V3 = dict(hidden_size=7168, intermediate_size=40960, num_attention_heads=56, num_key_value_heads=8, vocab_size=129280,
+                   draft_vocab_size=32000, head_dim=128, target_hidden_size=7168, max_position_embeddings=163840, rms_norm_eps=1e-5)
+CONFIGS = {
+    # name: (dims, default batch, default seq, label)
+    "llama3-8b": (LLAMA3_8B, 8, 2048, "Llama-3-8B EAGLE3 offline draft"),
+    "qwen3-8b": (QWEN3_8B, 8, 2048, "Qwen3-8B EAGLE3 offline draft"),
+    "qwen3-30b-a3b-eagle31": (QWEN3_30B_A3B_EAGLE31, 1, 4096, "Qwen3-30B-A3B EAGLE3.1 offline draft (fc_norm)"),
+    "deepseek-v3": (DEEPSEEK_V3, 1, 2048, "DeepSeek-V3 671B EAGLE3 offline draft (H 7168, I 40960, Vt 129280)"),
+}
 SMALL = dict(hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=2, vocab_size=4096,
              draft_vocab_size=1024, head_dim=128, target_hidden_size=512, max_position_embeddings=2048, rms_norm_eps=1e-5)
 PEAK_BF16_TFLOPS = 2500.0
@@ -156,14 +174,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--config", default="llama3-8b", choices=sorted(CONFIGS),
+                    help="model dims + default batch x seq (llama3-8b = BASELINE.json configs[1], the headline)")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--seq", type=int, default=None)
     ap.add_argument("--ttt", type=int, default=7)
     ap.add_argument("--small", action="store_true", help="tiny model dims (smoke / debugging only; NOT the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seq", type=int, default=2048,
                     help="sequence length of the CPU baseline sample (B = 1; the headline step is 8 such samples)")
     ap.add_argument("--no-dense-mask", action="store_true", help="skip the dense-position-mask variant")
+    ap.add_argument("--dense-mask", action="store_true", help="run the dense-position-mask variant also when world > 1 (default: only at N = 1)")
+    ap.add_argument("--feed", default="hbm", choices=["hbm", "ingest", "cpu_batch", "cpu_batch_pageable"],
+                    help="where the TIMED region's batches come from: hbm = already resident (the metric's definition); ingest = feature "
+                         "files -> pinned slots -> copy stream (what `specforge train` gets through reference_plugin); cpu_batch = CPU "
+                         "(pageable) batches as the reference's FeatureDataLoader hands them over, staged by the strategy through pinned "
+                         "slots; cpu_batch_pageable = the reference's own blocking pageable .to(device)")
+    ap.add_argument("--no-feeds", action="store_true", help="skip the feed comparison legs (hbm / ingest / cpu_batch / cpu_batch_pageable)")
+    ap.add_argument("--feeds", action="store_true", help="run the feed comparison legs also when world > 1")
+    ap.add_argument("--feed-steps", type=int, default=None, help="steps per feed leg (default: min(steps, 6))")
     ap.add_argument("--dp-single", action="store_true", help="one gradient all-reduce after the sweep instead of overlapped buckets (A/B)")
     ap.add_argument("--force-dp", action="store_true", help="run the gradient collectives even at world size 1 (RCCL path on a 1-GPU box)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (launcher smoke test)")
@@ -207,8 +236,11 @@ def main():
     from specforge_amd.training import BF16Optimizer, HipDPTrainingBackend
 
     _lib.lib()  # fails loudly if libsfhip.so is missing
-    cfg = SMALL if args.small else LLAMA3_8B
-    B, S = args.batch, args.seq
+    cfg_dims, B0, S0, cfg_label = CONFIGS[args.config]
+    cfg = SMALL if args.small else cfg_dims
+    B, S = args.batch or B0, args.seq or S0
+    if S + args.ttt > cfg["max_position_embeddings"] + 20:      # the engine's RoPE table has max_position_embeddings + 20 rows
+        cfg = dict(cfg, max_position_embeddings=S + args.ttt)
     torch.manual_seed(0)
     model = LlamaForCausalLMEagle3(DraftConfig(**cfg), device=dev)
     t2d = torch.zeros(cfg["vocab_size"], dtype=torch.bool)
@@ -224,11 +256,59 @@ def main():
     eagle.engine.materialise_soft_targets = args.materialise_targets
     batches = [TrainBatch(make_batch(cfg, B, S, dev, 100 + rank * 10 + i), {"target_repr": "hidden_state"}) for i in range(2)]
 
-    def timed(strategy, nsteps, timer=None):
+    # ---- where a step's batch comes from (--feed).  hbm: resident (the metric).  The others are what a
+    # `specforge train` run sees: feature files through the HIP ingest, or CPU batches as the reference's loader hands them over.
+    feed_state = {}
+
+    def make_feed(kind):
+        """-> (strategy, next_batch(i), close())"""
+        if kind == "hbm":
+            return strat, (lambda i: batches[i % 2]), (lambda: None)
+        if kind in ("cpu_batch", "cpu_batch_pageable"):
+            if "cpu" not in feed_state:      # pageable host tensors, as DataCollatorWithPadding's torch.cat produces them
+                feed_state["cpu"] = [TrainBatch({k: v.cpu() for k, v in b.tensors.items()}, dict(b.metadata)) for b in batches]
+            st = strat if kind == "cpu_batch" else Eagle3TrainStrategy(eagle, target_head=head, pinned_staging=False)
+            return st, (lambda i: feed_state["cpu"][i % 2]), (lambda: None)
+        # ingest: the batches as feature files in the reference's offline format (scripts/prepare_hidden_states.py:446-480)
+        import shutil
+        import tempfile
+
+        from specforge_amd.ingest import HiddenStateIngest
+
+        if "dir" not in feed_state:
+            d = feed_state["dir"] = tempfile.mkdtemp(prefix=f"sf_bench_feed_r{rank}_", dir="/tmp")
+            files = []
+            for bi, b in enumerate(batches):
+                t = {k: v.cpu() for k, v in b.tensors.items()}
+                for j in range(B):
+                    fpath = os.path.join(d, f"{bi:02d}_{j:03d}.ckpt")
+                    torch.save({"input_ids": t["input_ids"][j].clone(), "loss_mask": t["loss_mask"][j].clone(),
+                                "hidden_state": t["target"][j:j + 1].clone(), "aux_hidden_state": t["hidden_state"][j:j + 1].clone()}, fpath)
+                    files.append(fpath)
+            feed_state["files"] = files
+            feed_state["ingest"] = HiddenStateIngest(files, batch_size=B, max_len=S, device=dev, shuffle=False)
+        files, ing = feed_state["files"], feed_state["ingest"]
+        groups = [files[:B], files[B:2 * B]] * 4096
+        it = ing.stream(groups)
+
+        def close():
+            it.close()
+
+        return strat, (lambda i: next(it)), close
+
+    def cleanup_feeds():
+        if "dir" in feed_state:
+            import shutil
+
+            shutil.rmtree(feed_state.pop("dir"), ignore_errors=True)
+
+    def timed(strategy, nsteps, timer=None, next_batch=None):
         """W warm-up steps were done by the caller; times exactly nsteps optimizer steps: barrier + synchronize on
         both sides, MAX over ranks."""
+        nb = next_batch or (lambda i: batches[i % 2])
+
         def step(i):
-            out = strategy.forward_loss(batches[i % 2])
+            out = strategy.forward_loss(nb(i))
             backend.backward(out.loss, is_boundary=True)
             backend.step()
             return out
@@ -254,10 +334,12 @@ def main():
             elapsed = float(t.item())
         return elapsed, out
 
-    timed(strat, args.warmup)                      # untimed warm-up
+    main_strat, main_next, main_close = make_feed(args.feed)
+    timed(main_strat, args.warmup, next_batch=main_next)          # untimed warm-up
     timer = KernelTimer()
     backend.comm_wait_events = []                    # (N > 1) event pairs around the waits for the bucket all-reduces
-    elapsed, out = timed(strat, args.steps, timer)
+    elapsed, out = timed(main_strat, args.steps, timer, next_batch=main_next)
+    main_close()
     loss = float(out.loss.detach())
     mask_density = float(eagle.last_artifacts["position_mask"].float().mean())   # of the timed steps (before the dense-mask variant)
     fl, gemm_ms, nlaunch = timer.summary("gemm_nt")
@@ -268,7 +350,7 @@ def main():
     # teacher's argmax always lands inside the draft vocabulary (head rows outside it are zero), so every row reads its
     # target -- the worst case of real data.  Reported beside the headline value, never instead of it.
     dense = None
-    if not args.no_dense_mask:
+    if not args.no_dense_mask and (world == 1 or args.dense_mask):
         hw = head.fc.weight.data.clone()
         hw[~t2d.to(dev)] = 0
         strat_dense = Eagle3TrainStrategy(eagle, target_head=TargetHead(hw))
@@ -276,6 +358,29 @@ def main():
         e2, out2 = timed(strat_dense, args.steps)
         pm = eagle.last_artifacts["position_mask"].float().mean()
         dense = {"value": tokens / e2, "ms_per_step": 1e3 * e2 / args.steps, "position_mask_density": float(pm)}
+
+    # ---- the same step under every feed (N = 1 unless --feeds): ms per step, same process, same box, no kernel timers.  The
+    # metric's `value` is the --feed of the timed region above (default hbm = the metric's definition); this table is what the
+    # `specforge train` path (ingest) and the reference loader's hand-over (cpu_batch*) cost beside it.
+    feeds = None
+    if not args.no_feeds and (world == 1 or args.feeds):
+        fs = args.feed_steps or min(args.steps, 6)
+        feeds = {"steps_per_leg": fs}
+        for kind in ("hbm", "ingest", "cpu_batch", "cpu_batch_pageable"):
+            st, nb, close = make_feed(kind)
+            try:
+                timed(st, 2, next_batch=nb)
+                e3, _ = timed(st, fs, next_batch=nb)
+                feeds[kind] = {"ms_per_step": 1e3 * e3 / fs, "tokens_per_s": world * B * S * fs / e3}
+            finally:
+                close()
+        for kind in ("ingest", "cpu_batch", "cpu_batch_pageable"):
+            feeds[kind]["vs_hbm"] = feeds[kind]["ms_per_step"] / feeds["hbm"]["ms_per_step"]
+        feeds["note"] = ("hbm: batches resident (metric definition).  ingest: feature files (page cache) -> preadv into pinned slots -> "
+                         "copy stream -> device TrainBatch: what reference_plugin.install() gives `specforge train`.  cpu_batch: pageable "
+                         "CPU batches (what the reference's FeatureDataLoader hands over) staged by the strategy through pinned slots + "
+                         "copy stream.  cpu_batch_pageable: the reference strategy's own CPU shift + blocking pageable .to(device).")
+    cleanup_feeds()
 
     # ---- RCCL evidence: the gradient all-reduce of each bucket, timed alone on the communicator (outside the timed region)
     rccl = None
@@ -354,11 +459,12 @@ def main():
         f_draft = 3.0 * (args.ttt * f_step + 2.0 * 3 * cfg["target_hidden_size"] * H)
         draft_tflops = f_draft * (tokens / world) / elapsed / 1e12
         line = {
-            "metric": "EAGLE3 draft train tokens/sec, Llama-3-8B target, seq2048 at 1/2/4/8 MI355X",
+            "metric": ("EAGLE3 draft train tokens/sec, Llama-3-8B target, seq2048 at 1/2/4/8 MI355X" if args.config == "llama3-8b" else
+                       f"EAGLE3 draft train tokens/sec, {args.config} target dims, seq{S}"),
             "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("SMALL-debug" if args.small else "Llama-3-8B EAGLE3 offline draft")
+            "config": {"workload": ("SMALL-debug" if args.small else cfg_label)
                        + f", bf16, per-GPU batch {B} x seq {S}, ttt {args.ttt}, optimizer step included",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": GEMM_KERNEL_NAME, "achieved": ach,
@@ -376,6 +482,9 @@ def main():
             "final_loss": loss,
             "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
         }
+        line["feed"] = args.feed
+        if feeds is not None:
+            line["feeds"] = feeds
         if dense is not None:
             line["dense_mask"] = dense
         if rccl is not None:

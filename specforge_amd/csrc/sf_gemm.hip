@@ -181,6 +181,11 @@ static int sf_gemm_check(long lda, long ldb, long ldc, long ldr, int M, int N, i
     SF_CHECK_ARG(ldc % 4 == 0 && ldr % 4 == 0, "sf_gemm_nt: ldc, ldr must be multiples of 4");
     SF_CHECK_ARG(c_dtype == SF_BF16 || c_dtype == SF_F32, "sf_gemm_nt: c_dtype");
     SF_CHECK_ARG(!(R && c_dtype == SF_F32), "sf_gemm_nt: residual epilogue is bf16-only");
+    // Operands of ANY total size are fine (a 2.7 GB [N, 2I] activation, an 18 GB stash): the LDS-DMA buffer descriptor is rebuilt per
+    // 256-row tile from a 64-bit base and only the offsets INSIDE a tile are 32-bit, range-checked against num_records = 2^31 - 1.
+    // What must fit is therefore one tile's span: 256 rows of the leading dimension plus the K advance.
+    SF_CHECK_ARG(256 * lda * 2 + (long)K * 2 < (1L << 31) && 256 * ldb * 2 + (long)K * 2 < (1L << 31),
+                 "sf_gemm_nt: 256 rows of an operand (256 * ld * 2 bytes + K * 2) must span less than 2 GiB (buffer-descriptor offsets are 32-bit)");
     return 0;
 }
 

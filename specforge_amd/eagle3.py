@@ -167,7 +167,11 @@ class Eagle3TrainStrategy:
     required_features = {"input_ids", "attention_mask", "loss_mask", "hidden_state", "target"}
 
     def __init__(self, eagle3_model: OnlineEagle3Model, *, target_head: Optional[TargetHead] = None,
-                 ploss_decay: float = 0.8, compact_teacher: bool = True, compact_teacher_chunk_size: Optional[int] = None):
+                 ploss_decay: float = 0.8, compact_teacher: bool = True, compact_teacher_chunk_size: Optional[int] = None,
+                 pinned_staging: bool = True):
+        """``pinned_staging=False`` (A/B only, ``bench.py --feed cpu_batch_pageable``): CPU batches are shifted on the CPU and
+        moved with the blocking pageable ``.to(device)`` the reference's strategy uses (strategies/base.py:256-284)."""
+        self.pinned_staging = pinned_staging
         self.eagle3_model = eagle3_model
         self.target_head = target_head
         self.ploss_decay = ploss_decay
@@ -189,7 +193,7 @@ class Eagle3TrainStrategy:
         a blocking pageable ``.to(device)``, strategies/base.py:270-289) goes through a pinned double buffer and a HIP copy
         stream -- the TTT shift of ``preprocess`` then runs on the device either way."""
         dev = self.eagle3_model.engine.dev
-        if dev.type != "cuda" or all(v is None or v.is_cuda for v in tensors.values()):
+        if dev.type != "cuda" or not self.pinned_staging or all(v is None or v.is_cuda for v in tensors.values()):
             return tensors
         if self._stager is None:
             from .ingest import PinnedStager

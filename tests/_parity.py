@@ -9,8 +9,9 @@ bf16 run alike, which then dominated every gradient comparison at 8-17 %).
 
 What is compared (BASELINE.json north_star tolerance for the bf16 path: 2e-2):
   * plosses / loss / acceptance rates / accuracy
-  * acc_denoms: bit-exact; teacher argmax ids and position mask (two bf16 GEMMs with fp32 accumulation in different
-    orders can differ in the last ulp, so exact ties may flip: >= 99.95 %, measured 100 %)
+  * acc_denoms: bit-exact; teacher argmax ids and position mask: bit-exact (== 100 %) at these real dimensions -- both sides
+    round the SAME fp32-accumulated bf16 GEMM on the same GPU (measured 100 % in every case since round 2; the >= 99.5 % slack
+    survives only in tests/test_configs.py's small cases, where the other side is a CPU bf16 GEMM with another summation order)
   * every parameter gradient: max-abs error relative to the tensor's max-abs, and relative Frobenius error
 The same numbers are taken for the oracle run entirely in bf16 (= what the reference itself produces at that
 precision with torch/hipBLASLt kernels), the yardstick each HIP number is printed beside.
@@ -108,7 +109,7 @@ def grad_errors(got, ref):
     return rows
 
 
-def compare(name, c, *, loss_tol=5e-3, ids_min=0.9995, grad_cap=6e-2, yardstick_factor=1.1):
+def compare(name, c, *, loss_tol=5e-3, ids_min=1.0, grad_cap=6e-2, yardstick_factor=1.1):
     """runs both sides, writes the report, asserts the bars; returns the report dict."""
     dev = torch.device("cuda", 0)
     ttt = c["ttt"]

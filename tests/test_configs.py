@@ -91,6 +91,9 @@ REAL = {
     # configs/qwen3-30B-A3B-eagle3.1.json (fc_norm, nh*hd = 2H)
     "cfg4_qwen3_30b_a3b_eagle31": dict(H=2048, Ht=2048, I=12288, nh=32, nkv=4, hd=128, Vt=151936, Vd=32000, B=2, S=512, ttt=7,
                                        eps=1e-6, max_pos=2048, rope_theta=1000000.0, fc_norm=True, lengths=[512, 77]),
+    # ... at its recipe's sequence length (bs 1 x 4096), a ragged pair
+    "cfg4_qwen3_30b_a3b_eagle31_s4096": dict(H=2048, Ht=2048, I=12288, nh=32, nkv=4, hd=128, Vt=151936, Vd=32000, B=2, S=4096,
+                                             ttt=7, eps=1e-6, max_pos=4096, rope_theta=1000000.0, fc_norm=True, lengths=[4096, 2931]),
     # configs/deepseek-v3-671b-eagle3.json (3*Ht = 21504 fusion input, I 40960, 129k vocabulary)
     "cfg5_deepseek_v3": dict(H=7168, Ht=7168, I=40960, nh=56, nkv=8, hd=128, Vt=129280, Vd=32000, B=1, S=512, ttt=7, eps=1e-5,
                              max_pos=163840, lengths=[509]),

@@ -131,3 +131,92 @@ def test_llama3_8b_seq2048_matches_oracle():
     from tests._parity import compare
 
     compare("cfg2_llama3_8b", LLAMA3_8B_CASE)
+
+
+@pytest.mark.gpu
+def test_llama3_8b_three_optimizer_steps_match_oracle_adamw():
+    """>= 3 OPTIMIZER steps at the headline dimensions (Llama-3-8B draft, S 2048, B 2, three different
+    batches) -- the HIP strategy + HipDPTrainingBackend + fused grad-norm / clip / AdamW over the flat buffers against the
+    pinned oracle's autograd + the reference optimizer's arithmetic (optimizer.py:104-168: global norm of the gradients, clip
+    coefficient clamp(max_norm / (norm + 1e-6), max = 1), ``torch.optim.AdamW`` on fp32 masters, bf16 parameters re-cast from
+    them) run on the same GPU.  Truth = the oracle with the draft computing in fp32 from the bf16-rounded parameters;
+    yardstick = the same loop with the draft computing in bf16 (what the reference itself does at that precision).
+    Compared at every step: loss, plosses, grad_norm, learning rate; after the last: every tensor's fp32 MASTER update
+    (w_3 - w_0), whose error must stay within 1.25x the yardstick's (Adam's normalised update amplifies sign noise of
+    near-zero gradients alike on both sides) -- flat-buffer aliasing or a drifting fused AdamW would show as O(1)."""
+    from oracle import eagle3_oracle as O
+    from specforge_amd.training import BF16Optimizer, HipDPTrainingBackend
+    from tests._parity import _cfg_kw, make_case
+
+    dev = torch.device("cuda", 0)
+    c = dict(LLAMA3_8B_CASE)
+    ttt, steps, lr, max_norm = c["ttt"], 3, 2e-4, 0.5
+    oc, params, embed, head_w, t2d, d2t, _ = make_case(c)
+    batches = [O.make_batch(oc, c["B"], c["S"], seed=40 + i, dtype=torch.bfloat16, lengths=[2048, 1500 + 100 * i]) for i in range(steps)]
+
+    def oracle_loop(dtype):
+        masters = {k: v.to(dev).float().requires_grad_(True) for k, v in params.items()}
+        opt = torch.optim.AdamW(list(masters.values()), lr=lr, weight_decay=0.0)
+        hist = []
+        for b in batches:
+            p = {k: m.detach().to(torch.bfloat16).to(dtype).requires_grad_(True) for k, m in masters.items()}   # bf16 parameters
+            out = O.eagle3_forward(p, oc, embed_weight=embed.to(dev).to(dtype), target_head_weight=head_w.to(dev), t2d=t2d.to(dev),
+                                   d2t=d2t.to(dev), input_ids=b["input_ids"].to(dev), attention_mask=b["attention_mask"],
+                                   loss_mask=b["loss_mask"].to(dev), hidden_state=b["hidden_state"].to(dev).to(dtype),
+                                   target_hidden=b["target"].to(dev), ttt_length=ttt)
+            out.loss.backward()
+            grads = {k: (v.grad.to(torch.bfloat16) if dtype == torch.bfloat16 else v.grad).float() for k, v in p.items()}
+            norm = torch.stack([g.square().sum() for g in grads.values()]).sum().sqrt()
+            coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+            for k, m in masters.items():
+                m.grad = grads[k] * coef
+            opt.step()
+            opt.zero_grad()
+            hist.append(dict(loss=float(out.loss), plosses=[float(x) for x in out.plosses], grad_norm=float(norm)))
+            del p, out, grads
+            torch.cuda.empty_cache()
+        return hist, {k: m.detach().clone() for k, m in masters.items()}
+
+    truth_hist, truth_w = oracle_loop(torch.float32)
+    yard_hist, yard_w = oracle_loop(torch.bfloat16)
+
+    model = LlamaForCausalLMEagle3(DraftConfig(**_cfg_kw(c)), device=dev)
+    sd = dict(params)
+    sd["embed_tokens.weight"], sd["t2d"], sd["d2t"] = embed, t2d, d2t
+    model.load_state_dict(sd)
+    eagle = OnlineEagle3Model(model, length=ttt).train()
+    strat = Eagle3TrainStrategy(eagle, target_head=TargetHead(head_w.to(dev)))
+    backend = HipDPTrainingBackend(optimizer_factory=lambda m: BF16Optimizer(m, lr=lr, max_grad_norm=max_norm, warmup_ratio=0.0,
+                                                                             lr_scheduler="constant", total_steps=1000))
+    backend.prepare_model(eagle)
+    hip_hist = []
+    for b in batches:
+        out = strat.forward_loss(TrainBatch(dict(input_ids=b["input_ids"], attention_mask=b["attention_mask"], loss_mask=b["loss_mask"],
+                                                 hidden_state=b["hidden_state"].to(dev), target=b["target"].to(dev)),
+                                            {"target_repr": "hidden_state"}))
+        backend.backward(out.loss, is_boundary=True)
+        assert abs(backend.optimizer.get_learning_rate() - lr) < 1e-12
+        gn = backend.step()
+        hip_hist.append(dict(loss=float(out.loss), plosses=[float(x) for x in out.metrics["plosses"]], grad_norm=float(gn)))
+    f, master = eagle.engine.flat, backend.optimizer.master
+    rep = []
+    for i, (h, t, y) in enumerate(zip(hip_hist, truth_hist, yard_hist)):
+        rep.append((i, h["loss"], t["loss"], y["loss"], h["grad_norm"], t["grad_norm"], y["grad_norm"]))
+        assert abs(h["loss"] - t["loss"]) <= 5e-3 * max(1.0, abs(t["loss"])), rep[-1]
+        assert max(abs(a - b) for a, b in zip(h["plosses"], t["plosses"])) <= 5e-3, (i, h["plosses"], t["plosses"])
+        assert abs(h["grad_norm"] - t["grad_norm"]) <= max(2e-2, 1.25 * abs(y["grad_norm"] - t["grad_norm"])) * t["grad_norm"], rep[-1]
+    print("\n[3 optimizer steps, Llama-3-8B dims] (step, loss hip / fp32 / bf16, grad_norm hip / fp32 / bf16):", rep)
+    worst = {}
+    for k, w0 in params.items():
+        lo, hi = f.slices[k]
+        w0 = w0.to(dev).float()
+        d_hip, d_true, d_yard = master[lo:hi].view(w0.shape) - w0, truth_w[k] - w0, yard_w[k] - w0
+        e_hip = float((d_hip - d_true).norm() / d_true.norm().clamp_min(1e-20))
+        e_yard = float((d_yard - d_true).norm() / d_true.norm().clamp_min(1e-20))
+        worst[k] = (round(e_hip, 4), round(e_yard, 4))
+        # the update has the right size everywhere (an aliasing / slicing bug moves the wrong elements)
+        assert 0.5 <= float(d_hip.norm() / d_true.norm().clamp_min(1e-20)) <= 2.0, (k, worst[k])
+        assert e_hip <= max(0.05, 1.25 * e_yard), (k, worst[k])
+        # the bf16 parameters ARE the rounded masters (flat data aliases the module's parameters)
+        assert torch.equal(dict(model.named_parameters())[k].detach(), master[lo:hi].view(w0.shape).to(torch.bfloat16)), k
+    print("[3 optimizer steps] master update error vs fp32 truth, relative Frobenius (hip, bf16 yardstick):", worst)

@@ -149,7 +149,14 @@ def test_gemm_nt_teacher_headline_chunk():
         ops.teacher_reduce_perm(z[:, :vz], Vt=Vt, Vd=Vd, perm=perm.to(torch.int32), t2d_u8=t2d.to(torch.uint8), loss_mask_pad=lm, S=S,
                                 Spad=Spad, part=part, nparts=nparts, **o)
         res.append(o)
+        if fused:         # the STORED (draft-range) logits of the reduced form: the plain form's, bit for bit
+            assert torch.equal(z[:, :vz], z_plain[:, :vz])
         if not fused:     # the stored logits against fp32 torch, and the ids against torch.argmax on the natural layout
+            z_plain = z
+            for m0 in range(0, M, 1024):
+                zr = x[m0:m0 + 1024].float() @ wp.float().t()
+                err = float((z[m0:m0 + 1024].float() - zr).abs().max())
+                assert err <= 3e-3 * float(zr.abs().max()) + 1e-3, (m0, err)      # one bf16 rounding of an fp32-accumulated sum
             inv = torch.empty_like(perm); inv[perm] = torch.arange(Vt, device=DEV)
             want = torch.empty(M, dtype=torch.int64, device=DEV)
             for m0 in range(0, M, 1024):
@@ -225,9 +232,11 @@ def test_gemm_bitwise_determinism(form, M, N, K):
         assert torch.equal(o, first), f"run {i + 1} differs from run 0"
 
 
-@pytest.mark.parametrize("S,lengths", [(1024, [1024, 651]), (2048, [2048, 1675])])
+@pytest.mark.parametrize("S,lengths", [(1024, [1024, 651]), (2048, [2048, 1675]), (4096, [4096, 2817])])
 @pytest.mark.parametrize("nsteps", [1, 7])
 def test_ttt_attention_long(S, lengths, nsteps):
+    # S 4096 (cfg 4's recipe: bs 1 x 4096): 128 query blocks per (batch, kv head) -- twice what one XCD holds of the
+    # pair-major forward / dQ work order, 64 key tiles per query row
     from tests.test_attention import _mk, _oracle
 
     B, nh, nkv, hd = 2, 4, 2, 128
