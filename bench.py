@@ -48,12 +48,17 @@ QWEN3_30B_A3B_EAGLE31 = dict(hidden_size=2048, intermediate_size=12288, num_atte
                              max_position_embeddings=4096, rms_norm_eps=1e-6, rope_theta=1000000.0, fc_norm=True)
 DEEPSEEK_V3 = dict(hidden_size=7168, intermediate_size=40960, num_attention_heads=56, num_key_value_heads=8, vocab_size=129280,
                    draft_vocab_size=32000, head_dim=128, target_hidden_size=7168, max_position_embeddings=163840, rms_norm_eps=1e-5)
+# head_dim 256 (configs/qwen3-next-80b-a3b-eagle3.json; gemma3-1b and qwen3.5-35b-a3b share the head shape)
+QWEN3_NEXT_80B_A3B = dict(hidden_size=2048, intermediate_size=16384, num_attention_heads=16, num_key_value_heads=2, vocab_size=151936,
+                          draft_vocab_size=32000, head_dim=256, target_hidden_size=2048, max_position_embeddings=8192,
+                          rms_norm_eps=1e-6, rope_theta=10000000.0)
 CONFIGS = {
     # name: (dims, default batch, default seq, label)
     "llama3-8b": (LLAMA3_8B, 8, 2048, "Llama-3-8B EAGLE3 offline draft"),
     "qwen3-8b": (QWEN3_8B, 8, 2048, "Qwen3-8B EAGLE3 offline draft"),
     "qwen3-30b-a3b-eagle31": (QWEN3_30B_A3B_EAGLE31, 1, 4096, "Qwen3-30B-A3B EAGLE3.1 offline draft (fc_norm)"),
     "deepseek-v3": (DEEPSEEK_V3, 1, 2048, "DeepSeek-V3 671B EAGLE3 offline draft (H 7168, I 40960, Vt 129280)"),
+    "qwen3-next-80b-a3b": (QWEN3_NEXT_80B_A3B, 8, 2048, "Qwen3-Next-80B-A3B EAGLE3 offline draft (head_dim 256, 16 / 2 heads)"),
 }
 SMALL = dict(hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=2, vocab_size=4096,
              draft_vocab_size=1024, head_dim=128, target_hidden_size=512, max_position_embeddings=2048, rms_norm_eps=1e-5)

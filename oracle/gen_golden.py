@@ -203,3 +203,7 @@ if __name__ == "__main__":
         pos3 = torch.stack([tt, hh, ww]) + torch.tensor([0, 3]).view(1, 2, 1)      # second sample offset
         run_case("eagle3_rope_mrope_fp32", rope_scaling=dict(rope_type="mrope", mrope_section=[8, 12, 12]), seed=12,
                  position_ids=pos3, **small)
+    if want("hd256"):  # head_dim 256 (configs/gemma3-1b-eagle3.json: 4 / 1 heads; qwen3-next-80b-a3b, qwen3.5-35b-a3b: 16 / 2):
+        # nh * hd > H like those recipes; the reference's attention takes any head_dim (llama3_eagle.py:547-550)
+        run_case("eagle3_hd256_fp32", H=128, Ht=64, I=192, nh=2, nkv=1, hd=256, Vt=384, Vd=128, B=2, S=40, lengths=[40, 27],
+                 ttt=4, dtype=torch.float32, seed=13)

@@ -54,7 +54,7 @@ SF_DEVICE void mask_scores(sf_v16f& s, int rel) {
 }
 
 template <int HD, int NW>
-SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
+SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, AttnOcc<HD>::kWgPerCu) attn_fwd_kernel(AttnFwdArgs p) {
     constexpr int KS = HD / 16, DB = HD / 32, QB = NW * 32, TILE = 128 * HD * 2;
     SF_DYN_SMEM(smem);  // 2 x { K [64][HD], V [64][HD] }
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
@@ -202,6 +202,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
         for (int i = 0; i < p.ndiag; ++i) {
             sf_wait_vm0();
             sf_wave_lockstep();   // (interpreter only: the other lanes' pieces of this wave's DMA have been copied)
+            if constexpr (HD <= 128) {
             sf_v8s kk[KS];
             sf_v4s vv4[DB * 4];
 #pragma unroll
@@ -236,6 +237,33 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_fwd_kernel(AttnFwdArgs p) {
                     for (int t = 0; t < 4; ++t)
                         acc_o[d][4 * j + t] = acc_o[d][4 * j + t] * alpha + e * sf_bf2f((sf_bf16)vv[t]);
                 }
+            } else {
+            // head_dim 256: the query fragments and the output accumulators are 192 registers of the wave already -- the branch's
+            // K_i / V_i rows are consumed from LDS a few registers at a time, and the next branch is staged only after the last read
+            float dp = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) dp += dot8(qf[ks], frag_rows<HD>(mine, 0, ks, fo));
+            dp = sf_pair_sum(dp);
+            const float s2 = dp * sc;
+            const float mn = fmaxf(m, s2);
+            const float alpha = sf_exp2(m - mn);
+            const float e = sf_exp2(s2 - mn);
+            m = mn;
+            l = l * alpha + e;
+            const char* vrow = mine + 32 * HD * 2 + c * (HD * 2) + 8 * hi;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const sf_v4s vv = *reinterpret_cast<const sf_v4s*>(vrow + (((4 * d + j) ^ swz<HD>(c)) << 4));
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc_o[d][4 * j + t] = acc_o[d][4 * j + t] * alpha + e * sf_bf2f((sf_bf16)vv[t]);
+                }
+#pragma unroll
+            for (int d = 0; d < DB; ++d) sf_pin(acc_o[d]);       // every LDS read of this branch has returned
+            if (i + 1 < p.ndiag) stage_diag(i + 1);
+            }
         }
     }
     if (!qok) return;
@@ -388,7 +416,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_pre_kernel(AttnBwdPreArgs p) {
 // ------------------------------------------------------------- backward: dQ
 
 template <int HD, int NW>
-SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
+SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, AttnOcc<HD>::kWgPerCu) attn_bwd_dq_kernel(AttnBwdArgs p) {
     constexpr int KS = HD / 16, DB = HD / 32, QB = NW * 32, TILE = 128 * HD * 2;
     SF_DYN_SMEM(smem);  // 2 x { K [64][HD], V [64][HD] }; K serves both S^T = K.Q^T and (transpose-read) dQ^T += K^T.dS^T
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
@@ -573,7 +601,7 @@ extern "C" int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo,
     SF_CHECK_ARG(ndiag == 0 || dq_init, "sf_attn_bwd_pre: dq_init required with diagonal branches");
     SF_CHECK_ARG((!dk_last && !dv_last) || (dk_last && dv_last && ndiag > 0 && ld_last % 8 == 0),
                  "sf_attn_bwd_pre: dk_last / dv_last come together, need a diagonal branch and 16-byte aligned rows");
-    SF_CHECK_ARG(hd == 64 || hd == 128, "head_dim must be 64 or 128");
+    SF_CHECK_ARG(hd == 64 || hd == 128 || hd == 256, "head_dim must be 64, 128 or 256");
     SF_CHECK_ARG(ldq % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldk % 8 == 0 && lddk % 4 == 0,
                  "sf_attn_bwd_pre: strides must be multiples of 8 (16-byte row segments)");
     const int rows_per_block = 64 / (hd / 8);

@@ -50,10 +50,16 @@ struct AttnBwdArgs {
 // swz = ((r & 3) << 2) ^ ((r >> 2) & 3) is a bijection of r mod 16 onto 0..15, so a ds_read_b128 of 16
 // consecutive rows at one logical chunk is conflict-free, and the 8 (row, column-half) pieces of a 32-lane
 // ds_read_b64_tr_b16 pass land in 8 distinct 32-byte bank slots.  HD = 64 (8 chunks per row): r & 7.
+// HD = 256 (32 chunks per 512-byte row = two 256-byte bank spans): the same 4-bit value XORed into the LOW four bits of the
+// chunk index -- a chunk stays in its half of the row, and its position inside the bank span is permuted exactly as at HD 128.
 template <int HD>
 SF_DEVICE int swz(int r) {
-    return HD == 128 ? (((r & 3) << 2) ^ ((r >> 2) & 3)) : (r & 7);
+    return HD >= 128 ? (((r & 3) << 2) ^ ((r >> 2) & 3)) : (r & 7);
 }
+// Workgroups per CU of the MFMA attention kernels (fwd, dQ): two 4-wave workgroups (2 waves per SIMD, 256 registers each) up to
+// head_dim 128; at head_dim 256 the output accumulators alone are 128 registers per wave and the K / V ring is 128 KiB of LDS:
+// one workgroup per CU with the whole register file.
+template <int HD> struct AttnOcc { static constexpr int kWgPerCu = HD > 128 ? 1 : 2; };
 
 // ---- LDS tile staging -------------------------------------------------------
 // A tile of R rows x HD (row-major in LDS, 16-byte chunks XOR-swizzled by swz<HD>(row)) arrives as R*HD*2/1024 pieces
@@ -102,36 +108,41 @@ SF_DEVICE SfBufB rows_buf(const sf_bf16* base, long ld, int S) {
 // rows, so (row & 7) == (lane & 7) for every fragment row.
 template <int HD>
 struct FragOff {
-    int rows[HD / 16];  // natural tile, k-step ks: (lane&31)*rowbytes + swizzled chunk (2ks + hi)
-    int tr[HD / 32][2]; // transpose-read of a natural tile, 32-column block db, rows r0+.. / r0+8+..: this lane's piece
+    // chunk indices at or above 16 (HD = 256) differ from those below only in bit 4, which the swizzle leaves alone: entry
+    // i + NR of either table is entry i + 256 bytes -- an immediate offset of the read instead of another register
+    static constexpr int NR = HD / 16 > 8 ? 8 : HD / 16, NT = HD / 32 > 4 ? 4 : HD / 32;
+    int rows[NR];     // natural tile, k-step ks: (lane&31)*rowbytes + swizzled chunk (2ks + hi)
+    int tr[NT][2];    // transpose-read of a natural tile, 32-column block db, rows r0+.. / r0+8+..: this lane's piece
     SF_DEVICE void init(int lane) {
         const int c = lane & 31, hi = lane >> 5;
 #pragma unroll
-        for (int ks = 0; ks < HD / 16; ++ks) rows[ks] = c * (HD * 2) + (((2 * ks + hi) ^ swz<HD>(c)) << 4);
+        for (int ks = 0; ks < NR; ++ks) rows[ks] = c * (HD * 2) + (((2 * ks + hi) ^ swz<HD>(c)) << 4);
         // ds_read_b64_tr_b16: 16-lane group (lane>>4) covers tile rows r0 + 4*hi + 0..3 and columns
         // db*32 + 16*((lane>>4)&1) + 0..15; lane i of the group supplies piece i = (row i/4, cols 4*(i%4)..+3)
         const int i = lane & 15, t = 2 * ((lane >> 4) & 1) + ((i >> 1) & 1);
 #pragma unroll
-        for (int db = 0; db < HD / 32; ++db)
+        for (int db = 0; db < NT; ++db)
 #pragma unroll
             for (int sec = 0; sec < 2; ++sec) {
                 const int qx = 8 * sec + 4 * hi + (i >> 2);  // tile row (mod 16; r0 is a multiple of 16)
                 tr[db][sec] = qx * (HD * 2) + ((((4 * db + t) ^ swz<HD>(qx))) << 4) + (i & 1) * 8;
             }
     }
+    SF_DEVICE int row_off(int ks) const { return rows[ks % NR] + (ks / NR) * 256; }
+    SF_DEVICE int tr_off(int db, int sec) const { return tr[db % NT][sec] + (db / NT) * 256; }
 };
 // A fragment (32 rows x 16 k) from a natural tile: row = r0 + (lane&31), k = 16*ks + 8*(lane>>5)
 template <int HD>
 SF_DEVICE sf_v8s frag_rows(const char* lds, int r0, int ks, const FragOff<HD>& fo) {
-    return *reinterpret_cast<const sf_v8s*>(lds + r0 * (HD * 2) + fo.rows[ks]);
+    return *reinterpret_cast<const sf_v8s*>(lds + r0 * (HD * 2) + fo.row_off(ks));
 }
 // A fragment for the "C-layout as B operand" contraction, taken from a NATURAL tile X[row][d] with the
 // hardware transpose read: MFMA row = column d = db*32 + (lane&31) of the tile, k-slots = tile rows
 // {r0 + 4*hi + 0..3} and {r0 + 8 + 4*hi + 0..3}  (r0 multiple of 16)
 template <int HD>
 SF_DEVICE sf_v8s frag_tr(const char* lds, int db, int r0, const FragOff<HD>& fo) {
-    const sf_v4s lo = sf_ds_read_tr16(lds + r0 * (HD * 2) + fo.tr[db][0]);
-    const sf_v4s up = sf_ds_read_tr16(lds + r0 * (HD * 2) + fo.tr[db][1]);
+    const sf_v4s lo = sf_ds_read_tr16(lds + r0 * (HD * 2) + fo.tr_off(db, 0));
+    const sf_v4s up = sf_ds_read_tr16(lds + r0 * (HD * 2) + fo.tr_off(db, 1));
     return sf_v8s{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
 }
 SF_DEVICE sf_v8s pack_bf16x8(const sf_v16f& p, int r0) {
@@ -297,5 +308,6 @@ template <int PROF> struct SfProf {
     do {                                                          \
         if ((hd) == 128) { constexpr int HD = 128; CALL; }        \
         else if ((hd) == 64) { constexpr int HD = 64; CALL; }     \
-        else SF_CHECK_ARG(false, "head_dim must be 64 or 128");   \
+        else if ((hd) == 256) { constexpr int HD = 256; CALL; }   \
+        else SF_CHECK_ARG(false, "head_dim must be 64, 128 or 256"); \
     } while (0)

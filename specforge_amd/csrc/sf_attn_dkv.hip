@@ -288,6 +288,160 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
     });
 }
 
+// ------------------------------------------------ head_dim 256: the role-split kernel
+// At head_dim 256 both gradients of 32 keys are 256 accumulator registers -- the whole AGPR file, with the K / V fragments
+// (another 128) nowhere to go -- so the one-wave-owns-both-gradients kernel above does not exist for it.  This is round 2's
+// kernel (compiler-scheduled builtin MFMAs, generic in HD), kept for that case: the two gradients of a key sub-block go to
+// two waves, each recomputing S; at HD 256 a wave carries 128 accumulator + 128 fragment registers, so the workgroup is 4 waves
+// (2 key sub-blocks x 2 roles = 64 keys), one wave per SIMD.  Shipped recipes with head_dim 256 (gemma3-1b, qwen3-next-80b-a3b,
+// qwen3.5-35b-a3b: llama3_eagle.py:547-550 takes any head_dim) have 4 / 16 query heads: attention is a few percent of their step.
+// Workgroup = NW waves = NW/2 key sub-blocks of 32 keys x 2 roles: waves [0, NW/2) accumulate dV^T,
+// waves [NW/2, NW) accumulate dK^T of the same keys (each recomputes S; a wave then carries ONE
+// 64-register accumulator set, so the kernel fits 2 waves/SIMD without spilling and the two roles
+// of a key sub-block sit on the same SIMD and overlap exp/LDS work with MFMA).
+// LDS (double buffered): Q [64][HD], dO [64][HD], lse2[64], delta[64]; Q^T / dO^T fragments come from the
+// same tiles through the hardware transpose read
+template <int HD, int NW>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, NW / 4) attn_bwd_dkv_rs_kernel(AttnBwdArgs p) {
+    constexpr int KS = HD / 16, DB = HD / 32, NSUB = NW / 2, KB = NSUB * 32, TILE = 128 * HD * 2 + 512;
+    SF_DYN_SMEM(smem);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
+    const int role = wave / NSUB;  // 0: dV, 1: dK   (wave-uniform)
+    const int sub = wave - role * NSUB;
+    // 1-D grid, heaviest first: key block 0 sees every query tile, the last one only the final tiles
+    const int per_kb = p.nkv * p.B;
+    int kbi, g, b;
+    if (p.l2_map) {   // pair-major: the key blocks of one (batch, kv head) stream the same Q / dO tiles
+        const int nkb = (p.S + KB - 1) / KB;
+        const int v = attn_work_index((int)blockIdx.x, nkb * per_kb, 1);
+        if (v >= nkb * per_kb) return;
+        const int pr = v / nkb;
+        kbi = v - pr * nkb; b = pr / p.nkv; g = pr - b * p.nkv;
+    } else {
+        const int bid = (int)blockIdx.x, gb = bid % per_kb;
+        kbi = bid / per_kb; g = gb % p.nkv; b = gb / p.nkv;
+    }
+    const int kb0 = kbi * KB;
+    const int S = p.S, nrep = p.nh / p.nkv;
+    const int kvlen = p.kv_len ? p.kv_len[b] : S;
+    const int kw0 = kb0 + sub * 32;
+    const int ki = kw0 + c;  // this lane's key (column of S)
+    const bool kok = ki < S;
+    const long krow = (long)b * S + (kok ? ki : S - 1);
+    const float sc = p.scale * kLog2e;
+    FragOff<HD> fo;
+    fo.init(lane);
+
+    sf_v8s kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *reinterpret_cast<const sf_v8s*>(p.k0 + krow * p.ldk + g * HD + 16 * ks + 8 * hi);
+        vf[ks] = kf[ks];
+        if (role == 1) vf[ks] = *reinterpret_cast<const sf_v8s*>(p.v0 + krow * p.ldv + g * HD + 16 * ks + 8 * hi);
+    }
+    sf_v16f acc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+    const bool block_live = kb0 < kvlen;  // keys at/after kv_len never receive probability mass
+    const int qt_first = kb0 / 64;
+    const int nqt = (S + 63) / 64;
+    // a query q of the tile is visible to this lane's key iff  ki <= q < S  (and the key itself is valid): with
+    // q = q0 + 4*hi + C (C a compile-time constant per register) that is  lo <= C < up  for two per-tile values
+    const int key_lo = ki < kvlen ? ki : 0x3fffffff;
+    TileStage<HD, 64, NW> stq, stdo;
+    stq.init(p.ldq, wave, lane);
+    stdo.init(p.lddo, wave, lane);
+    const unsigned qtile = (unsigned)(64 * p.ldq * 2), dotile = (unsigned)(64 * p.lddo * 2);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { sf_pin(kf[ks]); sf_pin(vf[ks]); }   // complete HERE (see TileStage)
+    int it = 0;
+    if (block_live)
+        for (int hh = 0; hh < nrep; ++hh) {
+            const int h = g * nrep + hh;
+            const SfBufB qbuf = rows_buf<HD>(p.q + (long)b * S * p.ldq + h * HD, p.ldq, S);
+            const SfBufB dobuf = rows_buf<HD>(p.dout + (long)b * S * p.lddo + h * HD, p.lddo, S);
+            const SfBufB lsebuf = sf_make_bufb(p.lse + ((long)b * p.nh + h) * S, (unsigned)S * 4u);
+            const SfBufB dltbuf = sf_make_bufb(p.delta + ((long)b * p.nh + h) * S, (unsigned)S * 4u);
+            // lse / delta of the tile's 64 queries ride the same LDS-DMA path (one 4-byte-per-lane piece each, issued by
+            // waves 0 and 1): nothing in this loop is a load the compiler counts
+            auto stage = [&](char* dst, int qt) {
+                stq.issue(qbuf, (unsigned)qt * qtile, dst);
+                stdo.issue(dobuf, (unsigned)qt * dotile, dst + 64 * HD * 2);
+                if (wave == 0) sf_bufb_glds4(lsebuf, (unsigned)(qt * 64 + lane) * 4u, dst + 128 * HD * 2);
+                if (wave == 1 % NW) sf_bufb_glds4(dltbuf, (unsigned)(qt * 64 + lane) * 4u, dst + 128 * HD * 2 + 256);
+            };
+            // the buffer parity continues across the heads of the group: `it` counts tiles globally
+            if (qt_first < nqt) stage(smem + (it & 1) * TILE, qt_first);
+            for (int qt = qt_first; qt < nqt; ++qt, ++it) {
+                const int q0 = qt * 64;
+                sf_wait_vm0();
+                sf_syncthreads();
+                if (qt + 1 < nqt) stage(smem + ((it + 1) & 1) * TILE, qt + 1);
+                const char* lds_q = smem + (it & 1) * TILE;
+                const char* lds_do = lds_q + 64 * HD * 2;
+                const char* lds_x = role == 0 ? lds_do : lds_q;  // dV^T += dO^T.P   |   dK^T += Q^T.dS
+                const float* lds_lse = reinterpret_cast<const float*>(lds_q + 128 * HD * 2);
+                const float* lds_dlt = lds_lse + 64;
+                if (q0 + 63 < kw0) continue;  // every query of the tile is before this wave's keys
+                const int lo = key_lo - q0 - 4 * hi, up = S - q0 - 4 * hi;
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    sf_v16f s, dp;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) s = sf_mfma32(frag_rows<HD>(lds_q, qb * 32, ks, fo), kf[ks], s);
+                    if (role == 1) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) dp = sf_mfma32(frag_rows<HD>(lds_do, qb * 32, ks, fo), vf[ks], dp);
+                    }
+                    // rows crow(4j..4j+3) are consecutive: one 16-byte LDS read per 4 rows
+                    const bool need_mask = (q0 + qb * 32 < kw0 + 32) || (kw0 + 31 >= kvlen) || (q0 + 63 >= S);  // wave-uniform
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ql0 = qb * 32 + 8 * j + 4 * hi;
+                        const sf_v4f l4 = *reinterpret_cast<const sf_v4f*>(lds_lse + ql0);
+                        sf_v4f d4 = l4;
+                        if (role == 1) d4 = *reinterpret_cast<const sf_v4f*>(lds_dlt + ql0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int r = 4 * j + t;
+                            float pv = sf_exp2_raw(fmaf(s[r], sc, -kLog2e * l4[t]));
+                            if (need_mask) {
+                                const int C = qb * 32 + 8 * j + t;
+                                if (C < lo || C >= up) pv = 0.f;
+                            }
+                            s[r] = role == 0 ? pv : pv * (dp[r] - d4[t]);  // P (dV waves) | dS (dK waves)
+                        }
+                    }
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        const sf_v8s f = pack_bf16x8(s, 8 * jp);
+#pragma unroll
+                        for (int d = 0; d < DB; ++d)
+                            acc[d] = sf_mfma32(frag_tr<HD>(lds_x, d, qb * 32 + 16 * jp, fo), f, acc[d]);
+                    }
+                }
+            }
+        }
+    if (!kok || !block_live) return;
+    float* orow = (role == 0 ? p.dv : p.dk) + krow * p.lddk + g * HD;
+    const float oscale = role == 0 ? 1.0f : p.scale;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = d * 32 + 8 * j + 4 * hi;
+            sf_v4f a = *reinterpret_cast<const sf_v4f*>(orow + col);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] += acc[d][4 * j + t] * oscale;
+            *reinterpret_cast<sf_v4f*>(orow + col) = a;
+        }
+}
+
 }  // namespace
 
 extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long lddo,
@@ -309,8 +463,23 @@ extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long l
     p.dk = dk; p.dv = dv; p.lddk = lddk;
     p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.scale = scale;
     p.l2_map = sf_knob("SF_ATTN_DKV_L2MAP", 0);   // heaviest-first over ALL pairs wins here (measured: pair-major +20 %)
+    if (hd == 256) {
+        constexpr int HD = 256, NW = 4;       // 2 key sub-blocks x 2 roles: 64 keys per workgroup
+        dim3 grid(attn_grid((long)((S + NW * 16 - 1) / (NW * 16)) * nkv * B, p.l2_map));
+        SF_ALLOW_SMEM((attn_bwd_dkv_rs_kernel<HD, NW>), 2 * (128 * HD * 2 + 512));
+        SF_LAUNCH((attn_bwd_dkv_rs_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (128 * HD * 2 + 512), stream, p);
+        return sf_check_launch("sf_attn_bwd_dkv");
+    }
+    SF_CHECK_ARG(hd == 64 || hd == 128, "head_dim must be 64, 128 or 256");
     dim3 grid(attn_grid((long)((S + 127) / 128) * nkv * B, p.l2_map));   // 128 keys per workgroup
-    SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD>), 3 * (128 * HD * 2 + 768));
-                   SF_LAUNCH((attn_bwd_dkv_kernel<HD>), grid, dim3(256), 3 * (128 * HD * 2 + 768), stream, p));
+    if (hd == 128) {
+        constexpr int HD = 128;
+        SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD>), 3 * (128 * HD * 2 + 768));
+        SF_LAUNCH((attn_bwd_dkv_kernel<HD>), grid, dim3(256), 3 * (128 * HD * 2 + 768), stream, p);
+    } else {
+        constexpr int HD = 64;
+        SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD>), 3 * (128 * HD * 2 + 768));
+        SF_LAUNCH((attn_bwd_dkv_kernel<HD>), grid, dim3(256), 3 * (128 * HD * 2 + 768), stream, p);
+    }
     return sf_check_launch("sf_attn_bwd_dkv");
 }

@@ -394,7 +394,8 @@ template <int LANES> SF_DEVICE float sf_row_sum(float v) {
     v += sf_dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]
     v += sf_dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]
     v += sf_dpp_f32<0x141>(v);   // row_half_mirror
-    if (LANES == 16) v += sf_dpp_f32<0x140>(v);  // row_mirror
+    if (LANES >= 16) v += sf_dpp_f32<0x140>(v);  // row_mirror
+    if (LANES == 32) v += sf_shfl_xor(v, 16);     // the other 16-lane DPP row of the group (head_dim 256: 32 lanes per token row)
     return v;
 }
 #endif

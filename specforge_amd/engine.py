@@ -45,14 +45,16 @@ class Eagle3Engine:
         if lk_loss_type not in (None, "alpha", "lambda"):
             raise ValueError(f"Unknown lk loss type: {lk_loss_type}")  # core/lk_loss.py:99
         self.lk_loss_type, self.kl_scale, self.kl_decay = lk_loss_type, float(kl_scale), float(kl_decay)
-        # The MFMA attention kernels are instantiated for head_dim 64 and 128.  Other widths (the reference's own test
-        # fixture uses 16: tests/test_runtime/_fixtures.py:15-34) run through the same kernels on zero-padded heads: extra
-        # zero columns change neither q.k nor the softmax, and their outputs / gradients are dropped again.  That path copies
-        # q / k / v / o per step with torch ops -- correct and slow, for small models only; 64 and 128 never take it.
+        # The MFMA attention kernels are instantiated for head_dim 64, 128 and 256 (256: gemma3-1b, qwen3-next-80b-a3b,
+        # qwen3.5-35b-a3b among the reference's configs/*.json; its attention takes any head_dim, llama3_eagle.py:547-550).
+        # Other widths (the reference's own test fixture uses 16: tests/test_runtime/_fixtures.py:15-34) run through the same
+        # kernels on zero-padded heads: extra zero columns change neither q.k nor the softmax, and their outputs / gradients
+        # are dropped again.  That path copies q / k / v / o per step with torch ops -- correct and slow, for small models
+        # only; 64 / 128 / 256 never take it.
         hd = c.head_dim
-        if hd % 16 != 0 or hd > 128:
-            raise NotImplementedError("head_dim must be a multiple of 16 and <= 128 (64 / 128 native, smaller widths zero-padded)")
-        self.hdp = hd if hd in (64, 128) else (64 if hd < 64 else 128)
+        if hd % 16 != 0 or hd > 256:
+            raise NotImplementedError("head_dim must be a multiple of 16 and <= 256 (64 / 128 / 256 native, other widths zero-padded)")
+        self.hdp = hd if hd in (64, 128, 256) else (64 if hd < 64 else 128 if hd < 128 else 256)
         self.T = int(ttt_length)
         if not 1 <= self.T <= ops.MAX_DIAG + 1:
             raise ValueError(f"ttt_length must be in 1..{ops.MAX_DIAG + 1} (one diagonal branch per earlier TTT step)")

@@ -39,7 +39,7 @@ def _oracle(q, ks, vs, do, B, S, nh, nkv, hd, lengths):
     return flat(out.detach()), flat(qf.grad), [flat(k.grad) for k in kf], [flat(v.grad) for v in vf]
 
 
-@pytest.mark.parametrize("hd", [64, 128])
+@pytest.mark.parametrize("hd", [64, 128, 256])
 @pytest.mark.parametrize("B,S,nh,nkv,lengths,nsteps", [
     (2, 48, 4, 2, [48, 23], 1),
     (2, 48, 4, 2, [48, 23], 3),

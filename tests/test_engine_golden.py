@@ -73,7 +73,7 @@ def _oracle_bf16(blob):
 
 @pytest.mark.parametrize("name", ["eagle3_tiny_bf16", "eagle3_tiny_fp32", "eagle31_gqa_fp32", "eagle3_lk_alpha_fp32",
                                   "eagle3_lk_lambda_fp32", "eagle3_nonorm_fp32", "eagle3_rope_yarn_fp32",
-                                  "eagle3_rope_dynamic_fp32", "eagle3_rope_linear_fp32", "eagle3_rope_mrope_fp32"])
+                                  "eagle3_rope_dynamic_fp32", "eagle3_rope_linear_fp32", "eagle3_rope_mrope_fp32", "eagle3_hd256_fp32"])
 def test_micro_step_matches_reference_run(backend, golden_dir, name):
     blob = torch.load(os.path.join(golden_dir, f"{name}.pt"), weights_only=False)
     if "fp32" in name:

@@ -101,10 +101,10 @@ def test_no_compiler_vmcnt_wait_inside_the_tile_loops(src, pattern):
     ks = _kernels(_asm(src), pattern)
     assert ks, "kernel not found in the ISA"
     for name, (body, md) in ks.items():
-        assert md["vgpr_spill_count"] == 0 and md["sgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0, (name, md)
         region = _loop_region(body)
         assert region, (name, "no loop around the barrier")
         ins = list(_compiler_lines(region))
+        assert md["vgpr_spill_count"] == 0 and md["sgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0, (name, md)
         bad = [t for t, inasm in ins if not inasm and t.startswith("s_waitcnt") and "vmcnt" in t]
         assert not bad, (name, bad[:4])
         own = [t for t, inasm in ins if inasm and t.startswith("s_waitcnt") and "vmcnt" in t]

@@ -237,9 +237,20 @@ def test_gemm_bitwise_determinism(form, M, N, K):
 def test_ttt_attention_long(S, lengths, nsteps):
     # S 4096 (cfg 4's recipe: bs 1 x 4096): 128 query blocks per (batch, kv head) -- twice what one XCD holds of the
     # pair-major forward / dQ work order, 64 key tiles per query row
+    _attn_long(S, lengths, nsteps, 128)
+
+
+@pytest.mark.parametrize("nsteps", [1, 7])
+def test_ttt_attention_long_head_dim_256(nsteps):
+    """head_dim 256 (gemma3-1b / qwen3-next-80b-a3b / qwen3.5-35b-a3b recipes): one workgroup per CU for forward / dQ, the
+    role-split dK/dV kernel, 32 lanes per token row in the diagonal-branch kernel"""
+    _attn_long(1024, [1024, 651], nsteps, 256)
+
+
+def _attn_long(S, lengths, nsteps, hd):
     from tests.test_attention import _mk, _oracle
 
-    B, nh, nkv, hd = 2, 4, 2, 128
+    B, nh, nkv = 2, 4, 2
     q, ks, vs, do = _mk(B, S, nh, nkv, hd, nsteps, seed=S + nsteps)
     o_ref, dq_ref, dk_ref, dv_ref = _oracle(q, ks, vs, do, B, S, nh, nkv, hd, lengths)
     d = lambda t: t.to(DEV)

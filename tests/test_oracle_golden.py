@@ -35,7 +35,7 @@ def _run(blob):
 @pytest.mark.parametrize("name,tol", [("eagle3_tiny_fp32", 1e-5), ("eagle31_gqa_fp32", 1e-5), ("eagle3_tiny_bf16", 2e-2),
                                       ("eagle3_lk_alpha_fp32", 1e-5), ("eagle3_lk_lambda_fp32", 1e-5),
                                       ("eagle3_nonorm_fp32", 1e-5), ("eagle3_rope_yarn_fp32", 1e-5),
-                                      ("eagle3_rope_dynamic_fp32", 1e-5), ("eagle3_rope_linear_fp32", 1e-5),
+                                      ("eagle3_rope_dynamic_fp32", 1e-5), ("eagle3_rope_linear_fp32", 1e-5), ("eagle3_hd256_fp32", 1e-5),
                                       ("eagle3_rope_mrope_fp32", 1e-5)])
 def test_oracle_matches_reference_run(golden_dir, name, tol):
     blob = torch.load(os.path.join(golden_dir, f"{name}.pt"), weights_only=False)

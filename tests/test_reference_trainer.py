@@ -32,6 +32,7 @@ def ref(emu_lib_path):
     from specforge_amd import reference_plugin as RP
 
     _lib._inject_library_for_tests(emu_lib_path)
+    RP.draft_class()      # registers the HIP draft architecture (idempotent): the tests of this module may run in any order / worker
     yield RP
     RP.uninstall()
     _lib._inject_library_for_tests(None)
