@@ -29,7 +29,7 @@ extern "C" {
 #define SF_BF16 0
 #define SF_F32 1
 
-#define SF_ABI_VERSION 4
+#define SF_ABI_VERSION 5
 
 int sf_abi_version(void);
 /* 1 if this library is the SIMT-emulator test build, 0 for the gfx950 product build */
@@ -247,9 +247,14 @@ int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long lddo, const v
                    long ldv, const int* kv_len, const float* lse, const float* delta,
                    const float* dq_init, void* dq, long lddq, int B, int S, int nh, int nkv, int hd, float scale,
                    void* stream);
+/* workspace (ABI 5, optional): with few (batch, kv head, key block) workgroups -- B * nkv * ceil(S / 128) < 512, e.g. a bs 1 x 4096 recipe --
+ * the query heads of a kv group are divided over several workgroups whose partial sums go through `workspace`
+ * (sf_attn_bwd_dkv_workspace_floats floats, 16-byte aligned; 0 = this shape needs none) and are added to dk / dv in a fixed order
+ * (deterministic).  NULL / too small: the unsplit kernel, same result up to fp32 summation order. */
+long sf_attn_bwd_dkv_workspace_floats(int B, int S, int nh, int nkv, int hd);
 int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long lddo, const void* k0, long ldk, const void* v0, long ldv, const int* kv_len, const float* lse,
                     const float* delta, float* dk, float* dv, long lddk, int B, int S, int nh, int nkv, int hd,
-                    float scale, void* stream);
+                    float scale, float* workspace, long workspace_floats, void* stream);
 
 /* ---- optimizer: BF16Optimizer.step on flat buffers (specforge/optimizer.py:95-168) ---------
  * norm_out[0] = prescale*sqrt(sum float(g)^2); adamw: clip = min(1, max_norm/(norm+1e-6))

@@ -63,8 +63,9 @@ _SIGS = {
                                 c_int, c_int, c_int, c_int, c_float, P, P, c_long, P]),
     "sf_attn_bwd_dq": (c_int, [P, c_long, P, c_long, P, c_long, P, c_long, P, P, P, P, P, c_long, c_int, c_int,
                                c_int, c_int, c_int, c_float, P]),
+    "sf_attn_bwd_dkv_workspace_floats": (c_long, [c_int, c_int, c_int, c_int, c_int]),
     "sf_attn_bwd_dkv": (c_int, [P, c_long, P, c_long, P, c_long, P, c_long, P, P, P, P, P, c_long, c_int, c_int,
-                                c_int, c_int, c_int, c_float, P]),
+                                c_int, c_int, c_int, c_float, P, c_long, P]),
     "sf_grad_norm_workspace_floats": (c_long, []),
     "sf_grad_norm": (c_int, [P, c_int, c_long, c_float, P, P, P]),
     "sf_adamw_step": (c_int, [P, c_int, P, P, P, P, c_long, P, c_float, c_float, c_float, c_float, c_float, c_float,

@@ -43,6 +43,10 @@ struct AttnBwdArgs {
     int B, S, nh, nkv;
     float scale;
     int l2_map;
+    // dK/dV kernel, head split (small B * nkv): the query heads of a kv group are divided over `hsplit` workgroups, each writing
+    // (=, not +=) its partial gradients to part_k / part_v [hsplit][B*S, nkv*hd] fp32; attn_dkv_reduce_kernel adds them to dk / dv
+    int hsplit;
+    float* part_k; float* part_v; long part_stride;
 };
 
 // ---- LDS tile swizzle -------------------------------------------------------

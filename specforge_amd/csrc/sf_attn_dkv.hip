@@ -150,6 +150,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = sf_wave_id(), c = lane & 31, hi = lane >> 5;
     // 1-D grid, heaviest first: key block 0 sees every query tile, the last one only the final tiles
     const int per_kb = p.nkv * p.B;
+    const int hsplit = p.hsplit > 1 ? p.hsplit : 1;
     int kbi, g, b;
     if (p.l2_map) {   // pair-major (tools A/B only: heaviest-first over ALL pairs measured 20 % faster for this kernel)
         const int nkb = (p.S + KB - 1) / KB;
@@ -158,13 +159,14 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
         const int pr = v / nkb;
         kbi = v - pr * nkb; b = pr / p.nkv; g = pr - b * p.nkv;
     } else {
-        const int bid = (int)blockIdx.x, gb = bid % per_kb;
+        const int bid = (int)blockIdx.x / hsplit, gb = bid % per_kb;
         kbi = bid / per_kb; g = gb % p.nkv; b = gb / p.nkv;
     }
+    const int hs = (int)blockIdx.x % hsplit;     // this workgroup's slice of the group's query heads (heaviest key block still first)
     const int kb0 = kbi * KB;
-    const int S = p.S, nrep = p.nh / p.nkv;
+    const int S = p.S, nrep = (p.nh / p.nkv) / hsplit, hh0 = hs * nrep;
     const int kvlen = p.kv_len ? p.kv_len[b] : S;
-    if (kb0 >= kvlen) return;   // keys at / after kv_len never receive probability mass (workgroup-uniform)
+    if (kb0 >= kvlen) return;   // keys at / after kv_len never receive probability mass (workgroup-uniform; the reduce skips them too)
     const int kw0 = kb0 + wave * 32;
     const int ki = kw0 + c;  // this lane's key (column of S)
     const bool kok = ki < S;
@@ -198,10 +200,11 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
     stq.init(p.ldq, wave, lane);
     stdo.init(p.lddo, wave, lane);
     const unsigned qtile = (unsigned)(64 * p.ldq * 2), dotile = (unsigned)(64 * p.lddo * 2);
-    const sf_bf16* qb_base = p.q + (long)b * S * p.ldq + (long)g * nrep * HD;
-    const sf_bf16* dob_base = p.dout + (long)b * S * p.lddo + (long)g * nrep * HD;
-    const float* lse_base = p.lse + ((long)b * p.nh + (long)g * nrep) * S;
-    const float* dlt_base = p.delta + ((long)b * p.nh + (long)g * nrep) * S;
+    const int h0 = g * (p.nh / p.nkv) + hh0;     // first query head of this workgroup
+    const sf_bf16* qb_base = p.q + (long)b * S * p.ldq + (long)h0 * HD;
+    const sf_bf16* dob_base = p.dout + (long)b * S * p.lddo + (long)h0 * HD;
+    const float* lse_base = p.lse + ((long)b * p.nh + h0) * S;
+    const float* dlt_base = p.delta + ((long)b * p.nh + h0) * S;
     // Every wave issues the same number of DMA pieces per tile (a counted vmcnt needs one immediate): its Q and dO pieces
     // plus ONE 4-byte-per-lane piece -- lse (wave 0), delta (wave 1), or a re-read of lse into the slot's padding.
     struct Src { SfBufB q, dout, aux; unsigned qoff, dooff, auxoff; char* dst; };
@@ -270,22 +273,49 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
     sf_wait_vm0();   // (the stand-in pieces of the last iterations are still in flight: LDS must not be released under them)
     bank.drain();
     if (!kok) return;
-    float* dkrow = p.dk + krow * p.lddk + g * HD;
-    float* dvrow = p.dv + krow * p.lddk + g * HD;
+    const bool split = p.hsplit > 1;               // partial sums of this head slice: written, not accumulated
+    const long orow = split ? (long)hs * p.part_stride + krow * ((long)p.nkv * HD) : krow * p.lddk;
+    float* dkrow = (split ? p.part_k : p.dk) + orow + g * HD;
+    float* dvrow = (split ? p.part_v : p.dv) + orow + g * HD;
     static_for<0, DB>([&](auto D) SF_LAMBDA_INLINE {
         constexpr int d = decltype(D)::value;
         const sf_v16f ak = bank.template get_dk<d>(), av = bank.template get_dv<d>();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = d * 32 + 8 * j + 4 * hi;
-            sf_v4f a = *reinterpret_cast<const sf_v4f*>(dkrow + col);
-            sf_v4f e = *reinterpret_cast<const sf_v4f*>(dvrow + col);
+            sf_v4f a = sf_v4f{0.f, 0.f, 0.f, 0.f}, e = a;
+            if (!split) {
+                a = *reinterpret_cast<const sf_v4f*>(dkrow + col);
+                e = *reinterpret_cast<const sf_v4f*>(dvrow + col);
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) { a[t] += ak[4 * j + t] * p.scale; e[t] += av[4 * j + t]; }
             *reinterpret_cast<sf_v4f*>(dkrow + col) = a;
             *reinterpret_cast<sf_v4f*>(dvrow + col) = e;
         }
     });
+}
+
+// dk / dv += sum over the head slices' partials (fixed order: deterministic).  Key blocks at / after kv_len were never written.
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_dkv_reduce_kernel(AttnBwdArgs p, int W, int KB) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;       // one float4 of the [B*S, W] gradients
+    const long n4 = (long)p.B * p.S * (W / 4);
+    if (i4 >= n4) return;
+    const long row = i4 / (W / 4);
+    const int col = (int)(i4 - row * (W / 4)) * 4;
+    const int b = (int)(row / p.S), t = (int)(row - (long)b * p.S);
+    const int kvlen = p.kv_len ? p.kv_len[b] : p.S;
+    if ((t / KB) * KB >= kvlen) return;
+    sf_v4f a = *reinterpret_cast<const sf_v4f*>(p.dk + row * p.lddk + col);
+    sf_v4f e = *reinterpret_cast<const sf_v4f*>(p.dv + row * p.lddk + col);
+    for (int hs = 0; hs < p.hsplit; ++hs) {
+        const sf_v4f x = *reinterpret_cast<const sf_v4f*>(p.part_k + hs * p.part_stride + row * W + col);
+        const sf_v4f y = *reinterpret_cast<const sf_v4f*>(p.part_v + hs * p.part_stride + row * W + col);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] += x[k]; e[k] += y[k]; }
+    }
+    *reinterpret_cast<sf_v4f*>(p.dk + row * p.lddk + col) = a;
+    *reinterpret_cast<sf_v4f*>(p.dv + row * p.lddk + col) = e;
 }
 
 // ------------------------------------------------ head_dim 256: the role-split kernel
@@ -444,10 +474,29 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, NW / 4) attn_bwd_dkv_rs_kernel(AttnBwdA
 
 }  // namespace
 
+// Head split of the dK/dV kernel: its parallelism is (batch, kv head, 128-key block) and the longest workgroup (key block 0) walks
+// every query tile of every query head of its group -- with B * nkv * S / 128 < 2 x 256 the launch is as long as that one
+// workgroup (measured at cfg 4's recipe, bs 1 x 4096, 32 / 4 heads: 0.15 of the MFMA peak where bs 4 reaches 0.43).  The heads
+// of a group are then divided over `hsplit` workgroups (the smallest divisor of nh / nkv that brings the grid to 512).
+static int dkv_head_split(int B, int S, int nh, int nkv, int hd) {
+    if (hd == 256) return 1;
+    const long wgs = (long)((S + 127) / 128) * nkv * B;
+    const int nrep = nh / nkv;
+    if (wgs >= 512) return 1;
+    for (int d = 2; d < nrep; ++d)
+        if (nrep % d == 0 && wgs * d >= 512) return d;
+    return nrep;
+}
+extern "C" long sf_attn_bwd_dkv_workspace_floats(int B, int S, int nh, int nkv, int hd) {
+    if (B <= 0 || S <= 0 || nh <= 0 || nkv <= 0 || nh % nkv) return 0;
+    const int hs = dkv_head_split(B, S, nh, nkv, hd);
+    return hs > 1 ? 2L * hs * B * S * nkv * hd : 0;
+}
+
 extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long lddo,
                                const void* k0, long ldk, const void* v0, long ldv, const int* kv_len, const float* lse,
                                const float* delta, float* dk, float* dv, long lddk, int B, int S, int nh, int nkv,
-                               int hd, float scale, void* stream) {
+                               int hd, float scale, float* workspace, long workspace_floats, void* stream) {
     SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_dkv: bad shape");
     SF_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddk % 4 == 0,
                  "sf_attn_bwd_dkv: row strides must be multiples of 8 (16-byte segments)");
@@ -471,7 +520,13 @@ extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long l
         return sf_check_launch("sf_attn_bwd_dkv");
     }
     SF_CHECK_ARG(hd == 64 || hd == 128, "head_dim must be 64, 128 or 256");
-    dim3 grid(attn_grid((long)((S + 127) / 128) * nkv * B, p.l2_map));   // 128 keys per workgroup
+    int hsplit = dkv_head_split(B, S, nh, nkv, hd);
+    if (!workspace || workspace_floats < 2L * hsplit * B * S * nkv * hd || ((size_t)workspace & 15) || p.l2_map) hsplit = 1;
+    p.hsplit = hsplit;
+    p.part_stride = (long)B * S * nkv * hd;
+    p.part_k = workspace;
+    p.part_v = workspace ? workspace + hsplit * p.part_stride : nullptr;
+    dim3 grid(attn_grid((long)((S + 127) / 128) * nkv * B * hsplit, p.l2_map));   // 128 keys per workgroup
     if (hd == 128) {
         constexpr int HD = 128;
         SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD>), 3 * (128 * HD * 2 + 768));
@@ -480,6 +535,11 @@ extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long l
         constexpr int HD = 64;
         SF_ALLOW_SMEM((attn_bwd_dkv_kernel<HD>), 3 * (128 * HD * 2 + 768));
         SF_LAUNCH((attn_bwd_dkv_kernel<HD>), grid, dim3(256), 3 * (128 * HD * 2 + 768), stream, p);
+    }
+    if (hsplit > 1) {
+        const int W = nkv * hd;
+        const long n4 = (long)B * S * (W / 4);
+        SF_LAUNCH(attn_dkv_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, p, W, 128);
     }
     return sf_check_launch("sf_attn_bwd_dkv");
 }

@@ -274,6 +274,8 @@ class Eagle3Engine:
         # fp32 partials for the 2-way split-K of weight-gradient GEMMs whose tile count fills the CUs badly (down, q|k|v)
         # (+ 4096 floats at the tail: pace-keeping counters of sf_gemm_tn)
         b["tn_ws"] = cv("tn_ws", 2 * max(H * I, self.QW * H) + 4096, dtype=f32)
+        nws = ops.attn_bwd_dkv_workspace_floats(B, S, nh, nkv, hdp)     # head-split partials (small B * nkv only; else 0)
+        b["dkv_ws"] = cv("dkv_ws", nws, dtype=f32) if nws else None
         return b
 
     def _target_p(self, b, B: int, S: int) -> torch.Tensor:
@@ -673,7 +675,7 @@ class Eagle3Engine:
             ops.attn_bwd_dq(q, do, k0, v0, b["kvlen"], b["lse"][k], b["delta"], b["dq_init"] if k > 0 else None, dq_out,
                             B=B, S=S, nh=nh, nkv=nkv, hd=self.hdp, scale=scale)
             ops.attn_bwd_dkv(q, do, k0, v0, b["kvlen"], b["lse"][k], b["delta"], b["dk"][0], b["dv"][0], B=B, S=S, nh=nh,
-                             nkv=nkv, hd=self.hdp, scale=scale)
+                             nkv=nkv, hd=self.hdp, scale=scale, workspace=b["dkv_ws"])
             if self.hdp == hd:
                 if k == 0:      # block 0's keys: the dK/dV kernel of this step added the last term
                     ops.cast_from_f32(b["dk"][0], dqkv[:, kcol])

@@ -408,12 +408,19 @@ def attn_bwd_dq(q, dout, k0, v0, kv_len, lse, delta, dq_init, dq, *, B, S, nh, n
                                 _rowmajor(dq), B, S, nh, nkv, hd, scale, _stream()), "sf_attn_bwd_dq")
 
 
-def attn_bwd_dkv(q, dout, k0, v0, kv_len, lse, delta, dk, dv, *, B, S, nh, nkv, hd, scale):
+def attn_bwd_dkv_workspace_floats(B, S, nh, nkv, hd) -> int:
+    """fp32 workspace the head-split form of attn_bwd_dkv wants for this shape (0: it runs unsplit)"""
+    return int(_lib.lib().sf_attn_bwd_dkv_workspace_floats(B, S, nh, nkv, hd))
+
+
+def attn_bwd_dkv(q, dout, k0, v0, kv_len, lse, delta, dk, dv, *, B, S, nh, nkv, hd, scale, workspace=None):
     L = _lib.lib()
     assert dk.dtype == torch.float32 and dv.dtype == torch.float32 and _rowmajor(dk) == _rowmajor(dv)
+    assert workspace is None or (workspace.dtype == torch.float32 and workspace.is_contiguous())
     _lib.check(L.sf_attn_bwd_dkv(_p(q), _rowmajor(q), _p(dout), _rowmajor(dout), _p(k0), _rowmajor(k0),
                                  _p(v0), _rowmajor(v0), _p(kv_len), _p(lse), _p(delta), _p(dk), _p(dv), _rowmajor(dk),
-                                 B, S, nh, nkv, hd, scale, _stream()), "sf_attn_bwd_dkv")
+                                 B, S, nh, nkv, hd, scale, _p(workspace), workspace.numel() if workspace is not None else 0,
+                                 _stream()), "sf_attn_bwd_dkv")
 
 
 def grad_norm(g: torch.Tensor, norm_out: torch.Tensor, workspace: torch.Tensor, prescale: float = 1.0):

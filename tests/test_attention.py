@@ -121,3 +121,39 @@ def test_ttt_attention_fwd_bwd(backend, hd, B, S, nh, nkv, lengths, nsteps):
     ops.attn_bwd_dkv(qv, dout, kview[0], vview[0], kv_len, lse, delta, dk_acc[0], dv_acc[0], B=B, S=S, nh=nh,
                      nkv=nkv, hd=hd, scale=scale)
     torch.testing.assert_close(dk_acc[0].cpu(), 2 * before.cpu(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("hd", [64, 128])
+def test_dkv_head_split_equals_unsplit(backend, hd):
+    """B * nkv * ceil(S / 128) < 512 (a bs 1 recipe): the dK/dV kernel divides the query heads of a kv group over several
+    workgroups whose partial sums go through a workspace (sf_attn_bwd_dkv, ABI 5) -- same gradients as the unsplit launch
+    (fp32 summation order aside), run-to-run bit-identical, rows at / after kv_len untouched, accumulation (+=) kept."""
+    B, S, nh, nkv, nsteps = 2, 150, 8, 2, 1
+    lengths = [150, 97]
+    q, ks, vs, do = _mk(B, S, nh, nkv, hd, nsteps, seed=hd)
+    _, _, dk_ref, dv_ref = _oracle(q, ks, vs, do, B, S, nh, nkv, hd, lengths)
+    d = lambda t: t.to(backend)
+    N, scale = B * S, 1.0 / math.sqrt(hd)
+    qv, k0, v0, dout = d(q.view(N, -1)), d(ks[0].view(N, -1)), d(vs[0].view(N, -1)), d(do.view(N, -1))
+    kv_len = d(torch.tensor(lengths, dtype=torch.int32))
+    o = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=backend)
+    lse = torch.empty(B, nh, S, device=backend)
+    ops.attn_fwd(qv, k0, v0, [], [], kv_len, o, lse, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+    delta = torch.empty(B, nh, S, device=backend)
+    ops.attn_bwd_pre(qv, o, dout, [], [], [], [], lse, delta, None, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+    nws = ops.attn_bwd_dkv_workspace_floats(B, S, nh, nkv, hd)
+    assert nws == 2 * 4 * N * nkv * hd                 # 2 key blocks x 2 kv heads x 2 samples = 8 workgroups: all 4 heads of a group split
+    assert ops.attn_bwd_dkv_workspace_floats(8, 2048, 32, 8, hd) == 0    # the headline shape fills the chip unsplit
+    runs = []
+    for ws in (None, torch.full((nws,), float("nan"), device=backend), torch.full((nws,), 7.0, device=backend)):
+        dk = torch.full((N, nkv * hd), 0.5, device=backend)      # += semantics: the seed must survive
+        dv = torch.full((N, nkv * hd), -0.25, device=backend)
+        ops.attn_bwd_dkv(qv, dout, k0, v0, kv_len, lse, delta, dk, dv, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale, workspace=ws)
+        runs.append((dk.cpu(), dv.cpu()))
+    (dk0, dv0), (dk1, dv1), (dk2, dv2) = runs
+    assert torch.equal(dk1, dk2) and torch.equal(dv1, dv2)       # whatever the workspace held; run-to-run identical
+    torch.testing.assert_close(dk1, dk0, rtol=1e-5, atol=1e-5 * float(dk0.abs().max()))
+    torch.testing.assert_close(dv1, dv0, rtol=1e-5, atol=1e-5 * float(dv0.abs().max()))
+    tol = lambda r: 2e-2 * float(r.abs().max())
+    assert float((dk1 - 0.5 - dk_ref[0]).abs().max()) <= tol(dk_ref[0]) and float((dv1 + 0.25 - dv_ref[0]).abs().max()) <= tol(dv_ref[0])
+    assert float((dk1.view(B, S, -1)[1, 97:] - 0.5).abs().max()) == 0.0     # padded keys of sample 1: nothing added
