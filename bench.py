@@ -80,6 +80,27 @@ class KernelTimer:
     def _attn_units(kw):
         return kw["B"] * kw["nh"] * kw["hd"] * kw["S"] * kw["S"] / 2.0
 
+    @staticmethod
+    def _diag_bytes(k):
+        N, qw, kw = k["B"] * k["S"], k["nh"] * k["hd"], k["nkv"] * k["hd"]
+        own = k.get("q") is not None
+        by = (3 * N * qw * 2 if own else 0) + len(k.get("kd", ())) * 2 * N * kw * 2 + len(k.get("xq", ())) * 2 * N * qw * 2
+        if own and k.get("dq_init") is not None:
+            by += N * qw * 4 * (2 if k.get("dq_accumulate") else 1)
+        for j, first in enumerate(k.get("first", ())):
+            by += (0 if first else 2 * N * kw * 4) + (2 * N * kw * 2 if k["dk_out"][j] is not None else 2 * N * kw * 4)
+        return float(by)
+
+    @staticmethod
+    def _pre_bytes(a, k):     # the per-step form (A/B): every branch sum read + written in fp32, the last one written as bf16
+        N, qw, kw = k["B"] * k["S"], k["nh"] * k["hd"], k["nkv"] * k["hd"]
+        nd = len(a[3])
+        launches = max(1, (nd + 3) // 4)
+        by = launches * 3 * N * qw * 2 + nd * 2 * N * kw * 2 + nd * 2 * N * kw * 8
+        if nd:
+            by += N * qw * 4 * (2 * launches - 1)
+        return float(by)
+
     def wrap(self, ops):
         el = lambda t: t.numel() * t.element_size()
         fam = {
@@ -103,6 +124,10 @@ class KernelTimer:
             "ce_fused_zt": ("ce_fused_zt", lambda a, k: float(a[0].numel())),
             #   AdamW: grad bf16 r, master / m / v fp32 r+w, param bf16 w = 28 B per parameter
             "adamw_step": ("adamw_step", lambda a, k: 28.0 * a[0].numel()),
+            #   diagonal-branch backward: q / o / dO of the own step, k / v of the branches read, dq_init, the streamed steps' q / dO,
+            #   and the branch sums (fp32 read unless first touch; bf16 write when final, else fp32)
+            "attn_bwd_diag": ("attn_bwd_diag", lambda a, k: self._diag_bytes(k)),
+            "attn_bwd_pre": ("attn_bwd_pre", lambda a, k: self._pre_bytes(a, k)),
             #   teacher reduce: one bf16 read of the logits chunk + target_p fp32 write
             "teacher_reduce": ("teacher_reduce", lambda a, k: el(a[0]) + 4.0 * a[0].shape[0] * k["Vd"]),
             #   ... on the permuted head: the stored (draft) logits + 16 B per reduced 128-column block + the probabilities
@@ -202,6 +227,8 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="run the gradient collectives even at world size 1 (RCCL path on a 1-GPU box)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (launcher smoke test)")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: all ranks on cuda:0 (with --dist-backend gloo)")
+    ap.add_argument("--diag-per-step", action="store_true",
+                    help="A/B: the diagonal-branch backward as one sf_attn_bwd_pre per TTT step (round 3) instead of the blocked sf_attn_bwd_diag")
     ap.add_argument("--materialise-targets", action="store_true",
                     help="A/B: write the fp32 soft targets [B, S+T, Vd] instead of re-forming them in the fused CE from the teacher's draft logits")
     args = ap.parse_args()
@@ -259,6 +286,7 @@ def main():
                                    single_collective=args.dp_single, force_collectives=args.force_dp)
     backend.prepare_model(eagle)
     eagle.engine.materialise_soft_targets = args.materialise_targets
+    eagle.engine.blocked_diag = not args.diag_per_step
     batches = [TrainBatch(make_batch(cfg, B, S, dev, 100 + rank * 10 + i), {"target_repr": "hidden_state"}) for i in range(2)]
 
     # ---- where a step's batch comes from (--feed).  hbm: resident (the metric).  The others are what a
@@ -448,6 +476,9 @@ def main():
             "attn_fwd": kern("attn_fwd", "TFLOP/s", PEAK_BF16_TFLOPS, what="4 B nh hd S^2/2 (diagonal branches not counted)"),
             "attn_bwd_dq": kern("attn_bwd_dq", "TFLOP/s", PEAK_BF16_TFLOPS, what="6 B nh hd S^2/2"),
             "attn_bwd_dkv": kern("attn_bwd_dkv", "TFLOP/s", PEAK_BF16_TFLOPS, what="8 B nh hd S^2/2 (each product once)"),
+            "attn_bwd_diag": kern("attn_bwd_diag", "GB/s", PEAK_HBM_GBS,
+                                  what="diagonal-branch backward, blocked: q / o / dO + branch k / v + dq_init + streamed later steps + branch sums (first touch / bf16 final)"),
+            "attn_bwd_pre": kern("attn_bwd_pre", "GB/s", PEAK_HBM_GBS, what="diagonal-branch backward, one pair per step (A/B form, --diag-per-step)"),
             "ce_fused": kern("ce_fused", "GB/s", PEAK_HBM_GBS, scale=4.0 + 4.0 * density,
                              what=f"per logit: 2 B read + 2 B gradient written in place + 4 B soft target on the {density:.2f} of rows with a position mask"),
             "ce_fused_zt": kern("ce_fused_zt", "GB/s", PEAK_HBM_GBS, scale=4.0 + 2.0 * density,

@@ -243,6 +243,22 @@ int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo, const void
                     const void* const* kd, const void* const* vd, float* const* dkd, float* const* dvd, long ldk,
                     long lddk, int ndiag, const float* lse, float* delta, float* dq_init, int B, int S, int nh,
                     int nkv, int hd, float scale, void* dk_last, void* dv_last, long ld_last, void* stream);
+/* The diagonal-branch backward, blocked (ABI 5; sf_attn_bwd_pre remains the one-pair-per-step form).  One launch serves sweep step s:
+ *   own step (q non-null): delta = rowsum(dO * O); dq_init (=, or += with dq_accumulate) = sum over the `nread` <= 6 branches kd / vd
+ *     of ds_i k_i, with p_i = exp(q.k_i scale - lse), ds_i = p_i (dO.v_i - delta) scale;
+ *   the FIRST `nacc` <= 4 of those branches accumulate dK_i += ds_i q, dV_i += p_i dO (summed over the query heads of the kv group)
+ *     over the own step AND over `nx` <= 8 later TTT steps given as (xq, xdo, xlse, xdelta) -- same strides as q / dout, lse / delta
+ *     [B, nh, S] as written at those steps -- whose p / ds are recomputed;
+ *   per accumulating branch j: first[j] != 0 -> the fp32 sums dkd[j] / dvd[j] are NOT read (first touch, no zero fill needed);
+ *     dk_out[j] / dv_out[j] non-null -> the finished sums leave as bf16 [B*S, nkv*hd] (row stride ld_out) instead of going back to
+ *     dkd[j] / dvd[j] (which may then be null when first[j] is set too).
+ * A pair (step k, branch i) may run at any sweep step in [i, k]; specforge_amd/engine.py:diag_plan blocks them so that only the
+ * pairs inside a block of 4 branches remain read-modify-write. */
+int sf_attn_bwd_diag(const void* q, long ldq, const void* o, long ldo, const void* dout, long lddo, const float* lse, float* delta,
+                     float* dq_init, int dq_accumulate, const void* const* kd, const void* const* vd, long ldk, int nread,
+                     float* const* dkd, float* const* dvd, long lddk, int nacc, const int* first, void* const* dk_out,
+                     void* const* dv_out, long ld_out, const void* const* xq, const void* const* xdo, const float* const* xlse,
+                     const float* const* xdelta, int nx, int B, int S, int nh, int nkv, int hd, float scale, void* stream);
 int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long lddo, const void* k0, long ldk, const void* v0,
                    long ldv, const int* kv_len, const float* lse, const float* delta,
                    const float* dq_init, void* dq, long lddq, int B, int S, int nh, int nkv, int hd, float scale,

@@ -61,6 +61,8 @@ _SIGS = {
                             c_float, P]),
     "sf_attn_bwd_pre": (c_int, [P, c_long, P, c_long, P, c_long, P, P, P, P, c_long, c_long, c_int, P, P, P, c_int,
                                 c_int, c_int, c_int, c_int, c_float, P, P, c_long, P]),
+    "sf_attn_bwd_diag": (c_int, [P, c_long, P, c_long, P, c_long, P, P, P, c_int, P, P, c_long, c_int, P, P, c_long, c_int, P, P, P, c_long,
+                                 P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P]),
     "sf_attn_bwd_dq": (c_int, [P, c_long, P, c_long, P, c_long, P, c_long, P, P, P, P, P, c_long, c_int, c_int,
                                c_int, c_int, c_int, c_float, P]),
     "sf_attn_bwd_dkv_workspace_floats": (c_long, [c_int, c_int, c_int, c_int, c_int]),

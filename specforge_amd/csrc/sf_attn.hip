@@ -413,6 +413,188 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_pre_kernel(AttnBwdPreArgs p) {
     }
 }
 
+// ------------------------------------------- backward: diagonal branches, blocked (round 4)
+// The pair (step k, branch i <= k) of the TTT diagonal terms contributes  dq_k += ds k_i,  dK_i += ds q_k,  dV_i += p dO_k  with
+// p = exp(q_k.k_i scale - lse_k), ds = p (dO_k.v_i - delta_k) scale -- all per token.  dq_k is needed at sweep step k and dK_i / dV_i
+// at sweep step i (the QKV input gradient of step i feeds step i - 1), so a pair may run at any sweep step in [i, k].  attn_bwd_pre
+// runs every pair at step k: the fp32 sums of branch i are read and written back once per later step (21 times at ttt 7: 16 KB
+// per token and pair, 5.5 GB of the kernel's 12.6 GB per micro-step), plus their zero fill, plus a second launch re-reading q / o /
+// dO whenever a step has more than 4 branches.  Here a launch serves sweep step s with
+//   * the step's own q / o / dO: delta, and dq_init from ALL nread <= 6 branches read (their k_i / v_i: 4 KB per branch and token);
+//   * the first nacc <= 4 of those branches accumulating dK / dV in registers, over the own step AND over nx <= 8 LATER steps
+//     whose q / dO / lse / delta are streamed again (16 KB per step and token, p and ds recomputed) -- so a block of 4 branches takes
+//     all the steps above it in ONE pass, first touch (no read, no zero fill), and only the pairs inside a block remain
+//     read-modify-write.  A branch whose last contributor is this launch leaves as bf16 (one rounding), into the dqkv slot.
+// engine.py (diag_plan) builds the launches; bytes of the diagonal terms per token at ttt 7: 828 KB -> 516 KB.
+constexpr int kDiagRead = 6, kDiagAcc = 4, kDiagX = 8;
+struct AttnBwdDiagArgs {
+    const sf_bf16* q; long ldq;        // own step (null: this launch only streams later steps into the accumulating branches)
+    const sf_bf16* o; long ldo;
+    const sf_bf16* dout; long lddo;
+    const float* lse; float* delta; float* dq_init; int dq_accumulate;
+    const sf_bf16* kd[kDiagRead]; const sf_bf16* vd[kDiagRead]; long ldk; int nread;
+    float* dkd[kDiagAcc]; float* dvd[kDiagAcc]; long lddk; int nacc;
+    int first[kDiagAcc];               // 1: nothing to add to (first touch): the fp32 sums are not read
+    sf_bf16* dk_out[kDiagAcc]; sf_bf16* dv_out[kDiagAcc]; long ld_out;   // non-null: final -> bf16 here instead of fp32 back to dkd / dvd
+    const sf_bf16* xq[kDiagX]; const sf_bf16* xdo[kDiagX]; const float* xlse[kDiagX]; const float* xdelta[kDiagX]; int nx;
+    int B, S, nh, nkv;
+    float scale;
+};
+
+template <int HD>
+SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_diag_kernel(AttnBwdDiagArgs p) {
+    constexpr int LPH = HD / 8;     // lanes per row
+    constexpr int RPW = 64 / LPH;   // rows per wave
+    constexpr int NR = kDiagRead, NA = kDiagAcc;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int sub = lane / LPH, li = lane % LPH;
+    const int N = p.B * p.S;
+    const int row_raw = (int)blockIdx.x * RPW + sub;
+    const bool live = row_raw < N;
+    const int row = live ? row_raw : N - 1;   // dead lane groups shadow a valid row and skip every store
+    const int b = row / p.S, t = row - b * p.S;
+    const int nrep = p.nh / p.nkv;
+    const int d0 = li * 8;
+    for (int g = wave; g < p.nkv; g += 4) {
+        sf_v8s kv[NR], vv[NR];
+        float dk[NA][8], dv[NA][8];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (i < p.nread) {
+                kv[i] = *reinterpret_cast<const sf_v8s*>(p.kd[i] + (long)row * p.ldk + g * HD + d0);
+                vv[i] = *reinterpret_cast<const sf_v8s*>(p.vd[i] + (long)row * p.ldk + g * HD + d0);
+            } else {
+                kv[i] = sf_v8s{0, 0, 0, 0, 0, 0, 0, 0};
+                vv[i] = kv[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dk[i][e] = 0.f; dv[i][e] = 0.f; }
+        // ---- the launch's own step: delta, dq_init over every branch read, dK / dV of the accumulating ones
+        if (p.q) {
+            for (int hh = 0; hh < nrep; ++hh) {
+                const int h = g * nrep + hh;
+                const int col = h * HD + d0;
+                float qv[8], ov[8], dov[8];
+                SfVec8<sf_bf16>::ld(p.q + (long)row * p.ldq + col, qv);
+                SfVec8<sf_bf16>::ld(p.o + (long)row * p.ldo + col, ov);
+                SfVec8<sf_bf16>::ld(p.dout + (long)row * p.lddo + col, dov);
+                float dl = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl += ov[e] * dov[e];
+                dl = sf_row_sum<LPH>(dl);
+                const long lidx = ((long)b * p.nh + h) * p.S + t;
+                if (li == 0 && live) p.delta[lidx] = dl;
+                if (p.nread > 0) {
+                    const float lse = p.lse[lidx];
+                    float dq[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dq[e] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+                        if (i < p.nread) {
+                            float sdot = 0.f, pdot = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                sdot += qv[e] * sf_bf2f((sf_bf16)kv[i][e]);
+                                pdot += dov[e] * sf_bf2f((sf_bf16)vv[i][e]);
+                            }
+                            sdot = sf_row_sum<LPH>(sdot);
+                            pdot = sf_row_sum<LPH>(pdot);
+                            const float pi = sf_exp(sdot * p.scale - lse);
+                            const float ds = pi * (pdot - dl) * p.scale;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) dq[e] += ds * sf_bf2f((sf_bf16)kv[i][e]);
+                            if (i < NA) {      // (compile-time: register slots; i < p.nacc at run time)
+                                if (i < p.nacc) {
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) {
+                                        dk[i < NA ? i : 0][e] += ds * qv[e];
+                                        dv[i < NA ? i : 0][e] += pi * dov[e];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (live && p.dq_init) {
+                        float* dqp = p.dq_init + (long)row * (p.nh * HD) + col;
+                        if (p.dq_accumulate) {   // a later chunk of this step's branches: add to what the first chunk wrote
+                            float prev[8];
+                            SfVec8<float>::ld(dqp, prev);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) dq[e] += prev[e];
+                        }
+                        SfVec8<float>::st(dqp, dq);
+                    }
+                }
+            }
+        }
+        // ---- later TTT steps streamed into the accumulating branches (their dq / delta were finished at their own sweep step)
+        for (int x = 0; x < p.nx; ++x) {
+            const sf_bf16* xq = p.xq[x];
+            const sf_bf16* xdo = p.xdo[x];
+            const float* xl = p.xlse[x];
+            const float* xd = p.xdelta[x];
+            for (int hh = 0; hh < nrep; ++hh) {
+                const int h = g * nrep + hh;
+                const int col = h * HD + d0;
+                float qv[8], dov[8];
+                SfVec8<sf_bf16>::ld(xq + (long)row * p.ldq + col, qv);
+                SfVec8<sf_bf16>::ld(xdo + (long)row * p.lddo + col, dov);
+                const long lidx = ((long)b * p.nh + h) * p.S + t;
+                const float lse = xl[lidx], dl = xd[lidx];
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    if (i < p.nacc) {
+                        float sdot = 0.f, pdot = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            sdot += qv[e] * sf_bf2f((sf_bf16)kv[i][e]);
+                            pdot += dov[e] * sf_bf2f((sf_bf16)vv[i][e]);
+                        }
+                        sdot = sf_row_sum<LPH>(sdot);
+                        pdot = sf_row_sum<LPH>(pdot);
+                        const float pi = sf_exp(sdot * p.scale - lse);
+                        const float ds = pi * (pdot - dl) * p.scale;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            dk[i][e] += ds * qv[e];
+                            dv[i][e] += pi * dov[e];
+                        }
+                    }
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                if (i < p.nacc) {
+                    const long idx = (long)row * p.lddk + g * HD + d0;
+                    float a[8], c[8];
+                    if (p.first[i]) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { a[e] = dk[i][e]; c[e] = dv[i][e]; }
+                    } else {
+                        SfVec8<float>::ld(p.dkd[i] + idx, a);
+                        SfVec8<float>::ld(p.dvd[i] + idx, c);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { a[e] += dk[i][e]; c[e] += dv[i][e]; }
+                    }
+                    if (p.dk_out[i]) {   // every TTT step that reads this branch has contributed: round once, write the gradient
+                        const long oi = (long)row * p.ld_out + g * HD + d0;
+                        SfVec8<sf_bf16>::st(p.dk_out[i] + oi, a);
+                        SfVec8<sf_bf16>::st(p.dv_out[i] + oi, c);
+                    } else {
+                        SfVec8<float>::st(p.dkd[i] + idx, a);
+                        SfVec8<float>::st(p.dvd[i] + idx, c);
+                    }
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------- backward: dQ
 
 template <int HD, int NW>
@@ -626,6 +808,52 @@ extern "C" int sf_attn_bwd_pre(const void* q, long ldq, const void* o, long ldo,
         SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_pre_kernel<HD, chunk>), grid, dim3(256), 0, stream, p));
     }
     return sf_check_launch("sf_attn_bwd_pre");
+}
+
+extern "C" int sf_attn_bwd_diag(const void* q, long ldq, const void* o, long ldo, const void* dout, long lddo, const float* lse,
+                                float* delta, float* dq_init, int dq_accumulate, const void* const* kd, const void* const* vd,
+                                long ldk, int nread, float* const* dkd, float* const* dvd, long lddk, int nacc,
+                                const int* first, void* const* dk_out, void* const* dv_out, long ld_out, const void* const* xq,
+                                const void* const* xdo, const float* const* xlse, const float* const* xdelta, int nx, int B, int S,
+                                int nh, int nkv, int hd, float scale, void* stream) {
+    SF_CHECK_ARG(B > 0 && S > 0 && nh > 0 && nkv > 0 && nh % nkv == 0, "sf_attn_bwd_diag: bad shape");
+    SF_CHECK_ARG(nread >= 0 && nread <= kDiagRead && nacc >= 0 && nacc <= kDiagAcc && nacc <= nread && nx >= 0 && nx <= kDiagX,
+                 "sf_attn_bwd_diag: at most 6 branches read, the first <= 4 of them accumulating, <= 8 later steps streamed");
+    SF_CHECK_ARG(hd == 64 || hd == 128 || hd == 256, "head_dim must be 64, 128 or 256");
+    SF_CHECK_ARG(q || (nx > 0 && nacc > 0), "sf_attn_bwd_diag: nothing to do (no own step and nothing streamed)");
+    SF_CHECK_ARG(!q || (o && dout && delta && (nread == 0 || (lse && dq_init))), "sf_attn_bwd_diag: own step needs o, dout, delta (and lse, dq_init with branches)");
+    SF_CHECK_ARG(nx == 0 || (xq && xdo && xlse && xdelta && nacc > 0), "sf_attn_bwd_diag: streamed steps need q / dO / lse / delta and an accumulating branch");
+    SF_CHECK_ARG(ldq % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && ldk % 8 == 0 && lddk % 4 == 0 && ld_out % 8 == 0,
+                 "sf_attn_bwd_diag: strides must be multiples of 8 (16-byte row segments)");
+    AttnBwdDiagArgs p;
+    memset(&p, 0, sizeof(p));
+    p.q = (const sf_bf16*)q; p.ldq = ldq;
+    p.o = (const sf_bf16*)o; p.ldo = ldo;
+    p.dout = (const sf_bf16*)dout; p.lddo = lddo;
+    p.lse = lse; p.delta = delta; p.dq_init = dq_init; p.dq_accumulate = dq_accumulate;
+    for (int i = 0; i < nread; ++i) {
+        SF_CHECK_ARG(kd && vd && kd[i] && vd[i], "sf_attn_bwd_diag: null branch");
+        p.kd[i] = (const sf_bf16*)kd[i]; p.vd[i] = (const sf_bf16*)vd[i];
+    }
+    p.ldk = ldk; p.nread = nread;
+    for (int i = 0; i < nacc; ++i) {
+        const bool fin = dk_out && dk_out[i];
+        SF_CHECK_ARG(first && dkd && dvd && (fin ? (dv_out && dv_out[i]) != 0 : true), "sf_attn_bwd_diag: accumulating branch needs its buffers");
+        SF_CHECK_ARG((fin && first[i]) || (dkd[i] && dvd[i]), "sf_attn_bwd_diag: fp32 sums missing (needed unless first touch AND final)");
+        p.dkd[i] = dkd[i]; p.dvd[i] = dvd[i]; p.first[i] = first[i] ? 1 : 0;
+        p.dk_out[i] = fin ? (sf_bf16*)dk_out[i] : nullptr; p.dv_out[i] = fin ? (sf_bf16*)dv_out[i] : nullptr;
+    }
+    p.lddk = lddk; p.nacc = nacc; p.ld_out = ld_out;
+    for (int x = 0; x < nx; ++x) {
+        SF_CHECK_ARG(xq[x] && xdo[x] && xlse[x] && xdelta[x], "sf_attn_bwd_diag: null streamed step");
+        p.xq[x] = (const sf_bf16*)xq[x]; p.xdo[x] = (const sf_bf16*)xdo[x]; p.xlse[x] = xlse[x]; p.xdelta[x] = xdelta[x];
+    }
+    p.nx = nx;
+    p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.scale = scale;
+    const int rows_per_block = 64 / (hd / 8);
+    const dim3 grid((unsigned)((B * S + rows_per_block - 1) / rows_per_block));
+    SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_diag_kernel<HD>), grid, dim3(256), 0, stream, p));
+    return sf_check_launch("sf_attn_bwd_diag");
 }
 
 static int fill_bwd_args(AttnBwdArgs& p, const void* q, long ldq, const void* dout, long lddo,

@@ -26,7 +26,9 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     // COLUMN tiles and small (<= a quarter of the CUs), those columns are peeled off: the persistent kernel walks an exact number of
     // rounds and the peeled columns run as 128 x 128 tiles (4 x the workgroups, a quarter of the work each: one short round of the
     // generic kernel, measured 0.050 ms against the 0.098 ms round it replaces; tools/tail_bench.py).
-    if (!p.e.Cadd && !p.e.sw_gu && !p.e.sw_dgu && !p.e.red_part && sf_knob("SF_GEMM_PEEL", 1)) {
+    // (round 4: the row-addend form too -- at small M its grids are the ones that leave such rounds: 4096 x 5120, cfg 4 at bs 1 x 4096,
+    // is 320 tiles = 1 round + 64; 2048 x 9216, DeepSeek-V3 dims at bs 1 x 2048, 288 = 1 + 32.  The addend's columns move with C's.)
+    if (!p.e.sw_gu && !p.e.sw_dgu && !p.e.red_part && sf_knob("SF_GEMM_PEEL", 1)) {
         const long cus = sf_w4_grid(1L << 30);
         const long rem = nblk % cus;
         if (nblk > cus && rem != 0 && rem * 4 <= cus && rem % p.tiles_m == 0 && rem / p.tiles_m < p.tiles_n) {
@@ -36,6 +38,7 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
             et.N = N - n_main;
             et.C = c_dtype == SF_F32 ? (void*)((float*)e.C + n_main) : (void*)((sf_bf16*)e.C + n_main);
             if (e.R) et.R = e.R + n_main;
+            if (e.Cadd) et.Cadd = e.Cadd + n_main;
             if (int st = sf_gemm_nt_128_launch(A, lda, (const sf_bf16*)B + (long)n_main * ldb, ldb, K, et, c_dtype, stream)) return st;
             p.e.N = n_main;
             p.N = n_main;

@@ -35,6 +35,37 @@ from . import ops
 from .model import DraftConfig, FlatParams, LlamaForCausalLMEagle3, rope_tables
 
 
+def diag_plan(T: int, NA: int = ops.DIAG_ACC, NR: int = ops.DIAG_READ, NX: int = ops.DIAG_X):
+    """Launches of ``sf_attn_bwd_diag`` per backward sweep step (the TTT diagonal terms: pair (step k, branch i <= k); reference
+    blueprint llama3_eagle.py:1132-1143).  dq of step k needs every pair (k, i) AT sweep step k; dK_i / dV_i are final at sweep
+    step i, and a pair may add to them at any sweep step in [i, k].  Branches are grouped in blocks of ``NA``; at the sweep step of
+    a block's HIGHEST branch ("top") one launch gives the block's branches every step from the top upwards -- the own step plus the
+    later ones streamed again -- first touch, no read of the sums; the pairs inside a block (k below its top) are added at their own
+    step k (read-modify-write).  Per step: ``[dict(own, read, nacc, first, final, stream, dq_accumulate)]`` -- ``read`` lists the
+    branches whose k / v the launch reads (the accumulating ``nacc`` first), ``stream`` the later steps streamed into them."""
+    plan = {}
+    for s in range(T - 1, -1, -1):
+        if s == 0:
+            plan[s] = [dict(own=True, read=[], nacc=0, first=[], final=[], stream=[], dq_accumulate=False)]
+            continue
+        lo = (s - 1) // NA * NA + 1
+        top = min(lo + NA - 1, T - 1)
+        acc = list(range(s, lo - 1, -1))                       # the branches of s's block that exist at step s, s itself first
+        others = [i for i in range(1, s + 1) if i not in acc]
+        stream = list(range(s + 1, T)) if s == top else []
+        chunks = [stream[i:i + NX] for i in range(0, len(stream), NX)] or [[]]
+        launches = []
+        for ci, ch in enumerate(chunks):                       # launch 0 = the own step; further ones only stream
+            launches.append(dict(own=ci == 0, read=(acc + others[:NR - len(acc)]) if ci == 0 else list(acc), nacc=len(acc),
+                                 first=[s == top and ci == 0] * len(acc),
+                                 final=[i == s and ci == len(chunks) - 1 for i in acc], stream=ch, dq_accumulate=False))
+        rest = others[NR - len(acc):]
+        for i in range(0, len(rest), NR):                      # more than NR branches (ttt_length > 9): dq of the own step in chunks
+            launches.append(dict(own=True, read=rest[i:i + NR], nacc=0, first=[], final=[], stream=[], dq_accumulate=True))
+        plan[s] = launches
+    return plan
+
+
 class Eagle3Engine:
     def __init__(self, model: LlamaForCausalLMEagle3, *, ttt_length: int = 7, ploss_decay: float = 0.8,
                  teacher_rows: int = 4096, lk_loss_type: Optional[str] = None, kl_scale: float = 1.0,
@@ -56,6 +87,8 @@ class Eagle3Engine:
             raise NotImplementedError("head_dim must be a multiple of 16 and <= 256 (64 / 128 / 256 native, other widths zero-padded)")
         self.hdp = hd if hd in (64, 128, 256) else (64 if hd < 64 else 128 if hd < 128 else 256)
         self.T = int(ttt_length)
+        self._diag_plan = diag_plan(self.T)      # launches of the blocked diagonal-branch backward, per sweep step
+        self.blocked_diag = True                 # False (A/B, bench.py --diag-per-step): one sf_attn_bwd_pre per step, every pair at its step
         if not 1 <= self.T <= ops.MAX_DIAG + 1:
             raise ValueError(f"ttt_length must be in 1..{ops.MAX_DIAG + 1} (one diagonal branch per earlier TTT step)")
         self.decay = float(ploss_decay)
@@ -248,7 +281,10 @@ class Eagle3Engine:
         b["dh_b"] = [cv("dh_b0", N, H), cv("dh_b1", N, H)]   # residual-stream gradient handed from step k to k-1 (ping-pong)
         b["dact"] = cv("dact", N, I)
         b["dpn"] = cv("dpn", N, H)
-        b["do"] = cv("do", N, nh * hd)
+        # d(attention output) and delta of EVERY step are kept: the blocked diagonal-branch backward streams the later steps'
+        # q / dO / lse / delta again when it finishes a block of branches (diag_plan); with padded heads: one buffer, the per-step form
+        nat = self.hdp == hd
+        b["do"] = [cv(f"do_{k}", N, nh * hd) for k in range(T)] if nat else [cv("do", N, nh * hd)] * T
         b["dxh"] = cv("dxh", N, H)
         # backward of the hoisted embedding half: the fp32 sum over the steps of dqkv re-aligned to token positions, as a
         # two-term bf16 expansion [hi ; lo] (one pass over the dqkv stash after the sweep), and the matching operand [en ; en]
@@ -256,7 +292,7 @@ class Eagle3Engine:
         b["ds_hi"], b["ds_lo"] = b["ds2"][:Np], b["ds2"][Np:]
         b["dE"] = cv("dE", Np, H)
         b["dhs"] = cv("dhs", N, Ht3) if c.fc_norm else None
-        b["delta"] = cv("delta", B, nh, S, dtype=f32)
+        b["delta"] = [cv(f"delta_{k}", B, nh, S, dtype=f32) for k in range(T)] if nat else [cv("delta", B, nh, S, dtype=f32)] * T
         hdp = self.hdp
         b["dq_init"] = cv("dq_init", N, nh * hdp, dtype=f32)
         b["dk"] = [cv(f"dk_{k}", N, nkv * hdp, dtype=f32) for k in range(T)]
@@ -614,8 +650,10 @@ class Eagle3Engine:
         scale = 1.0 / math.sqrt(hd)
         kcol, vcol = slice(nh * hd, (nh + nkv) * hd), slice((nh + nkv) * hd, self.QW)
         ws = b["nws"]
-        for t in b["dk"] + b["dv"]:
-            t.zero_()
+        nat = self.hdp == hd
+        plan = self._diag_plan if (nat and self.blocked_diag) else None
+        for t in (b["dk"][:1] + b["dv"][:1]) if plan is not None else (b["dk"] + b["dv"]):   # (blocked form: the branch sums are
+            t.zero_()                                              # first-touch writes of sf_attn_bwd_diag, only block 0's accumulate)
         nm = self._norm_micro
         first = {n: True for n in nm}
 
@@ -655,26 +693,46 @@ class Eagle3Engine:
             ops.rmsnorm_bwd(b["dpn"], b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"), b["rstd_p"][k],
                             dx=dh1, add=dh, dw_acc=acc, dw_accumulate=a, workspace=ws)
             # attention
-            ops.gemm_nt(dh1, self.woT, b["do"])
+            ops.gemm_nt(dh1, self.woT, b["do"][k])
             qkv = b["qkv"][k]
             if self.hdp == hd:
-                q, o_k, do, dq_out = qkv[:, :nh * hd], b["o"][k], b["do"], dqkv[:, :nh * hd]
+                q, o_k, do, dq_out = qkv[:, :nh * hd], b["o"][k], b["do"][k], dqkv[:, :nh * hd]
                 k0, v0 = b["qkv"][0][:, kcol], b["qkv"][0][:, vcol]
                 kd = [b["qkv"][i][:, kcol] for i in range(1, k + 1)]
                 vd = [b["qkv"][i][:, vcol] for i in range(1, k + 1)]
             else:
-                self._pad_heads(b["do"], nh, b["dop"])
+                self._pad_heads(b["do"][k], nh, b["dop"])
                 q, o_k, do, dq_out = b["qp"][k], b["op"][k], b["dop"], b["dqp"]
                 k0, v0, kd, vd = b["kp"][0], b["vp"][0], b["kp"][1:k + 1], b["vp"][1:k + 1]
             # (K_k / V_k receive their last contribution here -- steps k..T-1 have all run: for k >= 1 their gradients leave the
             # kernel as bf16, straight into the dqkv slot)
-            fin = k > 0 and self.hdp == hd
-            ops.attn_bwd_pre(q, o_k, do, kd, vd, b["dk"][1:k + 1], b["dv"][1:k + 1], b["lse"][k], b["delta"],
-                             b["dq_init"] if k > 0 else None, B=B, S=S, nh=nh, nkv=nkv, hd=self.hdp, scale=scale,
-                             dk_last=dqkv[:, kcol] if fin else None, dv_last=dqkv[:, vcol] if fin else None)
-            ops.attn_bwd_dq(q, do, k0, v0, b["kvlen"], b["lse"][k], b["delta"], b["dq_init"] if k > 0 else None, dq_out,
+            delta = b["delta"][k]
+            if plan is not None:
+                # blocked form (diag_plan): dq_init of this step from all its branches; the branches of this step's block accumulate --
+                # at the block's top step over every later step too (streamed), first touch -- and K_k / V_k, final here, leave as bf16
+                for L in plan[k]:
+                    rd, na = L["read"], L["nacc"]
+                    fin = L["final"]
+                    ops.attn_bwd_diag(
+                        q=q if L["own"] else None, o=o_k if L["own"] else None, dout=do if L["own"] else None,
+                        lse=b["lse"][k] if L["own"] else None, delta=delta if L["own"] else None,
+                        dq_init=b["dq_init"] if (L["own"] and rd) else None, dq_accumulate=L["dq_accumulate"],
+                        kd=[b["qkv"][i][:, kcol] for i in rd], vd=[b["qkv"][i][:, vcol] for i in rd],
+                        dkd=[None if (L["first"][j] and fin[j]) else b["dk"][rd[j]] for j in range(na)],
+                        dvd=[None if (L["first"][j] and fin[j]) else b["dv"][rd[j]] for j in range(na)],
+                        first=L["first"], dk_out=[b["dqkv"][rd[j]][:, kcol] if fin[j] else None for j in range(na)],
+                        dv_out=[b["dqkv"][rd[j]][:, vcol] if fin[j] else None for j in range(na)],
+                        xq=[b["qkv"][x][:, :nh * hd] for x in L["stream"]], xdo=[b["do"][x] for x in L["stream"]],
+                        xlse=[b["lse"][x] for x in L["stream"]], xdelta=[b["delta"][x] for x in L["stream"]],
+                        B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+            else:
+                fin = k > 0 and nat     # (per-step form: K_k / V_k receive their last contribution here and leave as bf16)
+                ops.attn_bwd_pre(q, o_k, do, kd, vd, b["dk"][1:k + 1], b["dv"][1:k + 1], b["lse"][k], delta,
+                                 b["dq_init"] if k > 0 else None, B=B, S=S, nh=nh, nkv=nkv, hd=self.hdp, scale=scale,
+                                 dk_last=dqkv[:, kcol] if fin else None, dv_last=dqkv[:, vcol] if fin else None)
+            ops.attn_bwd_dq(q, do, k0, v0, b["kvlen"], b["lse"][k], delta, b["dq_init"] if k > 0 else None, dq_out,
                             B=B, S=S, nh=nh, nkv=nkv, hd=self.hdp, scale=scale)
-            ops.attn_bwd_dkv(q, do, k0, v0, b["kvlen"], b["lse"][k], b["delta"], b["dk"][0], b["dv"][0], B=B, S=S, nh=nh,
+            ops.attn_bwd_dkv(q, do, k0, v0, b["kvlen"], b["lse"][k], delta, b["dk"][0], b["dv"][0], B=B, S=S, nh=nh,
                              nkv=nkv, hd=self.hdp, scale=scale, workspace=b["dkv_ws"])
             if self.hdp == hd:
                 if k == 0:      # block 0's keys: the dK/dV kernel of this step added the last term

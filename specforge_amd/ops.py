@@ -372,7 +372,7 @@ MAX_DIAG = 32     # kMaxDiag of the attention kernels: diagonal branches per lau
 def _ptr_array(ts: Sequence[torch.Tensor]):
     arr = (ctypes.c_void_p * max(1, len(ts)))()
     for i, t in enumerate(ts):
-        arr[i] = _p(t).value
+        arr[i] = _p(t).value if t is not None else None
     return arr
 
 
@@ -399,6 +399,44 @@ def attn_bwd_pre(q, o, dout, kd, vd, dkd, dvd, lse, delta, dq_init, *, B, S, nh,
                                  _ptr_array(vd), _ptr_array(dkd), _ptr_array(dvd), ldk, lddk, len(kd), _p(lse), _p(delta),
                                  _p(dq_init), B, S, nh, nkv, hd, scale, _p(dk_last), _p(dv_last), ld_last, _stream()),
                "sf_attn_bwd_pre")
+
+
+DIAG_READ, DIAG_ACC, DIAG_X = 6, 4, 8      # sf_attn_bwd_diag: branches read / accumulating / later steps streamed per launch
+
+
+def attn_bwd_diag(*, q=None, o=None, dout=None, lse=None, delta=None, dq_init=None, dq_accumulate=False, kd=(), vd=(), dkd=(), dvd=(),
+                  first=(), dk_out=(), dv_out=(), xq=(), xdo=(), xlse=(), xdelta=(), B, S, nh, nkv, hd, scale):
+    """One launch of the blocked diagonal-branch backward (include/specforge_amd.h: sf_attn_bwd_diag).  ``kd`` / ``vd``: the branches
+    read (own step's dq); the first ``len(first)`` of them accumulate dK / dV -- ``dkd`` / ``dvd`` their fp32 sums (entries may be
+    None when first AND final), ``first`` flags, ``dk_out`` / ``dv_out`` bf16 destinations of the final ones (None = not final).
+    ``xq`` / ``xdo`` / ``xlse`` / ``xdelta``: later TTT steps streamed into the accumulating branches."""
+    L = _lib.lib()
+    nacc = len(first)
+    assert len(kd) == len(vd) <= DIAG_READ and nacc <= min(DIAG_ACC, len(kd)) and len(xq) == len(xdo) == len(xlse) == len(xdelta) <= DIAG_X
+    assert len(dkd) == len(dvd) == len(dk_out) == len(dv_out) == nacc
+    some = lambda ts: next((t for t in ts if t is not None), None)
+    ldk = _rowmajor(kd[0]) if kd else 0
+    for t in list(kd) + list(vd):
+        assert _rowmajor(t) == ldk
+    acc0, out0 = some(list(dkd) + list(dvd)), some(list(dk_out) + list(dv_out))
+    lddk = _rowmajor(acc0) if acc0 is not None else 0
+    ld_out = _rowmajor(out0) if out0 is not None else 0
+    for t in list(dkd) + list(dvd):
+        assert t is None or (t.dtype == torch.float32 and _rowmajor(t) == lddk)
+    for t in list(dk_out) + list(dv_out):
+        assert t is None or (t.dtype == torch.bfloat16 and _rowmajor(t) == ld_out)
+    src = q if q is not None else xq[0]
+    ldq = _rowmajor(src)
+    lddo = _rowmajor(dout if dout is not None else xdo[0])
+    for t in xq:
+        assert _rowmajor(t) == ldq
+    for t in xdo:
+        assert _rowmajor(t) == lddo
+    flags = (ctypes.c_int * max(1, nacc))(*[1 if f else 0 for f in first])
+    _lib.check(L.sf_attn_bwd_diag(_p(q), ldq, _p(o), _rowmajor(o) if o is not None else 0, _p(dout), lddo, _p(lse), _p(delta), _p(dq_init),
+                                  1 if dq_accumulate else 0, _ptr_array(kd), _ptr_array(vd), ldk, len(kd), _ptr_array(dkd), _ptr_array(dvd),
+                                  lddk, nacc, flags, _ptr_array(dk_out), _ptr_array(dv_out), ld_out, _ptr_array(xq), _ptr_array(xdo),
+                                  _ptr_array(xlse), _ptr_array(xdelta), len(xq), B, S, nh, nkv, hd, scale, _stream()), "sf_attn_bwd_diag")
 
 
 def attn_bwd_dq(q, dout, k0, v0, kv_len, lse, delta, dq_init, dq, *, B, S, nh, nkv, hd, scale):

@@ -157,3 +157,72 @@ def test_dkv_head_split_equals_unsplit(backend, hd):
     tol = lambda r: 2e-2 * float(r.abs().max())
     assert float((dk1 - 0.5 - dk_ref[0]).abs().max()) <= tol(dk_ref[0]) and float((dv1 + 0.25 - dv_ref[0]).abs().max()) <= tol(dv_ref[0])
     assert float((dk1.view(B, S, -1)[1, 97:] - 0.5).abs().max()) == 0.0     # padded keys of sample 1: nothing added
+
+
+@pytest.mark.parametrize("hd,T", [(64, 7), (128, 10), (128, 4), (256, 6)])
+def test_blocked_diagonal_backward_follows_the_plan(backend, hd, T):
+    """sf_attn_bwd_diag driven by engine.diag_plan over a whole backward sweep of T TTT steps (step k: its own q_k / dO_k, branches
+    1..k): every dq_k and every finished dK_i / dV_i (bf16, written at sweep step i) against the sum of the per-step oracle
+    gradients.  T = 10: two full blocks + one partial, steps with more than 6 branches (dq in two launches); T = 7 is the
+    headline's plan (block {1..4} gathered at step 4 with steps 5, 6 streamed)."""
+    from specforge_amd.engine import diag_plan
+
+    B, S, nh, nkv = 2, 40, 4, 2
+    lengths = [40, 27]
+    N, scale = B * S, 1.0 / math.sqrt(hd)
+    g = torch.Generator().manual_seed(100 * hd + T)
+    ks = [torch.randn(B, S, nkv * hd, generator=g).to(torch.bfloat16) for _ in range(T)]
+    vs = [torch.randn(B, S, nkv * hd, generator=g).to(torch.bfloat16) for _ in range(T)]
+    qs = [torch.randn(B, S, nh * hd, generator=g).to(torch.bfloat16) for _ in range(T)]
+    dos = [torch.randn(B, S, nh * hd, generator=g).to(torch.bfloat16) for _ in range(T)]
+    dq_ref, dk_ref, dv_ref = [], [torch.zeros(N, nkv * hd) for _ in range(T)], [torch.zeros(N, nkv * hd) for _ in range(T)]
+    for k in range(T):
+        _, dq, dk, dv = _oracle(qs[k], ks[:k + 1], vs[:k + 1], dos[k], B, S, nh, nkv, hd, lengths)
+        dq_ref.append(dq)
+        for i in range(k + 1):
+            dk_ref[i] += dk[i]
+            dv_ref[i] += dv[i]
+    d = lambda t: t.to(backend)
+    kv_len = d(torch.tensor(lengths, dtype=torch.int32))
+    K = [d(t.view(N, -1)) for t in ks]
+    V = [d(t.view(N, -1)) for t in vs]
+    Q = [d(t.view(N, -1)) for t in qs]
+    DO = [d(t.view(N, -1)) for t in dos]
+    O = [torch.empty(N, nh * hd, dtype=torch.bfloat16, device=backend) for _ in range(T)]
+    LSE = [torch.empty(B, nh, S, device=backend) for _ in range(T)]
+    for k in range(T):
+        ops.attn_fwd(Q[k], K[0], V[0], K[1:k + 1], V[1:k + 1], kv_len, O[k], LSE[k], B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+    DELTA = [torch.full((B, nh, S), float("nan"), device=backend) for _ in range(T)]
+    dq_init = torch.full((N, nh * hd), float("nan"), device=backend)
+    acc_k = [torch.full((N, nkv * hd), float("nan"), device=backend) for _ in range(T)]   # never zeroed: first touch must not read them
+    acc_v = [torch.full((N, nkv * hd), float("nan"), device=backend) for _ in range(T)]
+    out_k = [torch.full((N, nkv * hd), float("nan"), dtype=torch.bfloat16, device=backend) for _ in range(T)]
+    out_v = [torch.full((N, nkv * hd), float("nan"), dtype=torch.bfloat16, device=backend) for _ in range(T)]
+    plan = diag_plan(T)
+    assert all(len(plan[s]) == 1 for s in range(min(T, 7)))          # up to 6 branches and 8 streamed steps: one launch per step
+    nlaunch = 0
+    for s in range(T - 1, -1, -1):
+        for L in plan[s]:
+            rd, na, fin = L["read"], L["nacc"], L["final"]
+            own = L["own"]
+            ops.attn_bwd_diag(q=Q[s] if own else None, o=O[s] if own else None, dout=DO[s] if own else None, lse=LSE[s] if own else None,
+                              delta=DELTA[s] if own else None, dq_init=dq_init if (own and rd) else None, dq_accumulate=L["dq_accumulate"],
+                              kd=[K[i] for i in rd], vd=[V[i] for i in rd],
+                              dkd=[None if (L["first"][j] and fin[j]) else acc_k[rd[j]] for j in range(na)],
+                              dvd=[None if (L["first"][j] and fin[j]) else acc_v[rd[j]] for j in range(na)], first=L["first"],
+                              dk_out=[out_k[rd[j]] if fin[j] else None for j in range(na)],
+                              dv_out=[out_v[rd[j]] if fin[j] else None for j in range(na)],
+                              xq=[Q[x] for x in L["stream"]], xdo=[DO[x] for x in L["stream"]], xlse=[LSE[x] for x in L["stream"]],
+                              xdelta=[DELTA[x] for x in L["stream"]], B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+            nlaunch += 1
+        dq = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=backend)
+        ops.attn_bwd_dq(Q[s], DO[s], K[0], V[0], kv_len, LSE[s], DELTA[s], dq_init if s > 0 else None, dq, B=B, S=S, nh=nh, nkv=nkv,
+                        hd=hd, scale=scale)
+        tol = 3e-2 * float(dq_ref[s].abs().max())
+        assert float((dq.float().cpu() - dq_ref[s]).abs().max()) <= tol, ("dq", s)
+        if s >= 1:       # branch s is final at sweep step s: its bf16 gradient has been written
+            for got, ref, what in ((out_k[s], dk_ref[s], "dk"), (out_v[s], dv_ref[s], "dv")):
+                err = float((got.float().cpu() - ref).abs().max())
+                assert err <= 3e-2 * float(ref.abs().max()) + 1e-6, (what, s, err)
+    if T == 7:
+        assert nlaunch == 7 and [len(L["stream"]) for s in (6, 5, 4, 3) for L in plan[s]] == [0, 0, 2, 0]

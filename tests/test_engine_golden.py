@@ -111,6 +111,22 @@ def test_micro_step_matches_reference_run(backend, golden_dir, name):
     assert not bad, worst
 
 
+def test_blocked_and_per_step_diagonal_backward_agree(backend, golden_dir):
+    """engine.blocked_diag (round 4: sf_attn_bwd_diag over engine.diag_plan -- blocks of branches gathered at their top step, later
+    steps streamed, first-touch sums) vs the per-step form (one sf_attn_bwd_pre per TTT step): the same gradient up to fp32
+    summation order, on the ttt-7 golden (blocks {1..4} and {5, 6}) -- and the blocked run is bit-reproducible"""
+    blob = torch.load(os.path.join(golden_dir, "eagle31_gqa_fp32.pt"), weights_only=False)
+    grads = []
+    for blocked in (True, False, True):
+        cfg, model, eagle, strat = _build(blob, backend)
+        eagle.train()
+        eagle.engine.blocked_diag = blocked
+        strat.forward_loss(_batch(blob, backend)).loss.backward()
+        grads.append(eagle.engine.flat.grad.float().cpu().clone())
+    assert torch.equal(grads[0], grads[2])
+    torch.testing.assert_close(grads[0], grads[1], rtol=2e-2, atol=4e-3 * float(grads[1].abs().max()))
+
+
 def test_accumulation_window_and_eval_mode(backend, golden_dir):
     """two micro-steps accumulate (DDP no_sync semantics, training/backend.py:310-320); eval forward leaves no state"""
     blob = torch.load(os.path.join(golden_dir, "eagle3_tiny_bf16.pt"), weights_only=False)

@@ -133,6 +133,14 @@ def test_gemm_nt_peeled_last_round_epilogues(backend):
     ops.gemm_nt(_dev(backend, a), _dev(backend, b), outb, residual=_dev(backend, res))
     expect = (ref.to(torch.bfloat16) + res).float()
     torch.testing.assert_close(outb.float().cpu(), expect, rtol=2e-2, atol=0.5)
+    # the row-addend form (round 4: peeled too): the addend's columns move with the peeled C columns
+    S, T = 128, 3
+    B, Spad = M // S, S + T
+    add = _rand((B * Spad, N), torch.float32, 7, scale=3.0)
+    rows = (torch.arange(M) // S) * Spad + torch.arange(M) % S + T
+    outr = torch.full((M, N), 5.0, dtype=torch.bfloat16, device=backend)
+    ops.gemm_nt_rowadd(_dev(backend, a), _dev(backend, b), outr, _dev(backend, add), S=S, Spad=Spad, off=T)
+    torch.testing.assert_close(outr.float().cpu(), ref + add[rows], rtol=2e-2, atol=2e-2 * math.sqrt(K))
 
 
 # ------------------------------------------------------------------ fused CE
