@@ -472,15 +472,12 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_diag_kernel(AttnBwdDiagArgs p) 
         for (int i = 0; i < NA; ++i)
 #pragma unroll
             for (int e = 0; e < 8; ++e) { dk[i][e] = 0.f; dv[i][e] = 0.f; }
-        // ---- the launch's own step: delta, dq_init over every branch read, dK / dV of the accumulating ones
+        // ---- the launch's own step: delta, dq_init over every branch read, dK / dV of the accumulating ones.  The kernel is bound by
+        // load latency, not bandwidth (8 waves per CU, one 16-byte load per lane and operand in flight): two query heads are loaded
+        // per trip (6 loads in flight instead of 3), then both are worked through
         if (p.q) {
-            for (int hh = 0; hh < nrep; ++hh) {
-                const int h = g * nrep + hh;
+            auto own_head = [&](int h, const float (&qv)[8], const float (&ov)[8], const float (&dov)[8]) SF_LAMBDA_INLINE {
                 const int col = h * HD + d0;
-                float qv[8], ov[8], dov[8];
-                SfVec8<sf_bf16>::ld(p.q + (long)row * p.ldq + col, qv);
-                SfVec8<sf_bf16>::ld(p.o + (long)row * p.ldo + col, ov);
-                SfVec8<sf_bf16>::ld(p.dout + (long)row * p.lddo + col, dov);
                 float dl = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dl += ov[e] * dov[e];
@@ -529,6 +526,24 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_diag_kernel(AttnBwdDiagArgs p) 
                         SfVec8<float>::st(dqp, dq);
                     }
                 }
+            };
+            for (int hh = 0; hh < nrep; hh += 2) {
+                const int h = g * nrep + hh;
+                const bool two = hh + 1 < nrep;
+                const int h2 = two ? h + 1 : h;         // (odd group size: the second slot re-reads the first head and is not applied)
+                float qa[8], oa[8], da[8];
+                SfVec8<sf_bf16>::ld(p.q + (long)row * p.ldq + h * HD + d0, qa);
+                SfVec8<sf_bf16>::ld(p.o + (long)row * p.ldo + h * HD + d0, oa);
+                SfVec8<sf_bf16>::ld(p.dout + (long)row * p.lddo + h * HD + d0, da);
+                const sf_v8s qp = *reinterpret_cast<const sf_v8s*>(p.q + (long)row * p.ldq + h2 * HD + d0);     // second head: kept packed
+                const sf_v8s op = *reinterpret_cast<const sf_v8s*>(p.o + (long)row * p.ldo + h2 * HD + d0);
+                const sf_v8s dp = *reinterpret_cast<const sf_v8s*>(p.dout + (long)row * p.lddo + h2 * HD + d0);
+                own_head(h, qa, oa, da);
+                if (two) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { qa[e] = sf_bf2f((sf_bf16)qp[e]); oa[e] = sf_bf2f((sf_bf16)op[e]); da[e] = sf_bf2f((sf_bf16)dp[e]); }
+                    own_head(h2, qa, oa, da);
+                }
             }
         }
         // ---- later TTT steps streamed into the accumulating branches (their dq / delta were finished at their own sweep step)
@@ -537,12 +552,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_diag_kernel(AttnBwdDiagArgs p) 
             const sf_bf16* xdo = p.xdo[x];
             const float* xl = p.xlse[x];
             const float* xd = p.xdelta[x];
-            for (int hh = 0; hh < nrep; ++hh) {
-                const int h = g * nrep + hh;
-                const int col = h * HD + d0;
-                float qv[8], dov[8];
-                SfVec8<sf_bf16>::ld(xq + (long)row * p.ldq + col, qv);
-                SfVec8<sf_bf16>::ld(xdo + (long)row * p.lddo + col, dov);
+            auto x_head = [&](int h, const float (&qv)[8], const float (&dov)[8]) SF_LAMBDA_INLINE {
                 const long lidx = ((long)b * p.nh + h) * p.S + t;
                 const float lse = xl[lidx], dl = xd[lidx];
 #pragma unroll
@@ -564,6 +574,22 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_diag_kernel(AttnBwdDiagArgs p) 
                             dv[i][e] += pi * dov[e];
                         }
                     }
+                }
+            };
+            for (int hh = 0; hh < nrep; hh += 2) {
+                const int h = g * nrep + hh;
+                const bool two = hh + 1 < nrep;
+                const int h2 = two ? h + 1 : h;
+                float qa[8], da[8];
+                SfVec8<sf_bf16>::ld(xq + (long)row * p.ldq + h * HD + d0, qa);
+                SfVec8<sf_bf16>::ld(xdo + (long)row * p.lddo + h * HD + d0, da);
+                const sf_v8s qp = *reinterpret_cast<const sf_v8s*>(xq + (long)row * p.ldq + h2 * HD + d0);
+                const sf_v8s dp = *reinterpret_cast<const sf_v8s*>(xdo + (long)row * p.lddo + h2 * HD + d0);
+                x_head(h, qa, da);
+                if (two) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { qa[e] = sf_bf2f((sf_bf16)qp[e]); da[e] = sf_bf2f((sf_bf16)dp[e]); }
+                    x_head(h2, qa, da);
                 }
             }
         }

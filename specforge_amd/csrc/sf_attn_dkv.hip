@@ -340,6 +340,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, NW / 4) attn_bwd_dkv_rs_kernel(AttnBwdA
     const int sub = wave - role * NSUB;
     // 1-D grid, heaviest first: key block 0 sees every query tile, the last one only the final tiles
     const int per_kb = p.nkv * p.B;
+    const int hsplit = p.hsplit > 1 ? p.hsplit : 1;
     int kbi, g, b;
     if (p.l2_map) {   // pair-major: the key blocks of one (batch, kv head) stream the same Q / dO tiles
         const int nkb = (p.S + KB - 1) / KB;
@@ -348,11 +349,12 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, NW / 4) attn_bwd_dkv_rs_kernel(AttnBwdA
         const int pr = v / nkb;
         kbi = v - pr * nkb; b = pr / p.nkv; g = pr - b * p.nkv;
     } else {
-        const int bid = (int)blockIdx.x, gb = bid % per_kb;
+        const int bid = (int)blockIdx.x / hsplit, gb = bid % per_kb;
         kbi = bid / per_kb; g = gb % p.nkv; b = gb / p.nkv;
     }
+    const int hs = (int)blockIdx.x % hsplit;     // head split (small B * nkv), as in attn_bwd_dkv_kernel
     const int kb0 = kbi * KB;
-    const int S = p.S, nrep = p.nh / p.nkv;
+    const int S = p.S, nrep = (p.nh / p.nkv) / hsplit, h_first = g * (p.nh / p.nkv) + hs * nrep;
     const int kvlen = p.kv_len ? p.kv_len[b] : S;
     const int kw0 = kb0 + sub * 32;
     const int ki = kw0 + c;  // this lane's key (column of S)
@@ -390,7 +392,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, NW / 4) attn_bwd_dkv_rs_kernel(AttnBwdA
     int it = 0;
     if (block_live)
         for (int hh = 0; hh < nrep; ++hh) {
-            const int h = g * nrep + hh;
+            const int h = h_first + hh;
             const SfBufB qbuf = rows_buf<HD>(p.q + (long)b * S * p.ldq + h * HD, p.ldq, S);
             const SfBufB dobuf = rows_buf<HD>(p.dout + (long)b * S * p.lddo + h * HD, p.lddo, S);
             const SfBufB lsebuf = sf_make_bufb(p.lse + ((long)b * p.nh + h) * S, (unsigned)S * 4u);
@@ -458,14 +460,17 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, NW / 4) attn_bwd_dkv_rs_kernel(AttnBwdA
             }
         }
     if (!kok || !block_live) return;
-    float* orow = (role == 0 ? p.dv : p.dk) + krow * p.lddk + g * HD;
+    const bool split = p.hsplit > 1;      // partial sums of this head slice: written, not accumulated (attn_dkv_reduce_kernel adds them)
+    float* orow = split ? (role == 0 ? p.part_v : p.part_k) + (long)hs * p.part_stride + krow * ((long)p.nkv * HD) + g * HD
+                        : (role == 0 ? p.dv : p.dk) + krow * p.lddk + g * HD;
     const float oscale = role == 0 ? 1.0f : p.scale;
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int col = d * 32 + 8 * j + 4 * hi;
-            sf_v4f a = *reinterpret_cast<const sf_v4f*>(orow + col);
+            sf_v4f a = sf_v4f{0.f, 0.f, 0.f, 0.f};
+            if (!split) a = *reinterpret_cast<const sf_v4f*>(orow + col);
 #pragma unroll
             for (int t = 0; t < 4; ++t) a[t] += acc[d][4 * j + t] * oscale;
             *reinterpret_cast<sf_v4f*>(orow + col) = a;
@@ -479,8 +484,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, NW / 4) attn_bwd_dkv_rs_kernel(AttnBwdA
 // workgroup (measured at cfg 4's recipe, bs 1 x 4096, 32 / 4 heads: 0.15 of the MFMA peak where bs 4 reaches 0.43).  The heads
 // of a group are then divided over `hsplit` workgroups (the smallest divisor of nh / nkv that brings the grid to 512).
 static int dkv_head_split(int B, int S, int nh, int nkv, int hd) {
-    if (hd == 256) return 1;
-    const long wgs = (long)((S + 127) / 128) * nkv * B;
+    const long wgs = (long)((S + 127) / 128) * nkv * B * (hd == 256 ? 2 : 1);   // (head_dim 256: 64 keys per workgroup)
     const int nrep = nh / nkv;
     if (wgs >= 512) return 1;
     for (int d = 2; d < nrep; ++d)
@@ -512,20 +516,25 @@ extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long l
     p.dk = dk; p.dv = dv; p.lddk = lddk;
     p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.scale = scale;
     p.l2_map = sf_knob("SF_ATTN_DKV_L2MAP", 0);   // heaviest-first over ALL pairs wins here (measured: pair-major +20 %)
-    if (hd == 256) {
-        constexpr int HD = 256, NW = 4;       // 2 key sub-blocks x 2 roles: 64 keys per workgroup
-        dim3 grid(attn_grid((long)((S + NW * 16 - 1) / (NW * 16)) * nkv * B, p.l2_map));
-        SF_ALLOW_SMEM((attn_bwd_dkv_rs_kernel<HD, NW>), 2 * (128 * HD * 2 + 512));
-        SF_LAUNCH((attn_bwd_dkv_rs_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (128 * HD * 2 + 512), stream, p);
-        return sf_check_launch("sf_attn_bwd_dkv");
-    }
-    SF_CHECK_ARG(hd == 64 || hd == 128, "head_dim must be 64, 128 or 256");
+    SF_CHECK_ARG(hd == 64 || hd == 128 || hd == 256, "head_dim must be 64, 128 or 256");
     int hsplit = dkv_head_split(B, S, nh, nkv, hd);
     if (!workspace || workspace_floats < 2L * hsplit * B * S * nkv * hd || ((size_t)workspace & 15) || p.l2_map) hsplit = 1;
     p.hsplit = hsplit;
     p.part_stride = (long)B * S * nkv * hd;
     p.part_k = workspace;
     p.part_v = workspace ? workspace + hsplit * p.part_stride : nullptr;
+    if (hd == 256) {
+        constexpr int HD = 256, NW = 4;       // 2 key sub-blocks x 2 roles: 64 keys per workgroup
+        dim3 grid(attn_grid((long)((S + NW * 16 - 1) / (NW * 16)) * nkv * B * hsplit, p.l2_map));
+        SF_ALLOW_SMEM((attn_bwd_dkv_rs_kernel<HD, NW>), 2 * (128 * HD * 2 + 512));
+        SF_LAUNCH((attn_bwd_dkv_rs_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (128 * HD * 2 + 512), stream, p);
+        if (hsplit > 1) {
+            const int W = nkv * hd;
+            const long n4 = (long)B * S * (W / 4);
+            SF_LAUNCH(attn_dkv_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, p, W, NW * 16);
+        }
+        return sf_check_launch("sf_attn_bwd_dkv");
+    }
     dim3 grid(attn_grid((long)((S + 127) / 128) * nkv * B * hsplit, p.l2_map));   // 128 keys per workgroup
     if (hd == 128) {
         constexpr int HD = 128;

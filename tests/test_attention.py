@@ -123,7 +123,7 @@ def test_ttt_attention_fwd_bwd(backend, hd, B, S, nh, nkv, lengths, nsteps):
     torch.testing.assert_close(dk_acc[0].cpu(), 2 * before.cpu(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("hd", [64, 128])
+@pytest.mark.parametrize("hd", [64, 128, 256])
 def test_dkv_head_split_equals_unsplit(backend, hd):
     """B * nkv * ceil(S / 128) < 512 (a bs 1 recipe): the dK/dV kernel divides the query heads of a kv group over several
     workgroups whose partial sums go through a workspace (sf_attn_bwd_dkv, ABI 5) -- same gradients as the unsplit launch
