@@ -315,3 +315,11 @@ template <int PROF> struct SfProf {
         else if ((hd) == 256) { constexpr int HD = 256; CALL; }   \
         else SF_CHECK_ARG(false, "head_dim must be 64, 128 or 256"); \
     } while (0)
+
+// (tools-build variants that exist for head_dim 64 / 128 only)
+#define SF_HD_DISPATCH_128(hd, CALL)                              \
+    do {                                                          \
+        if ((hd) == 128) { constexpr int HD = 128; CALL; }        \
+        else if ((hd) == 64) { constexpr int HD = 64; CALL; }     \
+        else SF_CHECK_ARG(false, "this variant exists for head_dim 64 and 128 only"); \
+    } while (0)
