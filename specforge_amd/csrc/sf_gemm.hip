@@ -149,6 +149,22 @@ static int sf_gemm_dispatch(const void* A, long lda, const void* B, long ldb, in
     const bool big = (long)((M + 255) / 256) * ((N + 255) / 256) >= 256 && K >= 512;
 #endif
     const bool w4_ok = !(e.Cadd && e.alpha != 1.0f);   // its addend path starts the accumulators from Cadd
+#ifndef SF_EMU
+    // Under-filled grids (round 4): with at most HALF as many 256 x 256 tiles as CUs -- the N = H GEMMs of a bs 1 x 4096 recipe at
+    // H = 2048 are 16 x 8 = 128 tiles on 256 CUs -- the 128 x 128 kernel (4 x the workgroups, two per CU) keeps every CU busy and wins
+    // by 8 ... 39 % (4096 x 2048 x {4096, 5120, 6144, 12288, 32000}, 2048 x 4096 x 4096); from 160 tiles up the 256-tile kernels are
+    // faster again (tools/small_tile_ab.py, profiles/r4_small_tile_ab.jsonl).
+    {
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+            return n >= 8 ? n : 256;
+        }();
+        static const int small_tiles = sf_knob("SF_GEMM_SMALL128", 1);
+        if (small_tiles && 2L * ((M + 255) / 256) * ((N + 255) / 256) <= cus && sf_gemm_use_256())
+            return sf_gemm_nt_128_launch(A, lda, B, ldb, K, e, c_dtype, stream);
+    }
+#endif
     if (K % 64 == 0 && K >= 64 && M >= 192 && N >= 192 && sf_gemm_use_256() && w4_ok &&
         (w4_mode == 1 || (w4_mode < 0 && big)))
         return sf_gemm_nt_256w4_launch(A, lda, B, ldb, K, e, c_dtype, stream);
