@@ -423,22 +423,45 @@ SF_GLOBAL void norm_finish_kernel(const float* partial, int nb, float* norm_out,
 template <typename T>
 SF_GLOBAL void adamw_kernel(const T* g, float* master, float* m, float* v, T* param, long n, const float* norm,
                             float max_norm, float lr, float beta1, float beta2, float eps, float wd, float bc1,
-                            float bc2_sqrt, float grad_prescale) {
+                            float bc2_sqrt, float grad_prescale, int vec) {
     float clip = 1.0f;
     if (max_norm > 0.f) clip = fminf(1.0f, max_norm / (norm[0] + 1e-6f));
     const float gsc = clip * grad_prescale;
     const float step_size = lr / bc1;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float g32 = SfElem<T>::ld(g + i) * gsc;
-        float p = master[i] * (1.0f - lr * wd);
-        float mi = m[i] * beta1 + g32 * (1.0f - beta1);
-        float vi = v[i] * beta2 + g32 * g32 * (1.0f - beta2);
-        float denom = sqrtf(vi) / bc2_sqrt + eps;
+    auto update = [&](float g32, float& p, float& mi, float& vi) {
+        g32 *= gsc;
+        p = p * (1.0f - lr * wd);
+        mi = mi * beta1 + g32 * (1.0f - beta1);
+        vi = vi * beta2 + g32 * g32 * (1.0f - beta2);
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p = p - step_size * (mi / denom);
-        master[i] = p;
-        m[i] = mi;
-        v[i] = vi;
-        SfElem<T>::st(param + i, p);
+    };
+    // 28 bytes per parameter, nothing else: 8 parameters per thread and trip, every stream as 16-byte accesses (round 4: the scalar
+    // form -- 2- and 4-byte accesses, one parameter per trip -- ran at 4.8 TB/s; same arithmetic per element, bit-identical results)
+    const long n8 = vec ? n >> 3 : 0;      // (vec = 0: some stream is not 16-byte aligned -- one parameter per trip)
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < n8; u += (long)gridDim.x * blockDim.x) {
+        const long i = u * 8;
+        float gg[8], pp[8], mm[8], vv[8];
+        SfVec8<T>::ld(g + i, gg);
+        SfVec8<float>::ld(master + i, pp);
+        SfVec8<float>::ld(m + i, mm);
+        SfVec8<float>::ld(v + i, vv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) update(gg[e], pp[e], mm[e], vv[e]);
+        SfVec8<float>::st(master + i, pp);
+        SfVec8<float>::st(m + i, mm);
+        SfVec8<float>::st(v + i, vv);
+        SfVec8<T>::st(param + i, pp);
+    }
+    for (long i = n8 * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        {
+            float p = master[i], mi = m[i], vi = v[i];
+            update(SfElem<T>::ld(g + i), p, mi, vi);
+            master[i] = p;
+            m[i] = mi;
+            v[i] = vi;
+            SfElem<T>::st(param + i, p);
+        }
     }
 }
 
@@ -699,9 +722,10 @@ extern "C" int sf_adamw_step(const void* g, int dtype, float* master, float* m, 
     if (n == 0) return 0;
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    const int vec = (((size_t)g | (size_t)master | (size_t)m | (size_t)v | (size_t)param) & 15) == 0;
     SF_DISPATCH_T(dtype, SF_LAUNCH((adamw_kernel<T>), dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, stream, (const T*)g,
                                    master, m, v, (T*)param, n, norm, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2s,
-                                   grad_prescale));
+                                   grad_prescale, vec));
     return sf_check_launch("sf_adamw_step");
 }
 
