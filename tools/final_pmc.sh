@@ -3,7 +3,7 @@
 # usage: bash tools/final_pmc.sh [rN] [commit]
 export TMPDIR=/tmp
 R=${1:-r4}; C=${2:-unknown}; O=gpurun_out/final; mkdir -p $O
-B="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dense-mask"
+B="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dense-mask --no-feeds"
 rm -rf /tmp/pmc_f /tmp/pmc_w /tmp/pmc_m /tmp/pmc_fw
 timeout 150 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmc_f --output-format csv -- $B > $O/pmc_f.log 2>&1
 timeout 150 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmc_w --output-format csv -- $B > $O/pmc_w.log 2>&1
