@@ -77,16 +77,30 @@ def init_single_rank(port: int = 29577):
     os.environ.setdefault("WORLD_SIZE", "1")
     os.environ.setdefault("LOCAL_RANK", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if "MASTER_PORT" not in os.environ:   # `port` is only a hint: parallel test workers (pytest -n) must not collide
-        import socket
-
-        with socket.socket() as sk:
-            try:
-                sk.bind(("127.0.0.1", port))
-            except OSError:
-                sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        os.environ["MASTER_PORT"] = str(port)
     from specforge.distributed import init_distributed
 
-    init_distributed(timeout=10, tp_size=1)
+    if "MASTER_PORT" in os.environ:
+        init_distributed(timeout=10, tp_size=1)
+        return
+    # `port` is only a hint: parallel test workers (pytest -n) must not collide.  Probing a port and binding it later is a race
+    # (another worker can take it in between), so the rendezvous itself is retried on a fresh ephemeral port.
+    import socket
+
+    last = None
+    for attempt in range(5):
+        with socket.socket() as sk:
+            try:
+                sk.bind(("127.0.0.1", port if attempt == 0 else 0))
+            except OSError:
+                sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        try:
+            init_distributed(timeout=10, tp_size=1)
+            return
+        except Exception as e:      # EADDRINUSE surfaces as a RuntimeError / DistNetworkError from the TCP store
+            last = e
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            if "address" not in str(e).lower() and "EADDRINUSE" not in str(e):
+                raise
+    raise last

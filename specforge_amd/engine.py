@@ -176,6 +176,11 @@ class Eagle3Engine:
                 self._views.pop(next(iter(self._views)))
         self._views[key] = b                     # (re)inserted last = most recently used
         if self._active != key:
+            # per SHAPE SWITCH, not per step: on ragged data (the collator pads a batch to its own longest sample) that is nearly every
+            # step -- ~150 view carvings on a cache miss plus the constants below (a few dozen small fills; the padded q / k / v / o
+            # copies only with zero-padded heads).  It is host + launch overhead of the ragged path (tools/ragged_bench.py: 96 % of the
+            # aligned shape's throughput); bucketing S in the collator (ingest pad_multiple) makes shapes repeat, at the price of the
+            # reference's loss normalisation (a mean over ALL B * S rows), so it is not the default.
             self._init_constants(b, B, S)
             self._active = key
         return b

@@ -111,6 +111,27 @@ def test_micro_step_matches_reference_run(backend, golden_dir, name):
     assert not bad, worst
 
 
+@pytest.mark.parametrize("ttt", [10, 13])
+def test_long_ttt_unroll_matches_pinned_oracle(backend, golden_dir, ttt):
+    """ttt_length above the reference's default 7 at a native head_dim: the blocked diagonal backward then plans several blocks of
+    branches, steps with more than 6 branches (dq in two or three launches) and streamed-step lists; expected values = the pinned
+    oracle in bf16 on the golden's inputs with the longer unroll"""
+    blob = torch.load(os.path.join(golden_dir, "eagle3_tiny_fp32.pt"), weights_only=False)
+    blob["cfg"] = dict(blob["cfg"], ttt=ttt)
+    blob = _oracle_bf16(blob)
+    cfg, model, eagle, strat = _build(blob, backend)
+    eagle.train()
+    out = strat.forward_loss(_batch(blob, backend))
+    out.loss.backward()
+    assert len(out.metrics["plosses"]) == ttt and max(len(v) for v in eagle.engine._diag_plan.values()) >= 2
+    assert torch.equal(eagle.last_artifacts["target_token_ids"].cpu(), blob["target_token_ids"])
+    torch.testing.assert_close(torch.stack(out.metrics["plosses"]).float().cpu(), blob["plosses"], rtol=2e-2, atol=2e-2)
+    named = dict(model.named_parameters())
+    worst = {k: float((named[k].grad.float().cpu() - g.float()).abs().max()) / float(g.float().abs().max().clamp_min(1e-8))
+             for k, g in blob["grads"].items()}
+    assert max(worst.values()) <= 5e-2, worst
+
+
 def test_blocked_and_per_step_diagonal_backward_agree(backend, golden_dir):
     """engine.blocked_diag (round 4: sf_attn_bwd_diag over engine.diag_plan -- blocks of branches gathered at their top step, later
     steps streamed, first-touch sums) vs the per-step form (one sf_attn_bwd_pre per TTT step): the same gradient up to fp32
