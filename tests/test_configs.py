@@ -83,6 +83,71 @@ def test_config_micro_step_matches_oracle(name):
     assert not bad, worst
 
 
+# ------------------------------------------------------------------ dimension RELATIONS of the reference's other recipes (configs/*.json)
+# Scaled-down cases (the CPU oracle and the SIMT interpreter finish them in seconds; [emu] in the CPU suite, [gpu] on hardware) that keep
+# what the host code and the kernels branch on:
+#   longcat-flash-eagle3.json      draft vocabulary == target vocabulary (no pruning: t2d all true, d2t zero), 64 / 16 heads
+#   deepseek-v2-lite-eagle3.json   MHA (nkv == nh), yarn RoPE, I not a multiple of 128 / 256
+#   qwen2.5-7b / qwen2-5-vl-7b     28 / 4 heads: 7 query heads per kv group (odd: head pairs of the diagonal kernel, head split of dK/dV)
+#   gpt-oss-{20,120}B-eagle3.json  H = 2880 and I = 17280: multiples of 64 but not of 128 / 256 (edge tiles everywhere, unfused SwiGLU dgrad)
+#   gemma3-1b-eagle3.json          head_dim 256 with 4 / 1 heads and nh * hd != H
+ODD = {
+    "longcat_vd_equals_vt": dict(H=128, Ht=128, I=256, nh=4, nkv=1, hd=64, Vt=384, Vd=384, B=2, S=24, ttt=3, lengths=[24, 15]),
+    "deepseek_v2_lite_mha_yarn": dict(H=128, Ht=128, I=168, nh=2, nkv=2, hd=64, Vt=512, Vd=128, B=1, S=40, ttt=3, lengths=[37],
+                                      rope_scaling=dict(rope_type="yarn", factor=4.0, beta_fast=32, beta_slow=1, mscale=1.0, mscale_all_dim=0.5,
+                                                        original_max_position_embeddings=32)),
+    "qwen2.5_7b_seven_heads_per_group": dict(H=192, Ht=192, I=256, nh=7, nkv=1, hd=64, Vt=512, Vd=128, B=2, S=32, ttt=4, lengths=[32, 19]),
+    "gpt_oss_h_not_multiple_of_128": dict(H=192, Ht=192, I=320, nh=4, nkv=2, hd=64, Vt=640, Vd=192, B=2, S=20, ttt=3, lengths=[20, 11]),
+    "gemma3_head_dim_256": dict(H=128, Ht=128, I=192, nh=2, nkv=1, hd=256, Vt=384, Vd=128, B=1, S=36, ttt=3, lengths=[33]),
+}
+
+
+@pytest.mark.parametrize("name", list(ODD))
+def test_odd_dimension_relations_match_oracle(backend, name):
+    c = ODD[name]
+    kw = dict(hidden_size=c["H"], intermediate_size=c["I"], num_attention_heads=c["nh"], num_key_value_heads=c["nkv"],
+              vocab_size=c["Vt"], draft_vocab_size=c["Vd"], head_dim=c["hd"], target_hidden_size=c["Ht"],
+              max_position_embeddings=128, rms_norm_eps=1e-6, rope_scaling=c.get("rope_scaling"))
+    oc = O.DraftConfig(**kw)
+    bf = torch.bfloat16
+    params = {k: v.to(bf) for k, v in O.init_params(oc, seed=1).items()}
+    g = torch.Generator().manual_seed(2)
+    for k, v in params.items():
+        if v.dim() == 1:
+            params[k] = (1 + 0.1 * torch.randn(v.shape, generator=g)).to(bf)
+    embed = (torch.randn(c["Vt"], c["H"], generator=g) * 0.05).to(bf)
+    head_w = (torch.randn(c["Vt"], c["Ht"], generator=g) * 0.05).to(bf)
+    if c["Vd"] == c["Vt"]:
+        t2d, d2t = torch.ones(c["Vt"], dtype=torch.bool), torch.zeros(c["Vd"], dtype=torch.int64)
+    else:
+        t2d, d2t = O.make_vocab_mapping(c["Vt"], c["Vd"], seed=3)
+    batch = O.make_batch(oc, c["B"], c["S"], seed=4, dtype=bf, lengths=c["lengths"])
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref = O.eagle3_forward(p, oc, embed_weight=embed, target_head_weight=head_w, t2d=t2d, d2t=d2t, input_ids=batch["input_ids"],
+                           attention_mask=batch["attention_mask"], loss_mask=batch["loss_mask"], hidden_state=batch["hidden_state"],
+                           target_hidden=batch["target"], ttt_length=c["ttt"])
+    ref.loss.backward()
+    model = LlamaForCausalLMEagle3(DraftConfig(**kw), device=backend)
+    sd = dict(params)
+    sd["embed_tokens.weight"], sd["t2d"], sd["d2t"] = embed, t2d, d2t
+    model.load_state_dict(sd)
+    eagle = OnlineEagle3Model(model, length=c["ttt"]).train()
+    strat = Eagle3TrainStrategy(eagle, target_head=TargetHead(head_w.to(backend)))
+    out = strat.forward_loss(TrainBatch(dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], loss_mask=batch["loss_mask"],
+                                             hidden_state=batch["hidden_state"].to(backend), target=batch["target"].to(backend)),
+                                        {"target_repr": "hidden_state"}))
+    out.loss.backward()
+    ids = eagle.last_artifacts["target_token_ids"].cpu()
+    assert float((ids == ref.target_token_ids).float().mean()) >= 0.995         # (CPU bf16 GEMM on the other side: exact ties may flip)
+    torch.testing.assert_close(torch.stack(out.metrics["plosses"]).float().cpu(), torch.stack([x.detach().float() for x in ref.plosses]),
+                               rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(torch.stack(out.metrics["acc_denoms"]).cpu(), torch.stack(ref.acc_denoms).float())
+    named = dict(model.named_parameters())
+    worst = {k: float((named[k].grad.float().cpu() - v.grad.float()).abs().max()) / float(v.grad.float().abs().max().clamp_min(1e-8))
+             for k, v in p.items()}
+    assert max(worst.values()) <= 6e-2, worst
+
+
 # ------------------------------------------------------------------ the other configs at their REAL dimensions
 REAL = {
     # configs/qwen3-8b-eagle3.json
