@@ -322,3 +322,58 @@ def uninstall() -> None:
 
 
 uninstall_backend = uninstall
+
+
+def main(argv=None) -> int:
+    """``python -m specforge_amd.reference_plugin train -c run.yaml [--role ...] [--node-rank N] [--plan] [overrides ...]`` --
+    ``specforge train`` (cli.py:167-268) on the HIP path with the SAME run YAML / draft JSON: the reference's own ``load_config``,
+    ``resolve_run`` (handed the catalogue whose ``eagle3`` entry is the HIP registration), ``build_launch_plan`` and ``_train``,
+    with ``install(override=True)`` in every process.  Multi-GPU topologies launch their workers through this module again
+    (``worker_prefix`` / ``torchrun_prefix`` of ``build_launch_plan``, launch_plan.py:646-768), so each rank of
+    ``torch.distributed.run`` installs the plugin before it builds its trainer.  Every other sub-command (``export``,
+    ``benchmark``) is the reference's, untouched."""
+    import argparse
+    import os
+    import sys
+
+    from specforge import cli
+
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv or argv[0] != "train":
+        return cli.main(argv)
+    ap = argparse.ArgumentParser(prog="python -m specforge_amd.reference_plugin train")
+    ap.add_argument("-c", "--config", required=True)
+    ap.add_argument("--role", choices=("auto", "all", "producer", "consumer", "both"), default="auto")
+    ap.add_argument("--node-rank", type=int, default=None)
+    ap.add_argument("--plan", action="store_true")
+    ap.add_argument("overrides", nargs="*")
+    args = ap.parse_args(argv[1:])
+
+    from specforge.application import bind_run, resolve_run
+    from specforge.config import load_config
+    from specforge.launch_plan import build_launch_plan, run_commands
+
+    install(override=True)
+    cfg = load_config(args.config, args.overrides)
+    resolved = resolve_run(cfg, registry=registry(override=True))
+    me = (sys.executable, "-m", "specforge_amd.reference_plugin")
+    plan = build_launch_plan(resolved.config, algorithm=resolved.algorithm, config_path=args.config, overrides=args.overrides,
+                             requested_role=args.role, node_rank=args.node_rank, worker_prefix=me,
+                             torchrun_prefix=(sys.executable, "-m", "torch.distributed.run", "--no-python"))
+    if args.plan:
+        print(plan.render())
+        return 0
+    if plan.kind == "worker":
+        os.environ.update(plan.worker_env)
+        role_config = cli._config_for_role(resolved.config, plan.role)
+        try:
+            with cli._worker_signal_unwind():
+                cli._train(bind_run(role_config, resolved.algorithm))
+        except cli._WorkerTermination as received:
+            return 128 + received.signum
+        return 0
+    return run_commands(plan)
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -447,3 +447,58 @@ def test_reference_optimizer_with_weight_decay_skips_the_gradless_norm(ref, gold
     st = backend.optimizer.state_dict()["optimizer_state_dict"]["state"]
     trainable = [k for k, v in named.items() if v.requires_grad]
     assert trainable.index("norm.weight") not in st                            # no Adam state for the grad-less parameter
+
+
+def test_drop_in_cli_entry_runs_specforge_train_on_the_hip_path(ref, golden_dir, tmp_path, capsys):
+    """``python -m specforge_amd.reference_plugin train -c run.yaml`` = ``specforge train`` (cli.py:167-268) with the plugin installed in
+    every process: the single-process plan trains through ``cli._train`` (the reference's own application / Trainer / checkpoint
+    code, HIP model + step + backend + optimizer + loader); a 2-GPU topology renders a ``torch.distributed.run`` command whose
+    workers are this module again (so each rank installs the plugin), not ``specforge.cli``."""
+    import yaml
+
+    blob = torch.load(os.path.join(golden_dir, "loss_curve_tiny.pt"), weights_only=False)
+    work = str(tmp_path)
+    dj, feat, td, vp = _write_run_dir(work, blob, "LlamaForCausalLMEagle3")
+
+    def run_yaml(nproc, name):
+        run = dict(model=dict(target_model_path=td, draft_model_config=dj, embedding_key="model.embed_tokens.weight",
+                              vocab_mapping_path=vp, torch_dtype="bfloat16"),
+                   data=dict(hidden_states_path=feat, max_length=24),
+                   training=dict(strategy="eagle3", num_epochs=1, batch_size=2, learning_rate=1e-3, max_grad_norm=0.5, ttt_length=3,
+                                 attention_backend="sdpa", save_interval=0, log_interval=1, dist_timeout=5, seed=0, max_steps=2),
+                   run_id=name, output_dir=os.path.join(work, "out-" + name),
+                   deployment=dict(mode="local_colocated", trainer=dict(nnodes=1, nproc_per_node=nproc)))
+        yp = os.path.join(work, name + ".yaml")
+        yaml.safe_dump(run, open(yp, "w"))
+        return yp
+
+    import torch.distributed as dist
+
+    if dist.is_initialized():          # cli._train owns init / destroy of the process group
+        dist.destroy_process_group()
+    saved = {k: os.environ.pop(k, None) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        assert ref.main(["train", "-c", run_yaml(1, "hipmain")]) == 0
+        state = torch.load(os.path.join(work, "out-hipmain", "hipmain-latest", "training_state.pt"), weights_only=False)
+        assert state["strategy"] == "eagle3" and state["global_step"] == 2
+        capsys.readouterr()
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):     # (the one-process run bootstrapped them, cli.py:81-106)
+            os.environ.pop(k, None)
+        assert ref.main(["train", "-c", run_yaml(2, "hipplan"), "--plan"]) == 0
+        plan = json.loads(capsys.readouterr().out)
+        assert plan["kind"] == "command" and len(plan["commands"]) == 1
+        argv = plan["commands"][0]["argv"]
+        i = argv.index("torch.distributed.run")
+        assert argv[i + 1] == "--no-python" and argv[argv.index("--nproc_per_node") + 1] == "2"
+        j = argv.index("specforge_amd.reference_plugin")
+        assert argv[j - 1] == "-m" and argv[j + 1:j + 4] == ["train", "--config", os.path.join(work, "hipplan.yaml")]
+        assert "specforge.cli" not in argv
+    finally:
+        ref.uninstall()
+        for k, v in saved.items():
+            if v is not None:
+                os.environ[k] = v
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            if saved[k] is None:
+                os.environ.pop(k, None)
+        RH.init_single_rank(29587)
