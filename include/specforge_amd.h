@@ -162,7 +162,9 @@ int sf_rmsnorm_fwd(const void* x, int dtype, long ldx, const long long* ids_pad,
 int sf_rmsnorm_fwd2(const void* x, int dtype, long ldx, const void* w1, void* y1, long ldy1, float* rstd1, const void* w2, void* y2,
                     long ldy2, float* rstd2, float eps, int rows, int H, void* stream);
 long sf_rmsnorm_bwd_workspace_floats(int rows, int H);
-/* dx (optional) = add (optional) + d/dx; dw_acc[H] (optional, fp32) = or += d/dw. */
+/* dx (optional) = add (optional) + d/dx; dw_acc[H] (optional, fp32) = or += d/dw.
+ * dw_accumulate == 2 (ABI 5, here and in sf_rmsnorm_bwd2): only the per-block partials are written -- workspace[nb, H] with
+ * nb = sf_rmsnorm_bwd_workspace_floats(rows, H) / H -- and the column sum is the caller's (sf_colsum_accum, any stream, any time). */
 int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* x, long ldx, const long long* ids_pad, int S,
                    int Spad, int off, const void* w, const float* rstd, int rows, int H, const void* add,
                    long ldadd, void* dx, long lddx, float* dw_acc, int dw_accumulate, float* workspace,
@@ -175,6 +177,10 @@ int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* x, long ldx
 int sf_rmsnorm_bwd2(const void* dy1, long lddy1, const void* w1, float* dw1_acc, int dw1_accumulate, const void* dy2, long lddy2,
                     const void* w2, float* dw2_acc, int dw2_accumulate, int dtype, const void* x, long ldx, const float* rstd, int rows,
                     int H, const void* add, long ldadd, void* dx, long lddx, float* workspace, void* stream);
+
+/* acc[H] (= or +=) the column sums of partial[nb, H] in a fixed order (deterministic) -- the second half of a norm backward's weight
+ * gradient when it ran with dw_accumulate == 2 (ABI 5). */
+int sf_colsum_accum(const float* partial, int nb, int H, float* acc, int accumulate, void* stream);
 
 /* ---- RoPE in place on `nheads` consecutive heads (llama3_eagle.py:133-142; positions
  * position_ids + pos_off as in 718-734); backward = transposed rotation. */

@@ -513,19 +513,29 @@ extern "C" int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* 
                               float* workspace, void* stream) {
     SF_CHECK_ARG(rows >= 0 && H > 0 && H % 8 == 0 && H <= 256 * 8 * kNormVecs, "sf_rmsnorm_bwd: H must be a multiple of 8, <= 8192");
     SF_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && ldadd % 8 == 0, "sf_rmsnorm_bwd: strides");
-    SF_CHECK_ARG(!dw_acc || workspace, "sf_rmsnorm_bwd: workspace required for dw");
+    const bool partial_only = dw_accumulate == 2;
+    SF_CHECK_ARG((!dw_acc && !partial_only) || workspace, "sf_rmsnorm_bwd: workspace required for dw");
     if (rows == 0) return 0;
     const int rpb = 16, nb = (rows + rpb - 1) / rpb;
 #define SF_NORM_BWD(NV)                                                                                                    \
     SF_DISPATCH_T(dtype, SF_LAUNCH((rmsnorm_bwd_kernel<T, NV>), dim3(nb), dim3(256), 0, stream, (const T*)dy, lddy, (const T*)x, \
                                    ldx, ids_pad, S, Spad, off, (const T*)w, rstd, H, rows, rpb, (const T*)add, ldadd,      \
-                                   (T*)dx, lddx, dw_acc ? workspace : (float*)nullptr))
+                                   (T*)dx, lddx, (dw_acc || partial_only) ? workspace : (float*)nullptr))
     if (H <= 2048) { SF_NORM_BWD(1); } else if (H <= 4096) { SF_NORM_BWD(2); } else { SF_NORM_BWD(kNormVecs); }
 #undef SF_NORM_BWD
-    if (dw_acc)
+    if (dw_acc && !partial_only)
         SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, nb, H, dw_acc,
                   dw_accumulate);
     return sf_check_launch("sf_rmsnorm_bwd");
+}
+
+// The column sum of a norm backward's per-block partials as a call of its own (ABI 5): with dw_accumulate == 2 the two entry points above
+// only WRITE their partials (workspace: sf_rmsnorm_bwd_workspace_floats per weight vector) and the caller reduces them when and where it
+// likes -- the engine does it on a side stream, off the critical path of the sweep (22 launches of ~23 us + a launch gap each per step).
+extern "C" int sf_colsum_accum(const float* partial, int nb, int H, float* acc, int accumulate, void* stream) {
+    SF_CHECK_ARG(partial && acc && nb >= 0 && H > 0, "sf_colsum_accum: bad args");
+    SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, partial, nb, H, acc, accumulate ? 1 : 0);
+    return sf_check_launch("sf_colsum_accum");
 }
 
 extern "C" int sf_rmsnorm_bwd2(const void* dy1, long lddy1, const void* w1, float* dw1_acc, int dw1_accumulate, const void* dy2,
@@ -534,7 +544,8 @@ extern "C" int sf_rmsnorm_bwd2(const void* dy1, long lddy1, const void* w1, floa
                                float* workspace, void* stream) {
     SF_CHECK_ARG(rows >= 0 && H > 0 && H % 8 == 0 && H <= 4096, "sf_rmsnorm_bwd2: H must be a multiple of 8, <= 4096");
     SF_CHECK_ARG(lddy1 % 8 == 0 && lddy2 % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && ldadd % 8 == 0, "sf_rmsnorm_bwd2: strides");
-    SF_CHECK_ARG(dy1 && dy2 && w1 && w2 && x && rstd && dx && dw1_acc && dw2_acc && workspace, "sf_rmsnorm_bwd2: missing argument");
+    SF_CHECK_ARG(dy1 && dy2 && w1 && w2 && x && rstd && dx && (dw1_acc || dw1_accumulate == 2) && (dw2_acc || dw2_accumulate == 2) && workspace,
+                 "sf_rmsnorm_bwd2: missing argument");
     if (rows == 0) return 0;
     const int rpb = 16, nb = (rows + rpb - 1) / rpb;
     float* ws2 = workspace + (long)nb * H;      // (the workspace holds 2 x sf_rmsnorm_bwd_workspace_floats(rows, H))
@@ -544,8 +555,10 @@ extern "C" int sf_rmsnorm_bwd2(const void* dy1, long lddy1, const void* w1, floa
                                    (T*)dx, lddx, workspace, ws2))
     if (H <= 2048) { SF_NORM_BWD2(1); } else { SF_NORM_BWD2(2); }
 #undef SF_NORM_BWD2
-    SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, nb, H, dw1_acc, dw1_accumulate);
-    SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)ws2, nb, H, dw2_acc, dw2_accumulate);
+    if (dw1_accumulate != 2)
+        SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, nb, H, dw1_acc, dw1_accumulate);
+    if (dw2_accumulate != 2)
+        SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)ws2, nb, H, dw2_acc, dw2_accumulate);
     return sf_check_launch("sf_rmsnorm_bwd2");
 }
 

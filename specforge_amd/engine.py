@@ -89,6 +89,9 @@ class Eagle3Engine:
         self.T = int(ttt_length)
         self._diag_plan = diag_plan(self.T)      # launches of the blocked diagonal-branch backward, per sweep step
         self.blocked_diag = True                 # False (A/B, bench.py --diag-per-step): one sf_attn_bwd_pre per step, every pair at its step
+        self.side_colsum = True                  # False (A/B, bench.py --inline-colsum): the norm weights' column sums on the launch stream
+        self._side = None                        # side stream + event pool of the column sums
+        self._side_events = []
         if not 1 <= self.T <= ops.MAX_DIAG + 1:
             raise ValueError(f"ttt_length must be in 1..{ops.MAX_DIAG + 1} (one diagonal branch per earlier TTT step)")
         self.decay = float(ploss_decay)
@@ -311,6 +314,9 @@ class Eagle3Engine:
             b["cos_rows"] = [cv(f"cos_rows_{k}", N, hd) for k in range(T)]
             b["sin_rows"] = [cv(f"sin_rows_{k}", N, hd) for k in range(T)]
         b["nws"] = cv("nws", 2 * ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)   # (x 2: sf_rmsnorm_bwd2)
+        # one partial buffer per norm backward of a micro-step: their column sums run on a side stream (backward(): side_colsum)
+        b["nws_slots"] = ([cv(f"nws_slot_{i}", b["nws"].numel(), dtype=f32) for i in range(3 * T + 4)]
+                          if self.dev.type == "cuda" else None)
         b["nws_e"] = cv("nws_e", ops.rmsnorm_bwd_workspace(Np, H), dtype=f32)
         # fp32 partials for the 2-way split-K of weight-gradient GEMMs whose tile count fills the CUs badly (down, q|k|v)
         # (+ 4096 floats at the tail: pace-keeping counters of sf_gemm_tn)
@@ -667,6 +673,48 @@ class Eagle3Engine:
             first[name] = False
             return nm[name], acc
 
+        # The weight gradient of a norm backward ends in a column sum over its per-block partials: 64 workgroups, ~23 us + a launch
+        # gap, 22 times per step, each in the dependency chain of the sweep for no reason -- nothing reads the sums before the
+        # sweep is over.  Every norm backward therefore writes its partials into a buffer of its own and the column sum goes to a
+        # side stream (same order per weight: deterministic); the launch stream joins it before the totals are formed.
+        slots = b["nws_slots"] if (self.side_colsum and b["nws_slots"] is not None) else None
+        if slots is not None and self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        slot_i = [0]
+
+        def colsums_later(parts):    # parts: [(partial tensor, rows, width, acc, accumulate)]
+            i = slot_i[0] - 1
+            while len(self._side_events) <= i:
+                self._side_events.append(torch.cuda.Event())
+            ev = self._side_events[i]
+            ev.record()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                for part, rows, width, acc, a in parts:
+                    ops.colsum_accum(part, ops.rmsnorm_bwd_workspace(rows, width) // width, width, acc, a)
+
+        def norm_bwd(name, dy, x, w, rstd, *, dx, add):
+            acc, a = nacc(name)
+            if slots is None:
+                ops.rmsnorm_bwd(dy, x, w, rstd, dx=dx, add=add, dw_acc=acc, dw_accumulate=a, workspace=ws)
+                return
+            part = slots[slot_i[0]]
+            slot_i[0] += 1
+            ops.rmsnorm_bwd(dy, x, w, rstd, dx=dx, add=add, workspace=part, partial_only=True)
+            colsums_later([(part, dy.shape[0], w.numel(), acc, a)])
+
+        def norm_bwd2(name1, dy1, w1, name2, dy2, w2, x, rstd, *, dx, add):
+            acc1, a1 = nacc(name1)
+            acc2, a2 = nacc(name2)
+            if slots is None:
+                ops.rmsnorm_bwd2(dy1, w1, acc1, a1, dy2, w2, acc2, a2, x, rstd, dx=dx, add=add, workspace=ws)
+                return
+            part = slots[slot_i[0]]
+            slot_i[0] += 1
+            ops.rmsnorm_bwd2(dy1, w1, None, False, dy2, w2, None, False, x, rstd, dx=dx, add=add, workspace=part, partial_only=True)
+            n1 = ops.rmsnorm_bwd_workspace(dy1.shape[0], w1.numel())
+            colsums_later([(part[:n1], dy1.shape[0], w1.numel(), acc1, a1), (part[n1:], dy1.shape[0], w1.numel(), acc2, a2)])
+
         dh_next = None
         # h[k] feeds the final norm of step k - 1 AND the hidden_norm of step k: with the final norm in use (and H <= 4096) the
         # hidden_norm backward of step k is not run at the end of step k but together with the final-norm backward of step k - 1,
@@ -678,15 +726,11 @@ class Eagle3Engine:
             # dh / dgu / dh1 / dqkv are written straight into their slot of the weight-gradient stash.
             dh, dgu, dh1, dqkv = b["dh"][k], b["dgu"][k], b["dh1"][k], b["dqkv"][k]
             if pending is not None:
-                acc1, a1 = nacc("norm.weight")
-                acc2, a2 = nacc("midlayer.hidden_norm.weight")
-                ops.rmsnorm_bwd2(b["dln"][k], f.view("norm.weight"), acc1, a1, pending[0], f.view("midlayer.hidden_norm.weight"), acc2, a2,
-                                 b["h"][k + 1], b["rstd_n"][k], dx=dh, add=pending[1], workspace=ws)
+                norm_bwd2("norm.weight", b["dln"][k], f.view("norm.weight"), "midlayer.hidden_norm.weight", pending[0],
+                          f.view("midlayer.hidden_norm.weight"), b["h"][k + 1], b["rstd_n"][k], dx=dh, add=pending[1])
                 pending = None
             elif c.norm_output:
-                acc, a = nacc("norm.weight")
-                ops.rmsnorm_bwd(b["dln"][k], b["h"][k + 1], f.view("norm.weight"), b["rstd_n"][k], dx=dh, add=dh_next,
-                                dw_acc=acc, dw_accumulate=a, workspace=ws)
+                norm_bwd("norm.weight", b["dln"][k], b["h"][k + 1], f.view("norm.weight"), b["rstd_n"][k], dx=dh, add=dh_next)
             elif dh_next is None:   # lm_head reads the un-normed hidden state; `norm` gets no gradient
                 dh.copy_(b["dln"][k])
             else:
@@ -694,9 +738,8 @@ class Eagle3Engine:
             # MLP
             ops.gemm_nt_swiglu_bwd(dh, self.wdT, b["gu"][k], dgu, b["dact"])   # down dgrad + d(SwiGLU) in its epilogue
             ops.gemm_nt(dgu, self.wguT, b["dpn"])
-            acc, a = nacc("midlayer.post_attention_layernorm.weight")
-            ops.rmsnorm_bwd(b["dpn"], b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"), b["rstd_p"][k],
-                            dx=dh1, add=dh, dw_acc=acc, dw_accumulate=a, workspace=ws)
+            norm_bwd("midlayer.post_attention_layernorm.weight", b["dpn"], b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"),
+                     b["rstd_p"][k], dx=dh1, add=dh)
             # attention
             ops.gemm_nt(dh1, self.woT, b["do"][k])
             qkv = b["qkv"][k]
@@ -756,9 +799,8 @@ class Eagle3Engine:
                 pending = (b["dxh"], dh1)      # consumed at the top of step k - 1, before that step rewrites dxh
                 continue
             dh_prev = b["dh_b"][0]
-            acc, a = nacc("midlayer.hidden_norm.weight")
-            ops.rmsnorm_bwd(b["dxh"], b["h"][k], f.view("midlayer.hidden_norm.weight"), b["rstd_h"][k],
-                            dx=dh_prev, add=dh1, dw_acc=acc, dw_accumulate=a, workspace=ws)
+            norm_bwd("midlayer.hidden_norm.weight", b["dxh"], b["h"][k], f.view("midlayer.hidden_norm.weight"), b["rstd_h"][k],
+                     dx=dh_prev, add=dh1)
             dh_next = dh_prev  # consumed (as `add`) by step k-1 before it is rewritten at the end of that step
         dh0 = dh_next
         if N % 64 == 0:
@@ -779,9 +821,8 @@ class Eagle3Engine:
             ops.gemm_nt(dh0, self.wfcT, b["dhs"])
             hs = self._last_hs
             for i in range(3):
-                acc, a = nacc(f"fc_norm.{i}.weight")
-                ops.rmsnorm_bwd(b["dhs"][:, i * Ht:(i + 1) * Ht], hs[:, i * Ht:(i + 1) * Ht], f.view(f"fc_norm.{i}.weight"),
-                                b["rstd_fc"][i], dx=None, dw_acc=acc, dw_accumulate=a, workspace=ws)
+                norm_bwd(f"fc_norm.{i}.weight", b["dhs"][:, i * Ht:(i + 1) * Ht], hs[:, i * Ht:(i + 1) * Ht], f.view(f"fc_norm.{i}.weight"),
+                         b["rstd_fc"][i], dx=None, add=None)
 
         # ---- deferred weight gradients: dW = dY^T . X over all T*N token rows of the natural-layout stashes
         # (sf_gemm_tn), bf16 straight into flat.grad in all-reduce bucket order
@@ -806,6 +847,8 @@ class Eagle3Engine:
             if self.on_bucket_ready is not None:
                 self.on_bucket_ready(f.slices[first_name][0], f.slices[last_name][1])
         # norm weights: fp32 running total over the window, then one cast into the flat gradient
+        if slots is not None:
+            torch.cuda.current_stream().wait_stream(self._side)     # (the column sums of this micro-step)
         lo = f.slices[self._norm_names[0]][0]
         for n in self._norm_names:
             ops.axpy_f32(g, nm[n], self._norm_total[n], accumulate=self.micro_in_window > 0)

@@ -222,24 +222,34 @@ def rmsnorm_bwd_workspace(rows: int, H: int) -> int:
 
 
 def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, rstd: torch.Tensor, *, dx=None, add=None, dw_acc=None,
-                dw_accumulate: bool = True, workspace=None, ids_pad=None, S: int = 1, Spad: int = 1, off: int = 0):
+                dw_accumulate: bool = True, workspace=None, ids_pad=None, S: int = 1, Spad: int = 1, off: int = 0, partial_only: bool = False):
+    """``partial_only``: the weight gradient stops at the per-block partials in ``workspace`` [nb, H]; reduce them with ``colsum_accum``"""
     L = _lib.lib()
     rows, H = dy.shape[0], w.numel()
     _lib.check(L.sf_rmsnorm_bwd(_p(dy), _dt(dy), _rowmajor(dy), _p(x), _rowmajor(x), _p(ids_pad), S, Spad, off, _p(w),
                                 _p(rstd), rows, H, _p(add), _rowmajor(add) if add is not None else 0, _p(dx),
-                                _rowmajor(dx) if dx is not None else 0, _p(dw_acc), 1 if dw_accumulate else 0,
+                                _rowmajor(dx) if dx is not None else 0, _p(dw_acc), 2 if partial_only else (1 if dw_accumulate else 0),
                                 _p(workspace), _stream()), "sf_rmsnorm_bwd")
 
 
+def colsum_accum(partial: torch.Tensor, nb: int, H: int, acc: torch.Tensor, accumulate: bool):
+    """acc[H] (= / +=) column sums of partial[nb, H] (fixed order); runs on the CURRENT stream"""
+    L = _lib.lib()
+    assert partial.dtype == torch.float32 and acc.dtype == torch.float32 and partial.numel() >= nb * H and acc.numel() >= H
+    _lib.check(L.sf_colsum_accum(_p(partial), nb, H, _p(acc), 1 if accumulate else 0, _stream()), "sf_colsum_accum")
+
+
 def rmsnorm_bwd2(dy1: torch.Tensor, w1: torch.Tensor, dw1_acc: torch.Tensor, dw1_accumulate: bool, dy2: torch.Tensor, w2: torch.Tensor,
-                 dw2_acc: torch.Tensor, dw2_accumulate: bool, x: torch.Tensor, rstd: torch.Tensor, *, dx: torch.Tensor, add=None, workspace):
+                 dw2_acc: torch.Tensor, dw2_accumulate: bool, x: torch.Tensor, rstd: torch.Tensor, *, dx: torch.Tensor, add=None, workspace,
+                 partial_only: bool = False):
     """dx = d_norm(dy1; w1) + d_norm(dy2; w2) (+ add) for two RMSNorms of the same rows x; dw*_acc (+)= their weight gradients.
     workspace: >= 2 * rmsnorm_bwd_workspace(rows, H) floats."""
     L = _lib.lib()
     rows, H = dy1.shape[0], w1.numel()
     assert dy2.shape[0] == rows and w2.numel() == H and workspace.numel() >= 2 * rmsnorm_bwd_workspace(rows, H)
-    _lib.check(L.sf_rmsnorm_bwd2(_p(dy1), _rowmajor(dy1), _p(w1), _p(dw1_acc), 1 if dw1_accumulate else 0, _p(dy2), _rowmajor(dy2), _p(w2),
-                                 _p(dw2_acc), 1 if dw2_accumulate else 0, _dt(dy1), _p(x), _rowmajor(x), _p(rstd), rows, H, _p(add),
+    m1, m2 = (2, 2) if partial_only else (1 if dw1_accumulate else 0, 1 if dw2_accumulate else 0)
+    _lib.check(L.sf_rmsnorm_bwd2(_p(dy1), _rowmajor(dy1), _p(w1), _p(dw1_acc), m1, _p(dy2), _rowmajor(dy2), _p(w2),
+                                 _p(dw2_acc), m2, _dt(dy1), _p(x), _rowmajor(x), _p(rstd), rows, H, _p(add),
                                  _rowmajor(add) if add is not None else 0, _p(dx), _rowmajor(dx), _p(workspace), _stream()),
                "sf_rmsnorm_bwd2")
 

@@ -363,6 +363,40 @@ def test_rmsnorm_bwd2_equals_the_sum_of_two_backwards(backend, dtype, tol, R, H)
     torch.testing.assert_close((dw1 - 0.5).cpu(), a1.cpu(), rtol=1e-4, atol=1e-4 * float(a1.abs().max()))
 
 
+@pytest.mark.parametrize("R,H", [(20, 128), (70, 4096)])
+def test_rmsnorm_bwd_partials_then_colsum_equals_the_fused_call(backend, R, H):
+    """dw_accumulate == 2 (ABI 5): the norm backwards stop at their per-block partials and sf_colsum_accum finishes the weight gradient
+    (the engine runs it on a side stream) -- dx and dw bit-identical to the one-call form, = and += alike, for both entry points"""
+    dt = torch.bfloat16
+    x, dy1, dy2, add = (_rand((R, H), dt, i).to(backend) for i in (1, 2, 3, 4))
+    w1 = (1 + 0.1 * _rand((H,), torch.float32, 5)).to(dt).to(backend)
+    w2 = (1 + 0.1 * _rand((H,), torch.float32, 6)).to(dt).to(backend)
+    rstd = torch.empty(R, device=backend)
+    ops.rmsnorm_fwd(x, w1, 1e-5, torch.empty((R, H), dtype=dt, device=backend), rstd)
+    n1 = ops.rmsnorm_bwd_workspace(R, H)
+    nb = n1 // H
+    for acc in (False, True):
+        ws = torch.empty(2 * n1, device=backend)
+        dxa, dwa = torch.empty((R, H), dtype=dt, device=backend), torch.full((H,), 0.25, device=backend)
+        ops.rmsnorm_bwd(dy1, x, w1, rstd, dx=dxa, add=add, dw_acc=dwa, dw_accumulate=acc, workspace=ws)
+        part = torch.full((2 * n1,), float("nan"), device=backend)
+        dxb, dwb = torch.empty((R, H), dtype=dt, device=backend), torch.full((H,), 0.25, device=backend)
+        ops.rmsnorm_bwd(dy1, x, w1, rstd, dx=dxb, add=add, workspace=part, partial_only=True)
+        ops.colsum_accum(part, nb, H, dwb, acc)
+        assert torch.equal(dxa.cpu(), dxb.cpu()) and torch.equal(dwa.cpu(), dwb.cpu())
+        # the paired form
+        dxc = torch.empty((R, H), dtype=dt, device=backend)
+        c1, c2 = torch.full((H,), 0.25, device=backend), torch.full((H,), -1.0, device=backend)
+        ops.rmsnorm_bwd2(dy1, w1, c1, acc, dy2, w2, c2, acc, x, rstd, dx=dxc, add=add, workspace=ws)
+        part = torch.full((2 * n1,), float("nan"), device=backend)
+        dxd = torch.empty((R, H), dtype=dt, device=backend)
+        d1, d2 = torch.full((H,), 0.25, device=backend), torch.full((H,), -1.0, device=backend)
+        ops.rmsnorm_bwd2(dy1, w1, None, False, dy2, w2, None, False, x, rstd, dx=dxd, add=add, workspace=part, partial_only=True)
+        ops.colsum_accum(part[:n1], nb, H, d1, acc)
+        ops.colsum_accum(part[n1:], nb, H, d2, acc)
+        assert torch.equal(dxc.cpu(), dxd.cpu()) and torch.equal(c1.cpu(), d1.cpu()) and torch.equal(c2.cpu(), d2.cpu())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("R,H", [(20, 128), (19, 4096)])
 def test_rmsnorm_fwd2_equals_two_norms(backend, dtype, R, H):
