@@ -89,7 +89,10 @@ class Eagle3Engine:
         self.T = int(ttt_length)
         self._diag_plan = diag_plan(self.T)      # launches of the blocked diagonal-branch backward, per sweep step
         self.blocked_diag = True                 # False (A/B, bench.py --diag-per-step): one sf_attn_bwd_pre per step, every pair at its step
-        self.side_colsum = True                  # False (A/B, bench.py --inline-colsum): the norm weights' column sums on the launch stream
+        # Measured and rejected (round 4, bench.py --side-colsum, profiles/r4_side_colsum_ab.json): the norm weights' column sums on a side
+        # stream.  201.0 / 201.3 ms against 200.9 / 201.1 on the launch stream, same box, alternating -- the persistent GEMMs around them hold
+        # every CU, so a side-stream kernel waits for the same GEMM to end and then delays the next kernel by its own length.
+        self.side_colsum = False
         self._side = None                        # side stream + event pool of the column sums
         self._side_events = []
         if not 1 <= self.T <= ops.MAX_DIAG + 1:
@@ -316,7 +319,7 @@ class Eagle3Engine:
         b["nws"] = cv("nws", 2 * ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)   # (x 2: sf_rmsnorm_bwd2)
         # one partial buffer per norm backward of a micro-step: their column sums run on a side stream (backward(): side_colsum)
         b["nws_slots"] = ([cv(f"nws_slot_{i}", b["nws"].numel(), dtype=f32) for i in range(3 * T + 4)]
-                          if self.dev.type == "cuda" else None)
+                          if (self.dev.type == "cuda" and self.side_colsum) else None)
         b["nws_e"] = cv("nws_e", ops.rmsnorm_bwd_workspace(Np, H), dtype=f32)
         # fp32 partials for the 2-way split-K of weight-gradient GEMMs whose tile count fills the CUs badly (down, q|k|v)
         # (+ 4096 floats at the tail: pace-keeping counters of sf_gemm_tn)
@@ -674,9 +677,9 @@ class Eagle3Engine:
             return nm[name], acc
 
         # The weight gradient of a norm backward ends in a column sum over its per-block partials: 64 workgroups, ~23 us + a launch
-        # gap, 22 times per step, each in the dependency chain of the sweep for no reason -- nothing reads the sums before the
-        # sweep is over.  Every norm backward therefore writes its partials into a buffer of its own and the column sum goes to a
-        # side stream (same order per weight: deterministic); the launch stream joins it before the totals are formed.
+        # gap, 22 times per step, in the dependency chain of the sweep although nothing reads the sums before the sweep is over.
+        # side_colsum (A/B only, see __init__: measured, no gain): every norm backward writes its partials into a buffer of its own
+        # and the column sum goes to a side stream (same order per weight: deterministic), joined before the totals are formed.
         slots = b["nws_slots"] if (self.side_colsum and b["nws_slots"] is not None) else None
         if slots is not None and self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
