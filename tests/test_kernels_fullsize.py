@@ -343,3 +343,52 @@ def test_ce_fused_headline_shape(density):
     torch.testing.assert_close(row_acc, acc, rtol=tol, atol=tol)
     torch.testing.assert_close(x.float(), grad, rtol=tol, atol=tol * float(grad.abs().max()))
     assert float(x.float()[pm == 0].abs().max() if density < 1 else 0.0) == 0.0
+
+
+def test_operands_larger_than_4_gib():
+    """operands whose byte size passes 2^32.  The NT GEMM's LDS-DMA descriptors are rebuilt per 256-row tile from a
+    64-bit base (only offsets inside a tile are 32-bit; sf_gemm_nt refuses a tile span >= 2 GiB), the fused CE addresses rows with
+    64-bit arithmetic: an A operand of 4.7 GB (163 840 x 14 336 bf16) and a logits matrix of 4.6 GB (72 000 x 32 000 bf16) give the
+    same results in their LAST rows -- past the 4 GiB mark -- as torch computes there."""
+    M, K, N = 163840, 14336, 512
+    a = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    assert a.numel() * 2 > (1 << 32)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for m0 in range(0, M, 16384):
+        a[m0:m0 + 16384] = torch.randn(16384, K, device=DEV, generator=g).to(torch.bfloat16)
+    b = _randn((N, K), 4)
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a, b, c)
+    for m0 in (0, 81920, M - 4096):                    # first rows, the rows around the 2 GiB mark, the last rows (> 4 GiB)
+        ref = a[m0:m0 + 4096].float() @ b.float().t()
+        _check(c[m0:m0 + 4096], ref, K, torch.bfloat16, f"nt A > 4 GiB rows {m0}")
+    del a, c
+    torch.cuda.empty_cache()
+    # fused CE: rows x V x 2 bytes > 4 GiB; the last rows against an fp32 reference
+    B, S, V, T = 36, 2000, 32000, 7
+    Spad, Nr = S + T, B * S
+    logits = torch.empty(Nr, V, dtype=torch.bfloat16, device=DEV)
+    assert logits.numel() * 2 > (1 << 32)
+    for r0 in range(0, Nr, 8000):
+        logits[r0:r0 + 8000] = (torch.randn(8000, V, device=DEV, generator=g) * 2).to(torch.bfloat16)
+    keep = logits[-S:].clone()                         # the last sample's rows (the kernel writes the gradient in place)
+    target_pad = torch.zeros(B, Spad, V, device=DEV)
+    target_pad[-1, :S] = torch.softmax(torch.randn(S, V, device=DEV, generator=g) * 3, -1)
+    pos_pad = torch.zeros(B, Spad, dtype=torch.int32, device=DEV)
+    pos_pad[-1, :S] = 1
+    lm_pad = torch.ones(B, Spad, dtype=torch.int32, device=DEV)
+    rl, acc, cor = (torch.zeros(Nr, device=DEV) for _ in range(3))
+    gs = 1.0 / Nr
+    tsum_pad = target_pad.sum(-1)
+    pod_pad = torch.ones(B, Spad, device=DEV)
+    ids_pad = torch.zeros(B, Spad, dtype=torch.int64, device=DEV)
+    d2t = torch.zeros(V, dtype=torch.int64, device=DEV)
+    ops.ce_fused(logits, target_pad, S=S, Spad=Spad, off=0, pos_mask_pad=pos_pad, loss_mask_pad=lm_pad, tgt_ids_pad=ids_pad,
+                 pod_scale_pad=pod_pad, tsum_pad=tsum_pad, d2t=d2t, grad_scale=gs, row_loss=rl, row_correct=cor, row_accept=acc)
+    x = keep.float().requires_grad_(True)
+    want = -(target_pad[-1, :S] * torch.log_softmax(x, -1)).sum(-1)
+    (want.sum() * gs).backward()
+    torch.testing.assert_close(rl[-S:], want.detach(), rtol=1e-4, atol=1e-4)
+    err = float((logits[-S:].float() - x.grad).abs().max() / x.grad.abs().max())
+    assert err < 1e-2, err
+    assert float(rl[:-S].abs().max()) == 0.0           # rows without a position mask carry no loss
