@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, GPU call 4: measurement bundle of the (near-)final commit: full GPU suite, bench line (feeds, dense mask, CPU baseline),
+# round 4: measurement bundle of a commit (usage: bash tools/r4_bundle.sh <commit>): full GPU suite, bench line (feeds, dense mask, CPU baseline),
 # rocprofv3 kernel stats of the same command, PMC passes, per-shape GEMM table, attention A/B, smoke
 export TMPDIR=/tmp
 C=$1
