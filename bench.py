@@ -229,8 +229,6 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: all ranks on cuda:0 (with --dist-backend gloo)")
     ap.add_argument("--diag-per-step", action="store_true",
                     help="A/B: the diagonal-branch backward as one sf_attn_bwd_pre per TTT step (round 3) instead of the blocked sf_attn_bwd_diag")
-    ap.add_argument("--side-colsum", action="store_true",
-                    help="A/B (measured, no gain: profiles/r4_side_colsum_ab.json): the norm weights' column sums on a side stream")
     ap.add_argument("--materialise-targets", action="store_true",
                     help="A/B: write the fp32 soft targets [B, S+T, Vd] instead of re-forming them in the fused CE from the teacher's draft logits")
     args = ap.parse_args()
@@ -289,7 +287,6 @@ def main():
     backend.prepare_model(eagle)
     eagle.engine.materialise_soft_targets = args.materialise_targets
     eagle.engine.blocked_diag = not args.diag_per_step
-    eagle.engine.side_colsum = args.side_colsum
     batches = [TrainBatch(make_batch(cfg, B, S, dev, 100 + rank * 10 + i), {"target_repr": "hidden_state"}) for i in range(2)]
 
     # ---- where a step's batch comes from (--feed).  hbm: resident (the metric).  The others are what a

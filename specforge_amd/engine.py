@@ -89,12 +89,6 @@ class Eagle3Engine:
         self.T = int(ttt_length)
         self._diag_plan = diag_plan(self.T)      # launches of the blocked diagonal-branch backward, per sweep step
         self.blocked_diag = True                 # False (A/B, bench.py --diag-per-step): one sf_attn_bwd_pre per step, every pair at its step
-        # Measured and rejected (round 4, bench.py --side-colsum, profiles/r4_side_colsum_ab.json): the norm weights' column sums on a side
-        # stream.  201.0 / 201.3 ms against 200.9 / 201.1 on the launch stream, same box, alternating -- the persistent GEMMs around them hold
-        # every CU, so a side-stream kernel waits for the same GEMM to end and then delays the next kernel by its own length.
-        self.side_colsum = False
-        self._side = None                        # side stream + event pool of the column sums
-        self._side_events = []
         if not 1 <= self.T <= ops.MAX_DIAG + 1:
             raise ValueError(f"ttt_length must be in 1..{ops.MAX_DIAG + 1} (one diagonal branch per earlier TTT step)")
         self.decay = float(ploss_decay)
@@ -317,9 +311,6 @@ class Eagle3Engine:
             b["cos_rows"] = [cv(f"cos_rows_{k}", N, hd) for k in range(T)]
             b["sin_rows"] = [cv(f"sin_rows_{k}", N, hd) for k in range(T)]
         b["nws"] = cv("nws", 2 * ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)   # (x 2: sf_rmsnorm_bwd2)
-        # one partial buffer per norm backward of a micro-step: their column sums run on a side stream (backward(): side_colsum)
-        b["nws_slots"] = ([cv(f"nws_slot_{i}", b["nws"].numel(), dtype=f32) for i in range(3 * T + 4)]
-                          if (self.dev.type == "cuda" and self.side_colsum) else None)
         b["nws_e"] = cv("nws_e", ops.rmsnorm_bwd_workspace(Np, H), dtype=f32)
         # fp32 partials for the 2-way split-K of weight-gradient GEMMs whose tile count fills the CUs badly (down, q|k|v)
         # (+ 4096 floats at the tail: pace-keeping counters of sf_gemm_tn)
@@ -676,47 +667,14 @@ class Eagle3Engine:
             first[name] = False
             return nm[name], acc
 
-        # The weight gradient of a norm backward ends in a column sum over its per-block partials: 64 workgroups, ~23 us + a launch
-        # gap, 22 times per step, in the dependency chain of the sweep although nothing reads the sums before the sweep is over.
-        # side_colsum (A/B only, see __init__: measured, no gain): every norm backward writes its partials into a buffer of its own
-        # and the column sum goes to a side stream (same order per weight: deterministic), joined before the totals are formed.
-        slots = b["nws_slots"] if (self.side_colsum and b["nws_slots"] is not None) else None
-        if slots is not None and self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
-        slot_i = [0]
-
-        def colsums_later(parts):    # parts: [(partial tensor, rows, width, acc, accumulate)]
-            i = slot_i[0] - 1
-            while len(self._side_events) <= i:
-                self._side_events.append(torch.cuda.Event())
-            ev = self._side_events[i]
-            ev.record()
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(ev)
-                for part, rows, width, acc, a in parts:
-                    ops.colsum_accum(part, ops.rmsnorm_bwd_workspace(rows, width) // width, width, acc, a)
-
         def norm_bwd(name, dy, x, w, rstd, *, dx, add):
             acc, a = nacc(name)
-            if slots is None:
-                ops.rmsnorm_bwd(dy, x, w, rstd, dx=dx, add=add, dw_acc=acc, dw_accumulate=a, workspace=ws)
-                return
-            part = slots[slot_i[0]]
-            slot_i[0] += 1
-            ops.rmsnorm_bwd(dy, x, w, rstd, dx=dx, add=add, workspace=part, partial_only=True)
-            colsums_later([(part, dy.shape[0], w.numel(), acc, a)])
+            ops.rmsnorm_bwd(dy, x, w, rstd, dx=dx, add=add, dw_acc=acc, dw_accumulate=a, workspace=ws)
 
         def norm_bwd2(name1, dy1, w1, name2, dy2, w2, x, rstd, *, dx, add):
             acc1, a1 = nacc(name1)
             acc2, a2 = nacc(name2)
-            if slots is None:
-                ops.rmsnorm_bwd2(dy1, w1, acc1, a1, dy2, w2, acc2, a2, x, rstd, dx=dx, add=add, workspace=ws)
-                return
-            part = slots[slot_i[0]]
-            slot_i[0] += 1
-            ops.rmsnorm_bwd2(dy1, w1, None, False, dy2, w2, None, False, x, rstd, dx=dx, add=add, workspace=part, partial_only=True)
-            n1 = ops.rmsnorm_bwd_workspace(dy1.shape[0], w1.numel())
-            colsums_later([(part[:n1], dy1.shape[0], w1.numel(), acc1, a1), (part[n1:], dy1.shape[0], w1.numel(), acc2, a2)])
+            ops.rmsnorm_bwd2(dy1, w1, acc1, a1, dy2, w2, acc2, a2, x, rstd, dx=dx, add=add, workspace=ws)
 
         dh_next = None
         # h[k] feeds the final norm of step k - 1 AND the hidden_norm of step k: with the final norm in use (and H <= 4096) the
@@ -850,8 +808,6 @@ class Eagle3Engine:
             if self.on_bucket_ready is not None:
                 self.on_bucket_ready(f.slices[first_name][0], f.slices[last_name][1])
         # norm weights: fp32 running total over the window, then one cast into the flat gradient
-        if slots is not None:
-            torch.cuda.current_stream().wait_stream(self._side)     # (the column sums of this micro-step)
         lo = f.slices[self._norm_names[0]][0]
         for n in self._norm_names:
             ops.axpy_f32(g, nm[n], self._norm_total[n], accumulate=self.micro_in_window > 0)

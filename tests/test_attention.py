@@ -226,3 +226,46 @@ def test_blocked_diagonal_backward_follows_the_plan(backend, hd, T):
                 assert err <= 3e-2 * float(ref.abs().max()) + 1e-6, (what, s, err)
     if T == 7:
         assert nlaunch == 7 and [len(L["stream"]) for s in (6, 5, 4, 3) for L in plan[s]] == [0, 0, 2, 0]
+
+
+def test_diag_plan_covers_every_pair_once_within_its_window():
+    """engine.diag_plan for every ttt_length the engine accepts (1 .. 33): each pair (step k, branch i <= k) adds to the branch's
+    sums exactly once, at a sweep step in [i, k] (dK_i / dV_i are final at sweep step i, q_k / dO_k exist from sweep step k on);
+    the first launch touching a branch is first-touch and no later one is; the branch turns final exactly once, at sweep step i, in
+    the LAST launch that touches it; dq of every step reads each of its branches exactly once (first launch writes, later ones
+    accumulate); kernel limits (branches read / accumulating / steps streamed per launch) hold."""
+    from specforge_amd.engine import diag_plan
+
+    for T in range(1, ops.MAX_DIAG + 2):
+        plan = diag_plan(T)
+        assert sorted(plan) == list(range(T))
+        pairs, touched, final_at = {}, set(), {}
+        for s in range(T - 1, -1, -1):                      # the sweep order
+            seen_reads = []
+            for li, L in enumerate(plan[s]):
+                rd, na = L["read"], L["nacc"]
+                assert len(rd) <= ops.DIAG_READ and na <= min(ops.DIAG_ACC, len(rd)) and len(L["stream"]) <= ops.DIAG_X
+                assert len(L["first"]) == len(L["final"]) == na and all(1 <= i <= s for i in rd)
+                if L["own"]:
+                    seen_reads += rd
+                    assert L["dq_accumulate"] == (li > 0 and any(M["own"] for M in plan[s][:li]))
+                else:
+                    assert L["stream"] and not L["dq_accumulate"]
+                steps = ([s] if L["own"] else []) + list(L["stream"])
+                assert all(s < x < T for x in L["stream"])
+                for j in range(na):
+                    i = rd[j]
+                    assert i not in final_at, (T, s, i, "touched after it went final")
+                    assert L["first"][j] == (i not in touched), (T, s, i)
+                    touched.add(i)
+                    for k in steps:
+                        assert i <= s <= k and (k, i) not in pairs, (T, k, i, s)
+                        pairs[(k, i)] = s
+                    if L["final"][j]:
+                        assert s == i
+                        final_at[i] = (s, li)
+            assert sorted(seen_reads) == list(range(1, s + 1)), (T, s, seen_reads)      # dq of step s: every branch once
+        assert set(pairs) == {(k, i) for k in range(1, T) for i in range(1, k + 1)}, T
+        assert sorted(final_at) == list(range(1, T))
+        for i, (s, li) in final_at.items():                  # ... and final in the last launch of its step that accumulates it
+            assert not any(i in M["read"][:M["nacc"]] for M in plan[s][li + 1:])
