@@ -44,6 +44,12 @@ const char* sf_last_error(void);
  * projection has been rounded to bf16 (llama3_eagle.py:1641,1650). */
 int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
                int K, float alpha, float beta, const void* R, long ldr, void* stream);
+/* sf_gemm_nt(alpha 1, beta 0) with an fp32 workspace (ABI 5): when the grid is under-filled -- at most half as many 256 x 256 tiles as CUs,
+ * whole tiles, K in 2 or 4 chunks of >= 1024 -- the 4-wave kernel runs tiles x chunks work units (split-K: fp32 partials in `workspace`,
+ * ksplit * M * N floats, fixed-order reduce: deterministic; the residual R joins after the single rounding as in sf_gemm_nt).  Any other
+ * shape, a NULL / too small workspace: sf_gemm_nt.  Same result up to fp32 summation order. */
+int sf_gemm_nt_ws(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N, int K,
+                  const void* R, long ldr, float* workspace, long workspace_floats, void* stream);
 
 /* Weight-gradient form: C[M,N] = alpha * A^T . B (+ beta * C) with A [K, M] and B [K, N] row-major (bf16), i.e.
  * dW = dY^T . X on the tensors exactly as the sweep produced them -- replaces autograd's `grad_output.t() @ input`

@@ -23,6 +23,7 @@ _SIGS = {
     "sf_is_emulated": (c_int, []),
     "sf_last_error": (c_char_p, []),
     "sf_gemm_nt": (c_int, [P, c_long, P, c_long, P, c_int, c_long, c_int, c_int, c_int, c_float, c_float, P, c_long, P]),
+    "sf_gemm_nt_ws": (c_int, [P, c_long, P, c_long, P, c_int, c_long, c_int, c_int, c_int, P, c_long, P, c_long, P]),
     "sf_gemm_tn": (c_int, [P, c_long, P, c_long, P, c_int, c_long, c_int, c_int, c_int, c_float, c_float, P, c_long, c_int, P]),
     "sf_gemm_nt_rowadd": (c_int, [P, c_long, P, c_long, P, c_int, c_long, c_int, c_int, c_int, c_float, P, c_long, c_int,
                                   c_int, c_int, P]),

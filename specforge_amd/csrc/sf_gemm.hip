@@ -205,6 +205,26 @@ static int sf_gemm_check(long lda, long ldb, long ldc, long ldr, int M, int N, i
     return 0;
 }
 
+int sf_gemm_nt_256w4_splitk_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, float* workspace,
+                                   long workspace_floats, void* stream);
+
+// sf_gemm_nt with a workspace (ABI 5): C = A . B^T (+ R after the rounding), alpha 1, beta 0.  Under-filled grids take the split-K form of the
+// 4-wave kernel through `workspace` (>= 4 * M * N floats covers every split; less simply disables it); every other shape is sf_gemm_nt.
+extern "C" int sf_gemm_nt_ws(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N, int K,
+                             const void* R, long ldr, float* workspace, long workspace_floats, void* stream) {
+    if (int st = sf_gemm_check(lda, ldb, ldc, ldr, M, N, K, c_dtype, R)) return st;
+    if (M == 0 || N == 0) return 0;
+    SfGemmEpi e;
+    e.C = C; e.ldc = ldc; e.R = (const sf_bf16*)R; e.ldr = ldr;
+    e.Cadd = nullptr; e.ldadd = 0; e.add_S = 1; e.add_Spad = 1; e.add_off = 0;
+    e.M = M; e.N = N; e.alpha = 1.0f; e.beta = 0.0f;
+    if (sf_gemm_use_256()) {
+        const int st = sf_gemm_nt_256w4_splitk_launch(A, lda, B, ldb, K, e, c_dtype, workspace, workspace_floats, stream);
+        if (st != -1) return st;
+    }
+    return sf_gemm_dispatch(A, lda, B, ldb, K, e, c_dtype, stream);
+}
+
 extern "C" int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
                           int K, float alpha, float beta, const void* R, long ldr, void* stream) {
     if (int st = sf_gemm_check(lda, ldb, ldc, ldr, M, N, K, c_dtype, R)) return st;

@@ -109,3 +109,81 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
 #undef SF_W4_LOCAL
     SF_CHECK_ARG(false, "sf_gemm_nt(256w4): no kernel for this configuration");
 }
+
+// ---- split-K for under-filled grids (round 4) -----------------------------------------------------------------------------------
+// With at most half as many 256 x 256 tiles as CUs -- every N = H GEMM of a bs 1 x 4096 recipe at H = 2048 is 16 x 8 = 128 tiles on 256
+// CUs -- half the chip idles for the whole launch, and the 128 x 128 kernel that fills it runs at 0.85 - 0.99 PFLOP/s where this kernel
+// reaches 1.4.  When the caller provides a workspace, K is cut into 2 (or 4) chunks instead: tiles x chunks work units of the SAME
+// kernel (fp32 plain form, one unit per CU), fp32 partials, and a fixed-order reduce (deterministic) that rounds once and applies the
+// residual like the plain epilogue does.  Returns -1 when the shape does not qualify (the caller dispatches as before).
+namespace {
+template <int OUT_F32>
+SF_GLOBAL void nt_splitk_reduce_kernel(const float* ws, int ksplit, void* C, long ldc, const sf_bf16* R, long ldr, int M, int N) {
+    const long n8 = N / 8, total = (long)M * n8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / n8;
+        const int n = (int)(i - m * n8) * 8;
+        float a[8];
+        SfVec8<float>::ld(ws + m * N + n, a);
+        for (int y = 1; y < ksplit; ++y) {
+            float b[8];
+            SfVec8<float>::ld(ws + (long)y * M * N + m * N + n, b);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a[r] += b[r];
+        }
+        if (OUT_F32) {
+            SfVec8<float>::st((float*)C + m * ldc + n, a);
+        } else {
+            if (R) {      // round the projection first, then add the residual (bf16 + bf16), as sf_gemm_store4 does
+                float rr[8];
+                SfVec8<sf_bf16>::ld(R + m * ldr + n, rr);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) a[r] = sf_round_bf(a[r]) + rr[r];
+            }
+            SfVec8<sf_bf16>::st((sf_bf16*)C + m * ldc + n, a);
+        }
+    }
+}
+}  // namespace
+
+int sf_gemm_nt_256w4_splitk_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype,
+                                   float* workspace, long workspace_floats, void* stream) {
+    const int M = e.M, N = e.N;
+    if (!workspace || ((size_t)workspace & 15) || e.Cadd || e.sw_gu || e.sw_dgu || e.red_part || e.alpha != 1.0f || e.beta != 0.0f) return -1;
+    if (M % TM || N % TN || K % TK || (e.ldc & 7) || ((size_t)e.C & 15) || (e.R && ((e.ldr & 7) || ((size_t)e.R & 15)))) return -1;
+    const long tiles = (long)(M / TM) * (N / TN);
+    const long cus = sf_w4_grid(1L << 30);
+#ifdef SF_EMU
+    const int min_chunk = 2 * TK;          // (interpreter: the multi-unit path at test sizes)
+#else
+    const int min_chunk = 16 * TK;         // a chunk of at least 1024: prologue + epilogue stay a small part of a unit
+#endif
+    int ksplit = 0;
+    for (int c = 4; c >= 2; c >>= 1)
+        if (tiles * c <= cus && K % (c * TK) == 0 && K / c >= min_chunk && workspace_floats >= (long)c * M * N) { ksplit = c; break; }
+    if (!ksplit) return -1;
+    GemmW4Args p;
+    p.A = (const sf_bf16*)A; p.lda = lda;
+    p.B = (const sf_bf16*)B; p.ldb = ldb;
+    p.e = e;
+    p.e.C = workspace; p.e.ldc = N; p.e.R = nullptr; p.e.ldr = 0;
+    p.M = M; p.N = N; p.K = K / ksplit;
+    p.tiles_m = M / TM; p.tiles_n = N / TN;
+    p.gm = 4;
+    p.ksplit = ksplit; p.ks_a = p.K; p.ks_b = p.K; p.ks_c = (long)M * N;
+#ifdef SF_ABLATE
+    p.cyc = 0; p.stagger = 0;
+#endif
+    SF_CHECK_ARG(256L * lda * 2 < (1L << 31) && 256L * ldb * 2 < (1L << 31), "sf_gemm_nt: row stride too large for the 256-tile kernel");
+    const long units = tiles * ksplit;
+    const int sched = N <= 8192 ? 12 : 13;
+    int st = sched == 12 ? sf_w4_launch_1_0_12(p, units, stream) : sf_w4_launch_1_0_13(p, units, stream);
+    if (st) return st;
+    const long work = (long)M * (N / 8);
+    const int rgrid = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
+    if (c_dtype == SF_F32)
+        SF_LAUNCH((nt_splitk_reduce_kernel<1>), dim3(rgrid), dim3(256), 0, stream, (const float*)workspace, ksplit, e.C, e.ldc, e.R, e.ldr, M, N);
+    else
+        SF_LAUNCH((nt_splitk_reduce_kernel<0>), dim3(rgrid), dim3(256), 0, stream, (const float*)workspace, ksplit, e.C, e.ldc, e.R, e.ldr, M, N);
+    return sf_check_launch("sf_gemm_nt(split-K)");
+}

@@ -66,6 +66,10 @@ struct GemmW4Args {
     int M, N, K;
     int tiles_m, tiles_n;
     int gm;
+    // split-K (round 4; fp32 plain form only): work unit u = ks * tiles + tile computes K-range [ks * K, (ks + 1) * K) of the operands
+    // (K here = the chunk length; ks_a / ks_b = element offsets of a chunk in A / B rows) into partial ks of C (ks_c floats apart)
+    int ksplit = 1;
+    long ks_a = 0, ks_b = 0, ks_c = 0;
 #ifdef SF_ABLATE
     int stagger;
     int cyc;   // tools build: wave 0 of every workgroup overwrites C[m0][n0..n0+1] with its K-loop cycle count (fp32 bits)
@@ -234,8 +238,9 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     // first two K-tiles are put in flight BEFORE the epilogue of the finished one: its DMA latency, the per-tile set-up and
     // the workgroup hand-over (~3 us of a ~98 us tile at K = 4096) disappear behind the epilogue's stores.
     const int nblk = p.tiles_m * p.tiles_n;
+    const int nunits = nblk * p.ksplit;           // work units of the walk (= tiles unless split-K)
     int tile = (int)blockIdx.x;
-    int m0 = 0, n0 = 0;
+    int m0 = 0, n0 = 0, ks0 = 0;
     const int nkt = p.K / TK;
 
     // ---- DMA sources: this wave stages pieces 8*wave .. 8*wave+7 (8 rows x 128 B each) of A and of B through raw
@@ -249,17 +254,21 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     SfBufRaw rawA, rawB;   // the same descriptors for the asm (compiler-opaque) DMA forms
 #endif
     unsigned voff[16];
-    auto setup_tile = [&](int t) {   // tile origin, descriptors and per-lane source offsets of tile t
+    auto setup_tile = [&](int t) {   // tile origin, descriptors and per-lane source offsets of work unit t
         int tm, tn;
+        ks0 = 0;
+        if (p.ksplit > 1) { ks0 = t / nblk; t -= ks0 * nblk; }          // (split-K: the unit's K chunk)
         w4_tile_coords(t, nblk, p.tiles_m, p.tiles_n, p.gm, tm, tn);
         m0 = tm * TM;
         n0 = tn * TN;
-        bufA = sf_make_buf(p.A + (long)m0 * p.lda, 0x7fffffffu);
+        const sf_bf16* Ab = p.A + (long)m0 * p.lda + ks0 * p.ks_a;
         const long brow0 = ADD == 3 ? (long)tn * (TN / 2) : (long)n0;   // (ADD = 3: the tile's first gate row)
-        bufB = sf_make_buf(p.B + brow0 * p.ldb, 0x7fffffffu);
+        const sf_bf16* Bb = p.B + brow0 * p.ldb + ks0 * p.ks_b;
+        bufA = sf_make_buf(Ab, 0x7fffffffu);
+        bufB = sf_make_buf(Bb, 0x7fffffffu);
 #ifndef SF_EMU
-        rawA = sf_make_buf_raw(p.A + (long)m0 * p.lda);
-        rawB = sf_make_buf_raw(p.B + brow0 * p.ldb);
+        rawA = sf_make_buf_raw(Ab);
+        rawB = sf_make_buf_raw(Bb);
 #endif
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -414,8 +423,9 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
 
     // ---- hand-over: the finished tile's coordinates, then the next tile's first two K-tiles go in flight
     const int mc = m0, nc = n0;
+    const long coff = ks0 * p.ks_c;              // (split-K: this unit's partial of C; 0 otherwise)
     const int next = tile + (int)gridDim.x;
-    const bool has_next = next < nblk;
+    const bool has_next = next < nunits;
     // the interior-tile fast path of the epilogue (workgroup-uniform; 16-byte row segments need 16-byte aligned rows)
     const bool fast = SF_W4_FAST_EPI && mc + TM <= p.M && nc + TN <= p.N && p.e.beta == 0.f && !p.e.R && (p.e.ldc & 7) == 0 &&
                       ((size_t)p.e.C & 15) == 0;
@@ -536,7 +546,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
         if constexpr (OUT_F32) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float* crow = (float*)p.e.C + (long)(mc + wr * 128 + i * 16 + (lane & 15)) * p.e.ldc + nc + wc * 128 + 4 * (lane >> 4);
+                float* crow = (float*)p.e.C + coff + (long)(mc + wr * 128 + i * 16 + (lane & 15)) * p.e.ldc + nc + wc * 128 + 4 * (lane >> 4);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if constexpr (ADD == 1) *reinterpret_cast<sf_v4f*>(crow + j * 16) = acc[i][j] + ad[i & 1][j];   // (alpha == 1)

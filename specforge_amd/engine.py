@@ -315,6 +315,8 @@ class Eagle3Engine:
         # fp32 partials for the 2-way split-K of weight-gradient GEMMs whose tile count fills the CUs badly (down, q|k|v)
         # (+ 4096 floats at the tail: pace-keeping counters of sf_gemm_tn)
         b["tn_ws"] = cv("tn_ws", 2 * max(H * I, self.QW * H) + 4096, dtype=f32)
+        # split-K partials of the plain NT GEMMs when their grids are under-filled (few tokens x narrow outputs: bs 1 recipes); else unused
+        b["nt_ws"] = (cv("nt_ws", 4 * 128 * 65536, dtype=f32) if ((N + 255) // 256) * ((H + 255) // 256) <= 128 else None)
         nws = ops.attn_bwd_dkv_workspace_floats(B, S, nh, nkv, hdp)     # head-split partials (small B * nkv only; else 0)
         b["dkv_ws"] = cv("dkv_ws", nws, dtype=f32) if nws else None
         return b
@@ -518,7 +520,7 @@ class Eagle3Engine:
             b["hsn"].copy_(hs)                          # N % 64 != 0 (the usual case on ragged real data: the collator pads to
             # the longest sample, whatever it is): zero-padded copy of the fc input for the K = N weight-gradient GEMM
             fc_in, self._fc_x = b["hsn"], b["hs_s"]
-        ops.gemm_nt(fc_in, f.view("fc.weight"), b["h"][0])
+        ops.gemm_nt(fc_in, f.view("fc.weight"), b["h"][0], workspace=b["nt_ws"])
 
         kcol, vcol = slice(nh * hd, (nh + nkv) * hd), slice((nh + nkv) * hd, self.QW)
         lk = self.lk_loss_type
@@ -554,10 +556,10 @@ class Eagle3Engine:
                 ops.attn_fwd(b["qp"][k], b["kp"][0], b["vp"][0], b["kp"][1:k + 1], b["vp"][1:k + 1], b["kvlen"], b["op"][k],
                              b["lse"][k], B=B, S=S, nh=nh, nkv=nkv, hd=self.hdp, scale=scale)
                 self._unpad_heads(b["op"][k], nh, b["o"][k])
-            ops.gemm_nt(b["o"][k], f.view("midlayer.self_attn.o_proj.weight"), b["h1"][k], residual=b["h"][k])
+            ops.gemm_nt(b["o"][k], f.view("midlayer.self_attn.o_proj.weight"), b["h1"][k], residual=b["h"][k], workspace=b["nt_ws"])
             ops.rmsnorm_fwd(b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"), eps, pn, b["rstd_p"][k])
             ops.gemm_nt_swiglu_fwd(pn, self.w_gu, b["gu"][k], act)      # gate|up projection, SwiGLU in its epilogue
-            ops.gemm_nt(act, f.view("midlayer.mlp.down_proj.weight"), b["h"][k + 1], residual=b["h1"][k])
+            ops.gemm_nt(act, f.view("midlayer.mlp.down_proj.weight"), b["h"][k + 1], residual=b["h1"][k], workspace=b["nt_ws"])
             if c.norm_output:   # compute_logits (llama3_eagle.py:1772-1777)
                 ln = b["ln"][k]
                 if k + 1 < T:       # ... and the next step's hidden_norm of the same h[k+1]: one pass, one row statistic
@@ -588,7 +590,7 @@ class Eagle3Engine:
                                    kl_decay=self.kl_decay, step_scale=self.decay ** k, kl_row_scale=1.0 / N,
                                    accept_sum=b["metrics"][k][2:3], mask_sum=b["msum"][k:k + 1])
             if train:
-                ops.gemm_nt(logits, self.wlmT, b["dln"][k])        # lm_head dgrad, taken now
+                ops.gemm_nt(logits, self.wlmT, b["dln"][k], workspace=b["nt_ws"])        # lm_head dgrad, taken now
 
         self._fwd_state = (B, S) if train else None
         # ---- metrics (tiny integer-mask sums; eagle3/model.py:161-190, core/lk_loss.py:43-80)
@@ -698,11 +700,11 @@ class Eagle3Engine:
                 ops.add_bf16(b["dln"][k], dh_next, dh)
             # MLP
             ops.gemm_nt_swiglu_bwd(dh, self.wdT, b["gu"][k], dgu, b["dact"])   # down dgrad + d(SwiGLU) in its epilogue
-            ops.gemm_nt(dgu, self.wguT, b["dpn"])
+            ops.gemm_nt(dgu, self.wguT, b["dpn"], workspace=b["nt_ws"])
             norm_bwd("midlayer.post_attention_layernorm.weight", b["dpn"], b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"),
                      b["rstd_p"][k], dx=dh1, add=dh)
             # attention
-            ops.gemm_nt(dh1, self.woT, b["do"][k])
+            ops.gemm_nt(dh1, self.woT, b["do"][k], workspace=b["nt_ws"])
             qkv = b["qkv"][k]
             if self.hdp == hd:
                 q, o_k, do, dq_out = qkv[:, :nh * hd], b["o"][k], b["do"][k], dqkv[:, :nh * hd]
@@ -755,7 +757,7 @@ class Eagle3Engine:
                 ops.rope_(dqkv, nh + nkv, hd, b["cos_rows"][k], b["sin_rows"][k], b["pos"], 0, backward=True)
             else:
                 ops.rope_(dqkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k, backward=True)
-            ops.gemm_nt(dqkv, self.wqkvT[H:], b["dxh"])                 # hidden half of the QKV dgrad
+            ops.gemm_nt(dqkv, self.wqkvT[H:], b["dxh"], workspace=b["nt_ws"])                 # hidden half of the QKV dgrad
             if pair and k > 0:
                 pending = (b["dxh"], dh1)      # consumed at the top of step k - 1, before that step rewrites dxh
                 continue

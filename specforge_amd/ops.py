@@ -48,12 +48,19 @@ def _rowmajor(t: torch.Tensor) -> int:
 
 
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, alpha: float = 1.0, beta: float = 0.0,
-            residual: Optional[torch.Tensor] = None):
-    """out[M,N] = alpha * a[M,K] @ b[N,K]^T (+ beta*out) (+ residual); a, b bf16; out bf16|fp32."""
+            residual: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None):
+    """out[M,N] = alpha * a[M,K] @ b[N,K]^T (+ beta*out) (+ residual); a, b bf16; out bf16|fp32.
+    ``workspace`` (fp32, alpha 1 / beta 0 only): lets an under-filled grid run split-K (sf_gemm_nt_ws); other shapes ignore it."""
     L = _lib.lib()
     M, K = a.shape
     N, K2 = b.shape
     assert K == K2 and out.shape == (M, N) and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    if workspace is not None and alpha == 1.0 and beta == 0.0:
+        assert workspace.dtype == torch.float32 and workspace.is_contiguous()
+        _lib.check(L.sf_gemm_nt_ws(_p(a), _rowmajor(a), _p(b), _rowmajor(b), _p(out), _dt(out), _rowmajor(out), M, N, K, _p(residual),
+                                   _rowmajor(residual) if residual is not None else 0, _p(workspace), workspace.numel(), _stream()),
+                   "sf_gemm_nt_ws")
+        return out
     _lib.check(L.sf_gemm_nt(_p(a), _rowmajor(a), _p(b), _rowmajor(b), _p(out), _dt(out), _rowmajor(out), M, N, K,
                             alpha, beta, _p(residual), _rowmajor(residual) if residual is not None else 0, _stream()),
                "sf_gemm_nt")

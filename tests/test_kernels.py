@@ -118,6 +118,33 @@ def test_gemm_nt_epilogues(backend):
     assert float(wide[:, :8].abs().max()) == 0 and float(wide[:, 8 + N:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(512, 512, 512, 2), (256, 512, 1024, 4), (512, 768, 256, 0), (520, 512, 512, 0)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_gemm_nt_split_k_for_under_filled_grids(backend, M, N, K, ks, out_dtype):
+    """sf_gemm_nt_ws: with at most half as many 256-tiles as CUs (interpreter: 8 "CUs") K is cut into 2 / 4 chunks -- tiles x chunks work
+    units of the 4-wave kernel, fp32 partials, fixed-order reduce; the residual joins after the rounding like in sf_gemm_nt.  Shapes that
+    do not qualify (too many tiles, ragged M) and a missing workspace go the usual way.  ``ks`` = the split the shape should take."""
+    a, b = _rand((M, K), torch.bfloat16, 1), _rand((N, K), torch.bfloat16, 2)
+    res = _rand((M, N), torch.bfloat16, 3) if out_dtype == torch.bfloat16 else None
+    ref = a.float() @ b.float().t()
+    ws = torch.full((4 * M * N,), float("nan"), device=backend)
+    d = lambda t: None if t is None else _dev(backend, t)
+    out = torch.full((M, N), 7.0, dtype=out_dtype, device=backend)
+    ops.gemm_nt(d(a), d(b), out, residual=d(res), workspace=ws)
+    plain = torch.full((M, N), 7.0, dtype=out_dtype, device=backend)
+    ops.gemm_nt(d(a), d(b), plain, residual=d(res))
+    want = ref if res is None else (ref.to(torch.bfloat16) + res).float()
+    tol = 1e-3 if out_dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(out.float().cpu(), want, rtol=tol, atol=tol * math.sqrt(K))
+    torch.testing.assert_close(out.float().cpu(), plain.float().cpu(), rtol=1e-2 if res is not None else 1e-5, atol=0.25 if res is not None else 1e-3)
+    used = int(torch.isfinite(ws).sum())                   # the partials that were written say which split ran
+    if backend == "cpu":
+        assert used == ks * M * N, (used, ks * M * N)
+    again = torch.empty_like(out)
+    ops.gemm_nt(d(a), d(b), again, residual=d(res), workspace=torch.zeros_like(ws))
+    assert torch.equal(again.cpu(), out.cpu())             # run-to-run identical, whatever the workspace held
+
+
 def test_gemm_nt_peeled_last_round_epilogues(backend):
     """the peeled column tile of a partly filled last round (interpreter: 2 x 5 tiles on 8 "CUs") carries the same epilogue:
     residual after the rounding (bf16), alpha / beta (fp32)"""

@@ -4,6 +4,7 @@ Run once per setting on the TOOLS build (the knob is read once per process):
 
     python tools/small_tile_ab.py            > gpurun_out/small_tile_256.jsonl
     SF_GEMM_TILE=128 python tools/small_tile_ab.py > gpurun_out/small_tile_128.jsonl
+    SF_NT_WS=1 python tools/small_tile_ab.py > gpurun_out/small_tile_splitk.jsonl      (product library, sf_gemm_nt_ws: split-K where it qualifies)
 """
 import json
 import os
@@ -29,14 +30,15 @@ for M, N, K in SHAPES:
     a = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
     b = torch.randn(N, K, device=dev, generator=g).to(torch.bfloat16)
     c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ws = torch.empty(4 * M * N, device=dev) if os.environ.get("SF_NT_WS") else None
     for _ in range(5):
-        ops.gemm_nt(a, b, c)
+        ops.gemm_nt(a, b, c, workspace=ws)
     torch.cuda.synchronize()
     n = 30
     t0 = time.perf_counter()
     for _ in range(n):
-        ops.gemm_nt(a, b, c)
+        ops.gemm_nt(a, b, c, workspace=ws)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / n
     print(json.dumps(dict(M=M, N=N, K=K, tiles256=((M + 255) // 256) * ((N + 255) // 256), ms=round(ms, 4),
-                          tflops=round(2.0 * M * N * K / ms / 1e9, 1), tile=os.environ.get("SF_GEMM_TILE", "product dispatch"))), flush=True)
+                          tflops=round(2.0 * M * N * K / ms / 1e9, 1), tile=os.environ.get("SF_GEMM_TILE", "product dispatch" + (" + workspace (split-K)" if ws is not None else "")))), flush=True)
