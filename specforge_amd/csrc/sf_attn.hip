@@ -228,15 +228,23 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, AttnOcc<HD>::kWgPerCu) attn_fwd_kernel(
             const float e = sf_exp2(s2 - mn);
             m = mn;
             l = l * alpha + e;
+            // O = O * alpha + e * V_i: per 32-column block one 16-wide fp32 vector expression (v_pk_mul_f32 / v_pk_fma_f32: two
+            // columns per instruction), the bf16 values widened pairwise (lo: shift, hi: mask)
 #pragma unroll
-            for (int d = 0; d < DB; ++d)
+            for (int d = 0; d < DB; ++d) {
+                sf_v16f vf;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const sf_v4s vv = vv4[d * 4 + j];
+                    typedef unsigned sf_v2u_ __attribute__((ext_vector_type(2)));
+                    const sf_v2u_ w = __builtin_bit_cast(sf_v2u_, vv4[d * 4 + j]);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc_o[d][4 * j + t] = acc_o[d][4 * j + t] * alpha + e * sf_bf2f((sf_bf16)vv[t]);
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        vf[4 * j + 2 * h2] = __builtin_bit_cast(float, w[h2] << 16);
+                        vf[4 * j + 2 * h2 + 1] = __builtin_bit_cast(float, w[h2] & 0xffff0000u);
+                    }
                 }
+                acc_o[d] = acc_o[d] * alpha + vf * e;
+            }
             } else {
             // head_dim 256: the query fragments and the output accumulators are 192 registers of the wave already -- the branch's
             // K_i / V_i rows are consumed from LDS a few registers at a time, and the next branch is staged only after the last read

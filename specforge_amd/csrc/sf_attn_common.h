@@ -158,10 +158,12 @@ SF_DEVICE sf_v8s pack_bf16x8(const sf_v16f& p, int r0) {
 // row index inside a 32x32 MFMA result tile held by this lane in register r
 SF_DEVICE int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-SF_DEVICE float dot8(sf_v8s a, sf_v8s b) {
+SF_DEVICE float dot8(sf_v8s a, sf_v8s b) {      // 8 bf16 products summed in fp32: four v_dot2c_f32_bf16
+    typedef unsigned sf_v4u_ __attribute__((ext_vector_type(4)));
+    const sf_v4u_ x = __builtin_bit_cast(sf_v4u_, a), y = __builtin_bit_cast(sf_v4u_, b);
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += sf_bf2f((sf_bf16)a[i]) * sf_bf2f((sf_bf16)b[i]);
+    for (int i = 0; i < 4; ++i) s = sf_dot2_bf16(x[i], y[i], s);
     return s;
 }
 

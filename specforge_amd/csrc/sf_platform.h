@@ -350,6 +350,18 @@ SF_HD sf_bf16 sf_f2bf(float f) {
     return __builtin_bit_cast(sf_bf16, b);
 }
 SF_HD float sf_round_bf(float f) { return sf_bf2f(sf_f2bf(f)); }
+// c + a.lo * b.lo + a.hi * b.hi for two bf16 pairs packed in 32 bits each (gfx950: v_dot2c_f32_bf16, one VALU instruction for what is two
+// conversions per operand and two fmas otherwise).  Interpreter: the same sum in fp32.
+SF_DEVICE float sf_dot2_bf16(unsigned a, unsigned b, float c) {
+#ifdef SF_EMU
+    const float a0 = sf_bf2f((sf_bf16)(a & 0xffffu)), a1 = sf_bf2f((sf_bf16)(a >> 16));
+    const float b0 = sf_bf2f((sf_bf16)(b & 0xffffu)), b1 = sf_bf2f((sf_bf16)(b >> 16));
+    return c + a0 * b0 + a1 * b1;
+#else
+    typedef __bf16 sf_bf2_ __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sf_bf2_, a), __builtin_bit_cast(sf_bf2_, b), c, false);
+#endif
+}
 // two floats -> one dword of two bf16 (a in the low half): ONE v_cvt_pk_bf16_f32.  Four shorts assembled from scalar sf_f2bf casts
 // compile to three conversions + v_perm_b32 + v_alignbit_b32 per four values (hipcc pairs the middle two): 11 instead of 3
 // instructions per 8-byte store of a GEMM epilogue.
