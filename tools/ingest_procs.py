@@ -39,7 +39,7 @@ if "--worker" in sys.argv:
         idx = distributed_sampler_indices(len(files), dp_rank=rank, dp_size=procs, seed=0, epoch=0, shuffle=False)
         groups = [idx[i:i + B] for i in range(0, len(idx) - B + 1, B)]
         for g in groups[:1]:
-            ing._fill(ing._slots[0], g)
+            ing._fill(ing._slots[0], [files[i] for i in g])
     else:
         for _ in ing.epoch(0):
             pass
@@ -53,7 +53,7 @@ if "--worker" in sys.argv:
     for rep in range(2):
         if host_only:
             for i, g in enumerate(groups):
-                ing._fill(ing._slots[i & 1], g)
+                ing._fill(ing._slots[i & 1], [files[j] for j in g])
                 n += 1
         else:
             for _ in ing.epoch(rep):
