@@ -159,13 +159,31 @@ class KernelTimer:
         return sum(x[0] for x in r), sum(x[1].elapsed_time(x[2]) for x in r), len(r)
 
 
-def make_batch(cfg, B, S, dev, seed):
+def make_loss_mask(B, S, density, seed):
+    """host [B, S] int64 loss mask: all ones (the headline: every position carries a loss), or chat-like turns -- alternating
+    unmasked / masked spans of random length (mean 64 tokens) with the requested fraction of masked-in positions"""
+    if density >= 1.0:
+        return torch.ones(B, S, dtype=torch.int64)
+    g = torch.Generator().manual_seed(seed)
+    lm = torch.zeros(B, S, dtype=torch.int64)
+    for b in range(B):
+        pos, on = 0, False
+        while pos < S:
+            mean = 64.0 * (2 * density if on else 2 * (1 - density))
+            n = max(1, int(torch.empty(1).exponential_(1.0 / max(mean, 1.0), generator=g)))
+            if on:
+                lm[b, pos:pos + n] = 1
+            pos, on = pos + n, not on
+    return lm
+
+
+def make_batch(cfg, B, S, dev, seed, loss_mask=None):
     g = torch.Generator(device=dev).manual_seed(seed)
     Ht = cfg["target_hidden_size"]
     return dict(
         input_ids=torch.randint(0, cfg["vocab_size"], (B, S), device=dev, generator=g),
         attention_mask=torch.ones(B, S, dtype=torch.int64, device=dev),
-        loss_mask=torch.ones(B, S, dtype=torch.int64, device=dev),
+        loss_mask=torch.ones(B, S, dtype=torch.int64, device=dev) if loss_mask is None else loss_mask.to(dev),
         hidden_state=torch.randn(B, S, 3 * Ht, device=dev, generator=g).to(torch.bfloat16),
         target=torch.randn(B, S, Ht, device=dev, generator=g).to(torch.bfloat16),
     )
@@ -229,6 +247,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: all ranks on cuda:0 (with --dist-backend gloo)")
     ap.add_argument("--diag-per-step", action="store_true",
                     help="A/B: the diagonal-branch backward as one sf_attn_bwd_pre per TTT step (round 3) instead of the blocked sf_attn_bwd_diag")
+    ap.add_argument("--loss-mask-density", type=float, default=1.0,
+                    help="fraction of positions that carry a loss (default 1.0 = the headline workload: all ones).  < 1: chat-like spans; "
+                         "the engine runs lm_head / CE / lm_head gradients on those rows only (see --no-compact)")
+    ap.add_argument("--no-compact", action="store_true", help="A/B: the dense lm_head part also for sparse loss masks")
     ap.add_argument("--materialise-targets", action="store_true",
                     help="A/B: write the fp32 soft targets [B, S+T, Vd] instead of re-forming them in the fused CE from the teacher's draft logits")
     args = ap.parse_args()
@@ -287,7 +309,16 @@ def main():
     backend.prepare_model(eagle)
     eagle.engine.materialise_soft_targets = args.materialise_targets
     eagle.engine.blocked_diag = not args.diag_per_step
-    batches = [TrainBatch(make_batch(cfg, B, S, dev, 100 + rank * 10 + i), {"target_repr": "hidden_state"}) for i in range(2)]
+    eagle.engine.compact_loss_rows = not args.no_compact
+    from specforge_amd.eagle3 import loss_mask_suffix_counts
+
+    def resident_batch(i, density):
+        lm = make_loss_mask(B, S, density, 7 + rank * 10 + i)
+        # (the row counts a loader computes while the mask is in host memory -- HiddenStateIngest / the strategy for CPU batches)
+        return TrainBatch(make_batch(cfg, B, S, dev, 100 + rank * 10 + i, lm),
+                          {"target_repr": "hidden_state", "loss_mask_suffix_counts": loss_mask_suffix_counts(lm)})
+
+    batches = [resident_batch(i, args.loss_mask_density) for i in range(2)]
 
     # ---- where a step's batch comes from (--feed).  hbm: resident (the metric).  The others are what a
     # `specforge train` run sees: feature files through the HIP ingest, or CPU batches as the reference's loader hands them over.
@@ -423,6 +454,26 @@ def main():
                          "copy stream.  cpu_batch_pageable: the reference strategy's own CPU shift + blocking pageable .to(device).")
     cleanup_feeds()
 
+    # ---- sparse loss mask (what real chat data looks like; the headline has all ones): half of the positions carry a loss, in
+    # turn-like spans.  compact = the product path (lm_head / CE / lm_head gradients over the masked-in rows only, host-known row
+    # counts); dense = the same batches with engine.compact_loss_rows off.  Reported beside the headline, never instead of it.
+    sparse = None
+    if not args.no_feeds and (world == 1 or args.feeds) and args.loss_mask_density >= 1.0:
+        try:
+            fs = args.feed_steps or min(args.steps, 6)
+            sb = [resident_batch(i, 0.5) for i in range(2)]
+            sparse = {"loss_mask_density": float(sum(float(x.tensors["loss_mask"].float().mean()) for x in sb) / 2), "steps_per_leg": fs}
+            for name, flag in (("compact", True), ("dense", False)):
+                eagle.engine.compact_loss_rows = flag
+                timed(strat, 2, next_batch=lambda i: sb[i % 2])
+                e4, _ = timed(strat, fs, next_batch=lambda i: sb[i % 2])
+                sparse[name] = {"ms_per_step": 1e3 * e4 / fs, "tokens_per_s": world * B * S * fs / e4}
+            del sb
+        except Exception as e:
+            sparse = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            eagle.engine.compact_loss_rows = not args.no_compact
+
     # ---- RCCL evidence: the gradient all-reduce of each bucket, timed alone on the communicator (outside the timed region)
     rccl = None
     if dist.is_initialized():
@@ -512,7 +563,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("SMALL-debug" if args.small else cfg_label)
-                       + f", bf16, per-GPU batch {B} x seq {S}, ttt {args.ttt}, optimizer step included",
+                       + f", bf16, per-GPU batch {B} x seq {S}, ttt {args.ttt}, optimizer step included"
+                       + ("" if args.loss_mask_density >= 1.0 else f", loss mask density {args.loss_mask_density} (NOT the headline workload)"
+                          + (", dense lm_head" if args.no_compact else "")),
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": GEMM_KERNEL_NAME, "achieved": ach,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
@@ -532,6 +585,8 @@ def main():
         line["feed"] = args.feed
         if feeds is not None:
             line["feeds"] = feeds
+        if sparse is not None:
+            line["sparse_loss_mask"] = sparse
         if dense is not None:
             line["dense_mask"] = dense
         if rccl is not None:

@@ -85,7 +85,7 @@ int sf_ce_fused(void* logits, int dtype, long ld, int rows, int V, const float* 
                 const int* pos_mask_pad, const int* loss_mask_pad, const long long* tgt_ids_pad,
                 const float* pod_scale_pad, const float* tsum_pad, const long long* d2t, float grad_scale,
                 int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred,
-                void* stream);
+                const long long* row_map, void* stream);
 
 /* ---- LK-loss gradient (optional objective, lk_loss_type in {"alpha","lambda"}) ----------------
  * replaces the autograd path through specforge/core/lk_loss.py:43-99 selected at
@@ -98,11 +98,13 @@ int sf_ce_fused(void* logits, int dtype, long ld, int rows, int V, const float* 
 /* sf_ce_fused with the soft target given as the teacher's stored draft logits (ABI 4): zt [B*S, ldzt] bf16 in NATURAL token rows,
  * zmd_pad / zinv_pad [B, Spad] from sf_teacher_reduce_perm; row r = b*S+s of TTT step `off` uses target_p[j] = exp(zt[b*S+s+off][j] -
  * zmd) * zinv -- the expression the teacher kernel evaluates when it writes target_p, so results are bit-identical to sf_ce_fused on
- * that array; 2 bytes per element instead of 4, and [B, S, Vd] fp32 is never written or read.  tsum_pad is required. */
+ * that array; 2 bytes per element instead of 4, and [B, S, Vd] fp32 is never written or read.  tsum_pad is required.
+ * row_map (ABI 5, optional; the same argument of sf_ce_fused): `rows` COMPACT logits rows -- row r of `logits` / of the row_* outputs is token row row_map[r] of the
+ * [B, S] grid (loss-row compaction: only rows with a loss mask went through lm_head); targets and masks are addressed by token row. */
 int sf_ce_fused_zt(void* logits, int dtype, long ld, int rows, int V, const void* zt, long ldzt, const float* zmd_pad,
                    const float* zinv_pad, int S, int Spad, int off, const int* pos_mask_pad, const int* loss_mask_pad,
                    const long long* tgt_ids_pad, const float* pod_scale_pad, const float* tsum_pad, const long long* d2t,
-                   float grad_scale, int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred,
+                   float grad_scale, int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred, const long long* row_map,
                    void* stream);
 int sf_ce_lk_grad(void* logits, int dtype, long ld, int rows, int V, const float* target, int S, int Spad, int off,
                   const int* pos_mask_pad, const float* pod_scale_pad, const float* tsum_pad, int lk_mode,

@@ -28,7 +28,7 @@ _SIGS = {
     "sf_gemm_nt_rowadd": (c_int, [P, c_long, P, c_long, P, c_int, c_long, c_int, c_int, c_int, c_float, P, c_long, c_int,
                                   c_int, c_int, P]),
     "sf_ce_fused": (c_int, [P, c_int, c_long, c_int, c_int, P, c_int, c_int, c_int, P, P, P, P, P, P, c_float, c_int,
-                            P, P, P, P, P]),
+                            P, P, P, P, P, P]),
     "sf_ce_lk_grad": (c_int, [P, c_int, c_long, c_int, c_int, P, c_int, c_int, c_int, P, P, P, c_int, c_float, c_float,
                               c_float, c_float, P, P, P]),
     "sf_reduce_sum": (c_int, [P, c_long, c_int, P, c_float, P]),
@@ -39,7 +39,7 @@ _SIGS = {
                                        P, P, P, P]),
     "sf_gemm_nt_teacher_reduces": (c_int, [c_int, c_int, c_int, c_int]),
     "sf_ce_fused_zt": (c_int, [P, c_int, c_long, c_int, c_int, P, c_long, P, P, c_int, c_int, c_int, P, P, P, P, P, P, c_float, c_int, P, P,
-                               P, P, P]),
+                               P, P, P, P]),
     "sf_rmsnorm_fwd": (c_int, [P, c_int, c_long, P, c_int, c_int, c_int, P, c_float, c_int, c_int, P, c_long, P, P]),
     "sf_rmsnorm_fwd2": (c_int, [P, c_int, c_long, P, P, c_long, P, P, P, c_long, P, c_float, c_int, c_int, P]),
     "sf_rmsnorm_bwd2": (c_int, [P, c_long, P, P, c_int, P, c_long, P, P, c_int, c_int, P, c_long, P, c_int, c_int, P, c_long, P, c_long, P, P]),

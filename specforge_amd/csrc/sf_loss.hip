@@ -57,11 +57,15 @@ ce_fused_kernel(T* logits, long ld, int V, const float* target, int S, int Spad,
                 const int* pos_mask_pad, const int* loss_mask_pad, const long long* tgt_ids_pad,
                 const float* pod_scale_pad, const float* tsum_pad, const long long* d2t, float grad_scale,
                 int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred,
-                const sf_bf16* zt = nullptr, long ldzt = 0, const float* zmd_pad = nullptr, const float* zinv_pad = nullptr) {
+                const sf_bf16* zt = nullptr, long ldzt = 0, const float* zmd_pad = nullptr, const float* zinv_pad = nullptr,
+                const long long* row_map = nullptr) {
     SF_SHARED float red[32];
     SF_SHARED int redi[16];
     const int r = (int)blockIdx.x;
-    const int b = r / S, s = r - b * S;
+    // row_map (round 4: loss-row compaction): logits row r / its row_* outputs belong to token row row_map[r] of the [B, S] grid --
+    // only the rows that carry a loss mask went through lm_head; the targets and masks are still addressed by token position
+    const int rt = row_map ? (int)row_map[r] : r;
+    const int b = rt / S, s = rt - b * S;
     const long pr = (long)b * Spad + s + off;
     T* x = logits + (long)r * ld;
     const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
@@ -650,7 +654,7 @@ extern "C" int sf_ce_fused(void* logits, int dtype, long ld, int rows, int V, co
                            int off, const int* pos_mask_pad, const int* loss_mask_pad, const long long* tgt_ids_pad,
                            const float* pod_scale_pad, const float* tsum_pad, const long long* d2t, float grad_scale,
                            int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred,
-                           void* stream) {
+                           const long long* row_map, void* stream) {
     SF_CHECK_ARG(rows >= 0 && V > 0 && S > 0 && Spad >= S && off >= 0 && off + S <= Spad, "sf_ce_fused: bad shape");
     SF_CHECK_ARG(dtype == SF_BF16 || dtype == SF_F32, "sf_ce_fused: dtype");
     SF_CHECK_ARG(ld % 8 == 0 && V % 8 == 0, "sf_ce_fused: ld and V must be multiples of 8");
@@ -658,11 +662,11 @@ extern "C" int sf_ce_fused(void* logits, int dtype, long ld, int rows, int V, co
     if (dtype == SF_BF16)
         SF_LAUNCH((ce_fused_kernel<sf_bf16>), dim3(rows), dim3(256), 0, stream, (sf_bf16*)logits, ld, V, target, S, Spad,
                   off, pos_mask_pad, loss_mask_pad, tgt_ids_pad, pod_scale_pad, tsum_pad, d2t, grad_scale, write_grad,
-                  row_loss, row_correct, row_accept, row_pred);
+                  row_loss, row_correct, row_accept, row_pred, (const sf_bf16*)nullptr, 0L, (const float*)nullptr, (const float*)nullptr, row_map);
     else
         SF_LAUNCH((ce_fused_kernel<float>), dim3(rows), dim3(256), 0, stream, (float*)logits, ld, V, target, S, Spad,
                   off, pos_mask_pad, loss_mask_pad, tgt_ids_pad, pod_scale_pad, tsum_pad, d2t, grad_scale, write_grad,
-                  row_loss, row_correct, row_accept, row_pred);
+                  row_loss, row_correct, row_accept, row_pred, (const sf_bf16*)nullptr, 0L, (const float*)nullptr, (const float*)nullptr, row_map);
     return sf_check_launch("sf_ce_fused");
 }
 
@@ -748,8 +752,8 @@ extern "C" int sf_ce_fused_zt(void* logits, int dtype, long ld, int rows, int V,
                               const float* zinv_pad, int S, int Spad, int off, const int* pos_mask_pad, const int* loss_mask_pad,
                               const long long* tgt_ids_pad, const float* pod_scale_pad, const float* tsum_pad, const long long* d2t,
                               float grad_scale, int write_grad, float* row_loss, float* row_correct, float* row_accept, int* row_pred,
-                              void* stream) {
-    SF_CHECK_ARG(rows >= 0 && V > 0 && S > 0 && Spad >= S && off >= 0 && off + S <= Spad && rows % S == 0, "sf_ce_fused_zt: bad shape");
+                              const long long* row_map, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && V > 0 && S > 0 && Spad >= S && off >= 0 && off + S <= Spad && (row_map || rows % S == 0), "sf_ce_fused_zt: bad shape");
     SF_CHECK_ARG(dtype == SF_BF16 || dtype == SF_F32, "sf_ce_fused_zt: dtype");
     SF_CHECK_ARG(ld % 8 == 0 && V % 8 == 0 && ldzt % 8 == 0 && ldzt >= V, "sf_ce_fused_zt: ld, ldzt and V must be multiples of 8");
     SF_CHECK_ARG(zt && zmd_pad && zinv_pad && tsum_pad && pos_mask_pad, "sf_ce_fused_zt: teacher logits, their row scalars and tsum are required");
@@ -757,10 +761,10 @@ extern "C" int sf_ce_fused_zt(void* logits, int dtype, long ld, int rows, int V,
     if (dtype == SF_BF16)
         SF_LAUNCH((ce_fused_kernel<sf_bf16, 1>), dim3(rows), dim3(256), 0, stream, (sf_bf16*)logits, ld, V, (const float*)nullptr, S, Spad,
                   off, pos_mask_pad, loss_mask_pad, tgt_ids_pad, pod_scale_pad, tsum_pad, d2t, grad_scale, write_grad,
-                  row_loss, row_correct, row_accept, row_pred, (const sf_bf16*)zt, ldzt, zmd_pad, zinv_pad);
+                  row_loss, row_correct, row_accept, row_pred, (const sf_bf16*)zt, ldzt, zmd_pad, zinv_pad, row_map);
     else
         SF_LAUNCH((ce_fused_kernel<float, 1>), dim3(rows), dim3(256), 0, stream, (float*)logits, ld, V, (const float*)nullptr, S, Spad,
                   off, pos_mask_pad, loss_mask_pad, tgt_ids_pad, pod_scale_pad, tsum_pad, d2t, grad_scale, write_grad,
-                  row_loss, row_correct, row_accept, row_pred, (const sf_bf16*)zt, ldzt, zmd_pad, zinv_pad);
+                  row_loss, row_correct, row_accept, row_pred, (const sf_bf16*)zt, ldzt, zmd_pad, zinv_pad, row_map);
     return sf_check_launch("sf_ce_fused_zt");
 }

@@ -21,6 +21,15 @@ from .engine import Eagle3Engine
 from .model import LlamaForCausalLMEagle3
 
 
+def loss_mask_suffix_counts(loss_mask: torch.Tensor, n: int = ops.MAX_DIAG + 1):
+    """[sum(loss_mask[:, k:]) for k in range(n)] as python ints, from a HOST copy of the [B, S] loss mask: TTT step k scores row
+    (b, s) against the mask at position s + k (eagle3/model.py:364-433), so these are the per-step numbers of rows that carry a loss.
+    Computed where the mask still is in host memory (the ingest's pinned slot, a CPU batch): never a device read-back."""
+    assert not loss_mask.is_cuda
+    col = (loss_mask.reshape(loss_mask.shape[0], -1) != 0).sum(dim=0).flip(0).cumsum(0).flip(0).tolist()   # suffix sums over positions
+    return [int(col[k]) if k < len(col) else 0 for k in range(n)]
+
+
 def padding_left_shift(t: torch.Tensor) -> torch.Tensor:
     """``padding(tensor, left=False)`` (specforge/utils.py:128-135): shift left by one along dim 1, zero fill."""
     return torch.cat((t[:, 1:], torch.zeros_like(t[:, -1:])), dim=1)
@@ -42,6 +51,9 @@ class _TTTStep(torch.autograd.Function):
         # data-gradient sweep first and the read-back waits behind ~half a step of queued GPU work instead of stalling
         # the launch of the backward behind the forward.
         gp_dev = grad_plosses.detach().float()
+        nt = gp_dev.numel()
+        if eng._cnt_bad is not None:         # loss-row compaction ran on host-supplied row counts: their device-side check rides along
+            gp_dev = torch.cat([gp_dev.view(-1), eng._cnt_bad.float().view(1)])
         if gp_dev.is_cuda:
             host = getattr(eng, "_upstream_host", None)      # one pinned buffer for the engine's lifetime: allocating
             if host is None or host.shape != gp_dev.shape:   # pinned memory per step costs milliseconds of idle GPU
@@ -56,6 +68,10 @@ class _TTTStep(torch.autograd.Function):
             if ready is not None:
                 ready.synchronize()
             gp = host.tolist()
+            if len(gp) > nt and gp[nt] != 0.0:
+                raise RuntimeError("loss_counts passed to the forward do not match the loss mask (loss_counts[k] must be the number of "
+                                   "rows with loss_mask[b, s + k] != 0): the compacted lm_head rows of this step are wrong")
+            gp = gp[:nt]
             g = gp[0]
             # The decay weights are baked into the fused CE gradients; the caller must use the same ones.
             for k, v in enumerate(gp):
@@ -115,7 +131,9 @@ class OnlineEagle3Model(nn.Module):
 
     def forward(self, input_ids, attention_mask, target=None, loss_mask=None, hidden_states=None, past_key_values=None,
                 position_ids=None, target_hidden_for_compact=None, target_head_weight=None,
-                compact_teacher_chunk_size: Optional[int] = None):
+                compact_teacher_chunk_size: Optional[int] = None, loss_counts=None):
+        """``loss_counts`` (optional, not in the reference's signature): loss_counts[k] = number of rows whose loss mask at position
+        s + k is set, as HOST integers -- lets the engine run lm_head / CE on those rows only (``loss_mask_suffix_counts``)."""
         if past_key_values is not None:
             raise NotImplementedError("past_key_values is unused by EAGLE3 training (eagle3/model.py:262)")
         train = torch.is_grad_enabled() and self.training
@@ -124,7 +142,8 @@ class OnlineEagle3Model(nn.Module):
         out = self.engine.forward(
             input_ids=to(input_ids), attention_mask=attention_mask, loss_mask=to(loss_mask), hidden_states=to(hidden_states),
             target_hidden=to(target_hidden_for_compact), target_head_weight=target_head_weight,
-            target_logits=to(target) if target_hidden_for_compact is None else None, position_ids=to(position_ids), train=train)
+            target_logits=to(target) if target_hidden_for_compact is None else None, position_ids=to(position_ids), train=train,
+            loss_counts=loss_counts)
         plosses = torch.stack(out["plosses"])
         if train:
             plosses = _TTTStep.apply(self._anchor, self.engine, plosses)
@@ -203,6 +222,11 @@ class Eagle3TrainStrategy:
 
     def forward_loss(self, batch, ctx=None) -> StepOutput:
         self.validate_batch(batch)
+        # rows per TTT step that carry a loss (host integers): from the loader's metadata, or from the mask while it is still a CPU tensor
+        counts = getattr(batch, "metadata", {}).get("loss_mask_suffix_counts")
+        lm0 = batch.tensors.get("loss_mask")
+        if counts is None and lm0 is not None and not lm0.is_cuda:
+            counts = loss_mask_suffix_counts(lm0)
         t = self._resident(batch.tensors)
         target_repr = getattr(batch, "metadata", {}).get("target_repr")
         kwargs = {}
@@ -218,7 +242,7 @@ class Eagle3TrainStrategy:
             input_ids, target, loss_mask = t["input_ids"], t["target"], t["loss_mask"]
         plosses, acceptance_rates, acces, acc_corrects, acc_denoms, metric_losses, metric_loss_denoms = self.eagle3_model(
             input_ids=input_ids, attention_mask=t["attention_mask"], loss_mask=loss_mask, target=target,
-            hidden_states=t["hidden_state"], position_ids=t.get("position_ids"), **kwargs)
+            hidden_states=t["hidden_state"], position_ids=t.get("position_ids"), loss_counts=counts, **kwargs)
         weights = [self.ploss_decay ** i for i in range(len(plosses))]
         loss = sum(weights[i] * plosses[i] for i in range(len(plosses)))
         d = lambda xs: [x.detach() for x in xs]

@@ -89,6 +89,14 @@ class Eagle3Engine:
         self.T = int(ttt_length)
         self._diag_plan = diag_plan(self.T)      # launches of the blocked diagonal-branch backward, per sweep step
         self.blocked_diag = True                 # False (A/B, bench.py --diag-per-step): one sf_attn_bwd_pre per step, every pair at its step
+        # Loss-row compaction (round 4): lm_head forward, the fused CE and the lm_head input / weight gradients -- a third of the step's
+        # flops -- run only on the rows of a TTT step that carry a loss mask (real data: the assistant turns; padding never).  Needs the
+        # per-step row counts on the HOST (forward(loss_counts=...): the ingest has the mask in host memory; no device read-back);
+        # without them, or with fewer than 10 % of the rows masked out, the dense form runs.  Same losses / metrics / gradients: masked
+        # rows contribute exact zeros either way (bench.py --loss-mask-density D measures it; False = always dense).
+        self.compact_loss_rows = True
+        self._lm_compact_K = None                # rows of the compact lm_head stash of the last training forward (None: dense)
+        self._cnt_bad = None                     # device flag: the host-supplied row counts disagreed with the mask (read in backward)
         if not 1 <= self.T <= ops.MAX_DIAG + 1:
             raise ValueError(f"ttt_length must be in 1..{ops.MAX_DIAG + 1} (one diagonal branch per earlier TTT step)")
         self.decay = float(ploss_decay)
@@ -398,7 +406,7 @@ class Eagle3Engine:
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, *, input_ids, attention_mask, loss_mask, hidden_states, target_hidden=None,
-                target_head_weight=None, target_logits=None, position_ids=None, train: bool = True):
+                target_head_weight=None, target_logits=None, position_ids=None, train: bool = True, loss_counts=None):
         """One micro-step forward.  ``input_ids`` / ``target_*`` are already shifted by
         ``TargetHead.preprocess`` (target_head.py:103-108); ``loss_mask`` is [B,S] or [B,S,1].
         Returns the metric dict of ``Eagle3TrainStrategy.forward_loss`` (lists of 0-dim tensors)."""
@@ -535,10 +543,23 @@ class Eagle3Engine:
         ops.gemm_nt(b["en"], self.w_qkv[:, :H], b["epart"])
         if train:
             b["en2"][Np:].copy_(b["en"])
+        # ---- loss-row compaction of the lm_head part (see __init__): host-known row counts per step, or the dense form
+        cnt = None
+        if (self.compact_loss_rows and train and loss_counts is not None and lk is None and c.norm_output
+                and len(loss_counts) >= T):
+            cnt = [int(x) for x in loss_counts[:T]]
+            if not all(0 <= x <= N for x in cnt) or sum(cnt) > 0.9 * T * N:
+                cnt = None
+        cum = [0]
+        if cnt is not None:
+            for x in cnt:
+                cum.append(cum[-1] + x)
+        self._lm_compact_K = None
+        self._cnt_bad, cnt_probe = None, []
         for k in range(T):
             hn, qkv, pn, act, logits = b["hn"][k], b["qkv"][k], b["pn"][k], b["act"][k], b["logits"][k]
             # q/k/v of cat(input_layernorm(embed(ids<<k)), hidden_norm(h_k))   (llama3_eagle.py:1625-1630)
-            if k == 0 or not c.norm_output:     # (for k >= 1 the final norm of step k - 1 wrote hn[k] in the same pass over h[k])
+            if k == 0 or not c.norm_output or cnt is not None:     # (else: the final norm of step k - 1 wrote hn[k] in the same pass over h[k])
                 ops.rmsnorm_fwd(b["h"][k], f.view("midlayer.hidden_norm.weight"), eps, hn, b["rstd_h"][k])
             ops.gemm_nt_rowadd(hn, self.w_qkv[:, H:], qkv, b["epart"], S=S, Spad=Spad, off=k)
             if self.mrope:
@@ -560,6 +581,42 @@ class Eagle3Engine:
             ops.rmsnorm_fwd(b["h1"][k], f.view("midlayer.post_attention_layernorm.weight"), eps, pn, b["rstd_p"][k])
             ops.gemm_nt_swiglu_fwd(pn, self.w_gu, b["gu"][k], act)      # gate|up projection, SwiGLU in its epilogue
             ops.gemm_nt(act, f.view("midlayer.mlp.down_proj.weight"), b["h"][k + 1], residual=b["h1"][k], workspace=b["nt_ws"])
+            if cnt is not None:
+                # compact form: the rows of this step that carry a loss mask (lm_pad[b, s + k] != 0), in token order
+                Nc, lo = cnt[k], cum[k]
+                if Nc == 0:
+                    b["metrics"][k].zero_()
+                    if train:
+                        b["dln"][k].zero_()
+                        b["rstd_n"][k].zero_()
+                    continue
+                # (one slot more than the count: entry Nc - 1 must be a row and entry Nc the fill value -- checked on the device,
+                #  read back with the upstream gradient at the end of the backward sweep; a wrong count never indexes out of range)
+                idx = torch.nonzero_static(b["lm"][:, k:k + S].reshape(-1), size=Nc + 1, fill_value=-1).view(-1)
+                cnt_probe.append(idx[Nc - 1:Nc + 1])
+                rows_k = idx[:Nc].clamp_min(0)
+                lnc, logc = b["ln_s"][lo:lo + Nc], b["logits_s"][lo:lo + Nc]
+                rstd_c = b["rows"].view(-1)[3 * N - Nc:3 * N]       # (scratch: the tail of the row-statistics buffer, free until the CE)
+                ops.rmsnorm_fwd(b["h"][k + 1], f.view("norm.weight"), eps, lnc, rstd_c, ids_pad=rows_k, S=Nc, Spad=Nc, off=0, rows=Nc)
+                if train:       # the norm backward runs over ALL rows: zero rstd where dy is zero keeps dx = 0 finite
+                    b["rstd_n"][k].zero_()
+                    b["rstd_n"][k].index_copy_(0, rows_k, rstd_c)
+                ops.gemm_nt(lnc, f.view("lm_head.weight"), logc)
+                rows_c = b["rows"].view(-1)[:3 * Nc].view(3, Nc)
+                ce_kw = dict(S=S, Spad=Spad, off=k, pos_mask_pad=b["pm"], loss_mask_pad=b["lm"], tgt_ids_pad=b["tids"], pod_scale_pad=b["pod"],
+                             tsum_pad=b["tsum"], d2t=self._d2t, grad_scale=(self.decay ** k) / N, write_grad=train, row_loss=rows_c[0],
+                             row_correct=rows_c[1], row_accept=rows_c[2], row_map=rows_k)
+                if zt is not None:
+                    ops.ce_fused_zt(logc, zt[0], zt[1], zt[2], **ce_kw)
+                else:
+                    ops.ce_fused(logc, self._soft[1], **ce_kw)
+                ops.reduce_sum(rows_c, Nc, 3, b["metrics"][k], 1.0)
+                if train:
+                    dlnc = b["dxh"][:Nc]            # (a backward work buffer, idle during the forward)
+                    ops.gemm_nt(logc, self.wlmT, dlnc, workspace=b["nt_ws"])
+                    b["dln"][k].zero_()
+                    b["dln"][k].index_copy_(0, rows_k, dlnc)
+                continue
             if c.norm_output:   # compute_logits (llama3_eagle.py:1772-1777)
                 ln = b["ln"][k]
                 if k + 1 < T:       # ... and the next step's hidden_norm of the same h[k+1]: one pass, one row statistic
@@ -592,6 +649,15 @@ class Eagle3Engine:
             if train:
                 ops.gemm_nt(logits, self.wlmT, b["dln"][k], workspace=b["nt_ws"])        # lm_head dgrad, taken now
 
+        if cnt_probe:
+            pr = torch.stack(cnt_probe)
+            self._cnt_bad = ((pr[:, 0] < 0) | (pr[:, 1] >= 0)).any()
+        if cnt is not None and train:
+            # the compact lm_head stash: rows [0, cum[T]) of logits_s / ln_s, zero rows up to the next multiple of 64 (K of sf_gemm_tn)
+            Kc = max(64, (cum[T] + 63) // 64 * 64)
+            b["ln_s"][cum[T]:Kc].zero_()
+            b["logits_s"][cum[T]:Kc].zero_()
+            self._lm_compact_K = Kc
         self._fwd_state = (B, S) if train else None
         # ---- metrics (tiny integer-mask sums; eagle3/model.py:161-190, core/lk_loss.py:43-80)
         met = b["metrics"]
@@ -689,8 +755,11 @@ class Eagle3Engine:
             # dh / dgu / dh1 / dqkv are written straight into their slot of the weight-gradient stash.
             dh, dgu, dh1, dqkv = b["dh"][k], b["dgu"][k], b["dh1"][k], b["dqkv"][k]
             if pending is not None:
+                # (one rstd serves both norms of h[k+1]; in the compact form rstd_n[k] is zero on rows without a loss -- the hidden
+                # norm's own copy, computed over all rows by the next step's forward, is the same value)
                 norm_bwd2("norm.weight", b["dln"][k], f.view("norm.weight"), "midlayer.hidden_norm.weight", pending[0],
-                          f.view("midlayer.hidden_norm.weight"), b["h"][k + 1], b["rstd_n"][k], dx=dh, add=pending[1])
+                          f.view("midlayer.hidden_norm.weight"), b["h"][k + 1],
+                          b["rstd_h"][k + 1] if self._lm_compact_K is not None else b["rstd_n"][k], dx=dh, add=pending[1])
                 pending = None
             elif c.norm_output:
                 norm_bwd("norm.weight", b["dln"][k], b["h"][k + 1], f.view("norm.weight"), b["rstd_n"][k], dx=dh, add=dh_next)
@@ -794,7 +863,8 @@ class Eagle3Engine:
         beta = 0.0 if self.micro_in_window == 0 else 1.0
         ln_s = b["ln_s"] if c.norm_output else b["h_s"]
         jobs = [
-            ("lm_head.weight", "lm_head.weight", [(b["logits_s"], ln_s, f.gview("lm_head.weight"))]),
+            ("lm_head.weight", "lm_head.weight", [(b["logits_s"][:self._lm_compact_K], ln_s[:self._lm_compact_K], f.gview("lm_head.weight"))
+                                                  if self._lm_compact_K is not None else (b["logits_s"], ln_s, f.gview("lm_head.weight"))]),
             ("midlayer.mlp.gate_proj.weight", "midlayer.mlp.up_proj.weight", [(b["dgu_s"], b["pn_s"], self.g_gu)]),
             ("midlayer.mlp.down_proj.weight", "midlayer.mlp.down_proj.weight",
              [(b["dh_s"], b["act_s"], f.gview("midlayer.mlp.down_proj.weight"))]),

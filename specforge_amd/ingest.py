@@ -34,7 +34,7 @@ from typing import Dict, Iterator, List, Optional, Sequence
 
 import torch
 
-from .eagle3 import TrainBatch
+from .eagle3 import TrainBatch, loss_mask_suffix_counts
 from .training import distributed_sampler_indices
 
 
@@ -316,13 +316,14 @@ class HiddenStateIngest:
                     if slot.released is not None:      # the consumer's stream must be past this slot's tensors
                         slot.released.synchronize()
                     L = self._fill(slot, g)
+                    counts = loss_mask_suffix_counts(slot.h["loss_mask"][:len(g), :L])   # (host side: the engine's loss-row compaction)
                     if self._copy_stream is not None:
                         with torch.cuda.stream(self._copy_stream):
                             for k in slot.h:
                                 slot.dview(k, L)[:len(g)].copy_(slot.h[k][:len(g), :L], non_blocking=True)
                             slot.copied = torch.cuda.Event()
                             slot.copied.record()
-                    ready.put((si, L, g))
+                    ready.put((si, L, g, counts))
                 ready.put(None)
             except BaseException as e:  # surface loader failures in the consumer
                 ready.put(e)
@@ -343,7 +344,7 @@ class HiddenStateIngest:
                     break
                 if isinstance(item, BaseException):
                     raise item
-                si, L, g = item
+                si, L, g, counts = item
                 slot = self._slots[si]
                 nb = len(g)
                 if self._copy_stream is not None:
@@ -352,7 +353,7 @@ class HiddenStateIngest:
                 else:
                     tensors = {k: v[:nb, :L].clone() for k, v in slot.h.items()}
                 prev = si
-                yield TrainBatch(tensors, {"target_repr": "hidden_state", "sample_files": list(g)})
+                yield TrainBatch(tensors, {"target_repr": "hidden_state", "sample_files": list(g), "loss_mask_suffix_counts": counts})
         finally:
             # the consumer may abandon the iterator mid-epoch (max_steps reached): release the loader thread
             stop.set()

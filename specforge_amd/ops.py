@@ -97,29 +97,32 @@ def gemm_nt_rowadd(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, addend: 
 
 def ce_fused(logits: torch.Tensor, target_pad: torch.Tensor, *, S: int, Spad: int, off: int, pos_mask_pad, loss_mask_pad,
              tgt_ids_pad=None, pod_scale_pad=None, tsum_pad=None, d2t=None, grad_scale: float = 1.0, write_grad: bool = True,
-             row_loss, row_correct, row_accept, row_pred=None):
+             row_loss, row_correct, row_accept, row_pred=None, row_map=None):
+    """``row_map`` [rows] int64 (optional): logits row r is token row row_map[r] of the [B, S] grid (loss-row compaction)"""
     L = _lib.lib()
     rows, V = logits.shape
     assert target_pad.dtype == torch.float32 and target_pad.is_contiguous() and target_pad.shape[-1] == V
+    assert row_map is None or (row_map.dtype == torch.int64 and row_map.numel() >= rows and row_map.is_contiguous())
     _lib.check(L.sf_ce_fused(_p(logits), _dt(logits), _rowmajor(logits), rows, V, _p(target_pad), S, Spad, off,
                              _p(pos_mask_pad), _p(loss_mask_pad), _p(tgt_ids_pad), _p(pod_scale_pad), _p(tsum_pad),
                              _p(d2t), grad_scale, 1 if write_grad else 0, _p(row_loss), _p(row_correct), _p(row_accept),
-                             _p(row_pred), _stream()), "sf_ce_fused")
+                             _p(row_pred), _p(row_map), _stream()), "sf_ce_fused")
 
 
 def ce_fused_zt(logits: torch.Tensor, zt: torch.Tensor, zmd_pad: torch.Tensor, zinv_pad: torch.Tensor, *, S: int, Spad: int, off: int,
                 pos_mask_pad, loss_mask_pad, tgt_ids_pad=None, pod_scale_pad=None, tsum_pad, d2t=None, grad_scale: float = 1.0,
-                write_grad: bool = True, row_loss, row_correct, row_accept, row_pred=None):
+                write_grad: bool = True, row_loss, row_correct, row_accept, row_pred=None, row_map=None):
     """ce_fused with the soft target re-formed from the teacher's stored draft logits ``zt`` [B*S, >= V] (natural rows) and the
     per-row (max, 1 / sum-exp) of teacher_reduce_perm"""
     L = _lib.lib()
     rows, V = logits.shape
-    assert zt.dtype == torch.bfloat16 and zt.shape[0] >= rows and zt.shape[1] >= V
+    assert zt.dtype == torch.bfloat16 and (row_map is not None or zt.shape[0] >= rows) and zt.shape[1] >= V
+    assert row_map is None or (row_map.dtype == torch.int64 and row_map.numel() >= rows and row_map.is_contiguous())
     assert zmd_pad.dtype == zinv_pad.dtype == torch.float32 and zmd_pad.is_contiguous() and zinv_pad.is_contiguous()
     _lib.check(L.sf_ce_fused_zt(_p(logits), _dt(logits), _rowmajor(logits), rows, V, _p(zt), _rowmajor(zt), _p(zmd_pad), _p(zinv_pad), S,
                                 Spad, off, _p(pos_mask_pad), _p(loss_mask_pad), _p(tgt_ids_pad), _p(pod_scale_pad), _p(tsum_pad), _p(d2t),
                                 grad_scale, 1 if write_grad else 0, _p(row_loss), _p(row_correct), _p(row_accept), _p(row_pred),
-                                _stream()), "sf_ce_fused_zt")
+                                _p(row_map), _stream()), "sf_ce_fused_zt")
 
 
 def ce_lk_grad(logits: torch.Tensor, target_pad: torch.Tensor, *, S: int, Spad: int, off: int, pos_mask_pad, pod_scale_pad,

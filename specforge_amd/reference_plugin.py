@@ -33,7 +33,7 @@ from typing import Any, Optional
 
 import torch
 
-from .eagle3 import Eagle3TrainStrategy, OnlineEagle3Model
+from .eagle3 import Eagle3TrainStrategy, OnlineEagle3Model, loss_mask_suffix_counts
 from .model import DraftConfig, Eagle3DraftMethods
 from .training import BF16Optimizer, HipDPTrainingBackend
 
@@ -241,16 +241,24 @@ def feature_loader_class():
             for chunk, b in zip(chunks, ing.stream(groups)):
                 yield RefTrainBatch(sample_ids=[r.sample_id for r in chunk], strategy=self.strategy, tensors=b.tensors,
                                     metadata={"target_repr": chunk[0].metadata.get("target_repr"),
-                                              "ttt_length": chunk[0].metadata.get("ttt_length")})
+                                              "ttt_length": chunk[0].metadata.get("ttt_length"),
+                                              # (host-side row counts for the engine's loss-row compaction; the reference ignores extra keys)
+                                              "loss_mask_suffix_counts": b.metadata.get("loss_mask_suffix_counts")})
 
         def _iter_staged(self, chunks, dev):
             """the reference's own materialisation (store.get + transform + collate) one batch ahead on a thread, then
             pinned slot + copy stream instead of the strategy's pageable ``.to(device)``"""
             from concurrent.futures import ThreadPoolExecutor
 
+            def counted(batch):
+                lm = batch.tensors.get("loss_mask")
+                if lm is not None and not lm.is_cuda and isinstance(batch.metadata, dict):
+                    batch.metadata.setdefault("loss_mask_suffix_counts", loss_mask_suffix_counts(lm))
+                return batch
+
             if dev.type != "cuda":
                 for chunk in chunks:
-                    yield self._make_batch(chunk)
+                    yield counted(self._make_batch(chunk))
                 return
             if self._stager is None:
                 self._stager = PinnedStager(dev)
@@ -260,6 +268,7 @@ def feature_loader_class():
                     batch = fut.result()
                     if i + 1 < len(chunks):
                         fut = ex.submit(self._make_batch, chunks[i + 1])
+                    counted(batch)
                     batch.tensors = self._stager.stage(batch.tensors)
                     yield batch
 

@@ -148,6 +148,44 @@ def test_blocked_and_per_step_diagonal_backward_agree(backend, golden_dir):
     torch.testing.assert_close(grads[0], grads[1], rtol=2e-2, atol=4e-3 * float(grads[1].abs().max()))
 
 
+@pytest.mark.parametrize("mask", ["random", "head_only", "golden"])
+def test_loss_row_compaction_equals_the_dense_form(backend, golden_dir, mask):
+    """engine.compact_loss_rows (round 4): lm_head / CE / lm_head gradients over the rows with loss_mask[b, s + k] != 0 only, from
+    host-side row counts -- same losses, metrics and gradients as the dense form (masked rows contribute exact zeros there).
+    ``head_only``: the mask ends at position 2, so TTT steps 3.. have no row at all; wrong counts are refused in backward."""
+    blob = torch.load(os.path.join(golden_dir, "eagle31_gqa_fp32.pt"), weights_only=False)
+    lm = blob["batch"]["loss_mask"].clone()
+    if mask == "random":
+        lm = (torch.rand(lm.shape, generator=torch.Generator().manual_seed(5)) < 0.4).to(lm.dtype)
+    elif mask == "head_only":
+        lm.zero_()
+        lm[:, :3] = 1
+    blob["batch"] = dict(blob["batch"], loss_mask=lm)
+    runs = []
+    for compact in (True, False):
+        cfg, model, eagle, strat = _build(blob, backend)
+        eagle.train()
+        eagle.engine.compact_loss_rows = compact
+        out = strat.forward_loss(_batch(blob, backend))
+        assert (eagle.engine._lm_compact_K is not None) == (compact and float(lm.float().mean()) < 0.85)
+        out.loss.backward()
+        runs.append((out, eagle.engine.flat.grad.float().cpu().clone()))
+    (a, ga), (d, gd) = runs
+    for key in ("plosses", "acces", "acceptance_rates", "acc_corrects", "acc_denoms"):
+        torch.testing.assert_close(torch.stack(a.metrics[key]).float().cpu(), torch.stack(d.metrics[key]).float().cpu(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ga, gd, rtol=2e-2, atol=4e-3 * float(gd.abs().max()))
+    if mask == "random":
+        cfg, model, eagle, strat = _build(blob, backend)
+        eagle.train()
+        batch = _batch(blob, backend)
+        from specforge_amd.eagle3 import loss_mask_suffix_counts
+        wrong = loss_mask_suffix_counts(lm)
+        wrong[2] += 1
+        batch.metadata["loss_mask_suffix_counts"] = wrong
+        with pytest.raises(RuntimeError, match="loss_counts"):
+            strat.forward_loss(batch).loss.backward()
+
+
 def test_accumulation_window_and_eval_mode(backend, golden_dir):
     """two micro-steps accumulate (DDP no_sync semantics, training/backend.py:310-320); eval forward leaves no state"""
     blob = torch.load(os.path.join(golden_dir, "eagle3_tiny_bf16.pt"), weights_only=False)

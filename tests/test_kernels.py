@@ -530,6 +530,26 @@ def test_ce_fused_from_teacher_logits_equals_materialised_targets(backend, dtype
         for a, b_ in zip(*outs):
             assert torch.equal(a, b_)
         assert float(outs[0][1].abs().sum()) > 0          # (some rows carry a position mask at this offset)
+        # row_map (ABI 5, loss-row compaction): the kernels over a COMPACT copy of the rows with loss_mask[b, s + off] != 0 give, row
+        # for row, the bits of the dense call -- and the rows left out are exactly the ones the dense call zeroes
+        keep = torch.nonzero(lm_pad[:, off:off + S].reshape(-1)).view(-1)
+        for form in ("tp", "zt"):
+            xc = d(logits[keep].clone())
+            rows = [torch.zeros(keep.numel(), device=backend) for _ in range(3)]
+            pred = torch.zeros(keep.numel(), dtype=torch.int32, device=backend)
+            common.update(row_loss=rows[0], row_correct=rows[1], row_accept=rows[2], row_pred=pred, row_map=d(keep))
+            if form == "tp":
+                ops.ce_fused(xc, tp, **common)
+            else:
+                ops.ce_fused_zt(xc, d(zd), zmd, zinv, **common)
+            dense = outs[0]
+            assert torch.equal(xc.cpu(), dense[0][keep])
+            for i in range(3):
+                assert torch.equal(rows[i].cpu(), dense[1 + i][keep])
+            assert torch.equal(pred.cpu(), dense[4][keep])
+            left = torch.ones(B * S, dtype=torch.bool)
+            left[keep] = False
+            assert float(dense[0][left].float().abs().max()) == 0 and all(float(dense[1 + i][left].abs().max()) == 0 for i in range(3))
 
 
 @pytest.mark.parametrize("M,Vt,Vd,K", [(512, 1000, 256, 512),     # reduced range 256 .. 999: 6 blocks, the last one partly past Vt

@@ -181,7 +181,12 @@ def test_plugin_loader_yields_the_reference_loaders_batches(ref, golden_dir, tmp
         return cls(LocalFeatureStore("t"), refs=refs, **kw)
 
     def same(a, b):
-        assert a.sample_ids == b.sample_ids and a.strategy == b.strategy and a.metadata == b.metadata
+        from specforge_amd.eagle3 import loss_mask_suffix_counts
+
+        # (one extra metadata key: the per-TTT-step loss-row counts, computed where the mask is in host memory -- the engine's
+        #  loss-row compaction reads them; the reference ignores unknown keys)
+        extra = {"loss_mask_suffix_counts": loss_mask_suffix_counts(b.tensors["loss_mask"])}
+        assert a.sample_ids == b.sample_ids and a.strategy == b.strategy and a.metadata == dict(b.metadata, **extra)
         assert set(a.tensors) == set(b.tensors)
         for k, v in b.tensors.items():
             assert a.tensors[k].shape == v.shape and a.tensors[k].dtype == v.dtype and torch.equal(a.tensors[k].cpu(), v), k
