@@ -96,6 +96,7 @@ class Eagle3Engine:
         # rows contribute exact zeros either way (bench.py --loss-mask-density D measures it; False = always dense).
         self.compact_loss_rows = True
         self._lm_compact_K = None                # rows of the compact lm_head stash of the last training forward (None: dense)
+        self._teacher_compacted = False          # last forward: target ids / soft targets exist only where the loss mask is set
         self._cnt_bad = None                     # device flag: the host-supplied row counts disagreed with the mask (read in backward)
         if not 1 <= self.T <= ops.MAX_DIAG + 1:
             raise ValueError(f"ttt_length must be in 1..{ops.MAX_DIAG + 1} (one diagonal branch per earlier TTT step)")
@@ -405,6 +406,51 @@ class Eagle3Engine:
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
+    def _teacher_compact(self, b, th, Nm, zd, Vz, perm, head, part, cnt_probe, B, S, Spad) -> bool:
+        """The teacher of a sparse loss mask (loss-row compaction, see __init__): TTT step k scores row (b, s) against position s + k only
+        where loss_mask[b, s + k] != 0, so only the Nm = loss_counts[0] positions with a loss mask need target logits.  Their hidden rows
+        are gathered, go through the permuted head GEMM + reduction in chunks of ``teacher_rows``, and the stored draft logits / per-row
+        scalars are scattered back to their natural positions (what the fused CE addresses); every other position gets position mask 0 and
+        target id 0 (nothing reads its soft target; ``last_artifacts`` are meaningful where the loss mask is set).  -> False when a chunk
+        would not take the reduced GEMM form (the caller runs the dense teacher)."""
+        Vd, Vt, Ht = self.cfg.draft_vocab_size, head.shape[0], th.shape[1]
+        nch = max(1, -(-Nm // self.teacher_rows))
+        m = -(-Nm // nch)
+        sizes = [min(m, Nm - i * m) for i in range(nch)] if Nm else []
+        if Nm and not all(x > 0 and ops.gemm_nt_teacher_reduces(x, Vt, Ht, Vd) for x in sizes):
+            return False
+        for nm in ("pm", "tids"):
+            b[nm].zero_()
+        if Nm == 0:
+            return True
+        idx = torch.nonzero_static(b["lm"][:, :S].reshape(-1), size=Nm + 1, fill_value=-1).view(-1)
+        cnt_probe.append(idx[Nm - 1:Nm + 1])
+        rows = idx[:Nm].clamp_min(0)
+        pidx = rows + torch.div(rows, S, rounding_mode="floor") * (Spad - S)         # index into the padded [B, Spad] arrays
+        thc = self._carve("teacher_thc", Nm, Ht, invalidate=False)
+        torch.index_select(th, 0, rows, out=thc)
+        zc = self._carve("teacher_zc", m, Vz, invalidate=False)
+        f32 = {nm: self._carve("teacher_c_" + nm, 1, Nm, dtype=torch.float32, invalidate=False) for nm in ("pod", "tsum", "zmd", "zinv")}
+        ids_c = self._carve("teacher_c_tids", 1, Nm, dtype=torch.int64, invalidate=False)
+        pm_c = self._carve("teacher_c_pm", 1, Nm, dtype=torch.int32, invalidate=False)
+        ones = self._carve("teacher_c_ones", 1, Nm, dtype=torch.int32, invalidate=False)
+        ones.fill_(1)
+        lo = 0
+        for x in sizes:
+            sl = slice(lo, lo + x)
+            vz, nparts = ops.gemm_nt_teacher(thc[sl], head, zc[:x], part, Vd=Vd)
+            assert vz == Vz and nparts > 0
+            ops.teacher_reduce_perm(zc[:x], Vt=Vt, Vd=Vd, perm=perm, t2d_u8=self._t2d_u8, part=part, nparts=nparts, target_p_pad=None,
+                                    loss_mask_pad=ones[:, sl], S=x, Spad=x, pod_scale_pad=f32["pod"][:, sl], tsum_pad=f32["tsum"][:, sl],
+                                    ids_pad=ids_c[:, sl], pos_mask_pad=pm_c[:, sl], zmd_pad=f32["zmd"][:, sl], zinv_pad=f32["zinv"][:, sl])
+            zd.index_copy_(0, rows[sl], zc[:x])
+            lo += x
+        for nm in ("pod", "tsum", "zmd", "zinv"):
+            b[nm].view(-1).index_copy_(0, pidx, f32[nm].view(-1))
+        b["tids"].view(-1).index_copy_(0, pidx, ids_c.view(-1))
+        b["pm"].view(-1).index_copy_(0, pidx, pm_c.view(-1))
+        return True
+
     def forward(self, *, input_ids, attention_mask, loss_mask, hidden_states, target_hidden=None,
                 target_head_weight=None, target_logits=None, position_ids=None, train: bool = True, loss_counts=None):
         """One micro-step forward.  ``input_ids`` / ``target_*`` are already shifted by
@@ -467,6 +513,20 @@ class Eagle3Engine:
         hs = hidden_states.reshape(N, 3 * Ht)
         self._last_hs = hs
 
+        # ---- loss-row compaction (see __init__): host-known row counts per step, or the dense form
+        cnt = None
+        if (self.compact_loss_rows and train and loss_counts is not None and self.lk_loss_type is None and c.norm_output
+                and len(loss_counts) >= T):
+            cnt = [int(x) for x in loss_counts[:T]]
+            if not all(0 <= x <= N for x in cnt) or sum(cnt) > 0.9 * T * N:
+                cnt = None
+        cum = [0]
+        if cnt is not None:
+            for x in cnt:
+                cum.append(cum[-1] + x)
+        self._cnt_bad, cnt_probe = None, []
+        self._teacher_compacted = False
+
         # ---- teacher: target logits (chunked GEMM, bf16 like TargetHead.forward) -> soft targets
         zt = None        # (zd, zmd, zinv) when the soft targets stay un-materialised (see below); else b["tp"] holds them
         if target_logits is not None:
@@ -493,6 +553,9 @@ class Eagle3Engine:
                 zd = self._carve("teacher_zd", N, Vz, invalidate=False)
                 zt = (zd, b["zmd"], b["zinv"])
                 self._soft = ("zt", zt)
+                if cnt is not None and self._teacher_compact(b, th.reshape(N, Ht), cnt[0], zd, Vz, perm, head, part, cnt_probe, B, S, Spad):
+                    chunks = []         # done: only the positions with a loss mask went through the head
+                    self._teacher_compacted = True
             else:
                 zbuf = self._carve("teacher_z", min(cb, B) * S, Vt, invalidate=False)   # scratch: no cached view aliases it
             for b0, nb in chunks:
@@ -543,19 +606,7 @@ class Eagle3Engine:
         ops.gemm_nt(b["en"], self.w_qkv[:, :H], b["epart"])
         if train:
             b["en2"][Np:].copy_(b["en"])
-        # ---- loss-row compaction of the lm_head part (see __init__): host-known row counts per step, or the dense form
-        cnt = None
-        if (self.compact_loss_rows and train and loss_counts is not None and lk is None and c.norm_output
-                and len(loss_counts) >= T):
-            cnt = [int(x) for x in loss_counts[:T]]
-            if not all(0 <= x <= N for x in cnt) or sum(cnt) > 0.9 * T * N:
-                cnt = None
-        cum = [0]
-        if cnt is not None:
-            for x in cnt:
-                cum.append(cum[-1] + x)
         self._lm_compact_K = None
-        self._cnt_bad, cnt_probe = None, []
         for k in range(T):
             hn, qkv, pn, act, logits = b["hn"][k], b["qkv"][k], b["pn"][k], b["act"][k], b["logits"][k]
             # q/k/v of cat(input_layernorm(embed(ids<<k)), hidden_norm(h_k))   (llama3_eagle.py:1625-1630)

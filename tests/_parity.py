@@ -94,6 +94,7 @@ def run_hip(c, params, embed, head_w, t2d, d2t, batch, ttt, dev):
                acceptance=torch.stack(out.metrics["acceptance_rates"]).float().cpu(),
                acc_denoms=torch.stack(out.metrics["acc_denoms"]).float().cpu(),
                ids=eagle.last_artifacts["target_token_ids"].cpu(), pos_mask=eagle.last_artifacts["position_mask"].int().cpu(),
+               teacher_compacted=eagle.engine._teacher_compacted,
                grads={k: named[k].grad.float().cpu() for k in params})
     del model, eagle, strat, out
     torch.cuda.empty_cache()
@@ -119,12 +120,17 @@ def compare(name, c, *, loss_tol=5e-3, ids_min=1.0, grad_cap=6e-2, yardstick_fac
     t_ref = time.time() - t0
     hip = run_hip(c, *case[1:], ttt, dev)
     rep = dict(case=name, dims={k: v for k, v in c.items()}, oracle_fp32_seconds=round(t_ref, 1))
+    # sparse loss mask (ragged lengths): the engine ran the teacher only on positions that carry a loss (loss-row compaction) -- target
+    # ids exist there, every other position holds id 0 and position mask 0 (which is what the reference's position mask has there too)
+    on = case[6]["loss_mask"].bool() if hip["teacher_compacted"] else torch.ones_like(case[6]["loss_mask"], dtype=torch.bool)
+    assert int(hip["ids"][~on].abs().sum()) == 0
+    rep["teacher_compacted"], rep["ids_compared_on"] = bool(hip["teacher_compacted"]), float(on.float().mean())
     rep["hip_vs_fp32"] = dict(
         plosses=hip["plosses"].tolist(), plosses_ref=ref["plosses"].tolist(),
         ploss_max_abs=float((hip["plosses"] - ref["plosses"]).abs().max()), loss=float(hip["loss"]), loss_ref=float(ref["loss"]),
         acceptance_max_abs=float((hip["acceptance"] - ref["acceptance"]).abs().max()),
         acc_max_abs=float((hip["acces"] - ref["acces"]).abs().max()),
-        ids_agree=float((hip["ids"] == ref["ids"]).float().mean()),
+        ids_agree=float((hip["ids"] == ref["ids"])[on].float().mean()),
         pos_mask_agree=float((hip["pos_mask"] == ref["pos_mask"]).float().mean()),
         grads=grad_errors(hip["grads"], ref["grads"]))
     if True:
@@ -132,7 +138,7 @@ def compare(name, c, *, loss_tol=5e-3, ids_min=1.0, grad_cap=6e-2, yardstick_fac
         rep["oracle_bf16_vs_fp32"] = dict(
             ploss_max_abs=float((bf["plosses"] - ref["plosses"]).abs().max()),
             ids_agree=float((bf["ids"] == ref["ids"]).float().mean()), grads=grad_errors(bf["grads"], ref["grads"]))
-        rep["hip_vs_oracle_bf16"] = dict(ids_agree=float((hip["ids"] == bf["ids"]).float().mean()),
+        rep["hip_vs_oracle_bf16"] = dict(ids_agree=float((hip["ids"] == bf["ids"])[on].float().mean()),
                                          pos_mask_agree=float((hip["pos_mask"] == bf["pos_mask"]).float().mean()))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"parity_{name}.json"), "w") as f:

@@ -66,7 +66,8 @@ def test_config_micro_step_matches_oracle(name):
     # integer artefacts: teacher argmax ids / position mask.  The teacher logits come from two different bf16 GEMMs
     # (torch CPU vs MFMA) whose last-ulp rounding can differ, so exact ties may resolve differently: require >= 99.5 %.
     ids = eagle.last_artifacts["target_token_ids"].cpu()
-    agree = float((ids == ref.target_token_ids).float().mean())
+    on = batch["loss_mask"].bool() if eagle.engine._teacher_compacted else torch.ones_like(ids, dtype=torch.bool)   # (loss-row compaction)
+    agree = float((ids == ref.target_token_ids)[on].float().mean())
     assert agree >= 0.995, agree
     tol = 2e-2
     pl = torch.stack(out.metrics["plosses"]).float().cpu()
@@ -138,7 +139,8 @@ def test_odd_dimension_relations_match_oracle(backend, name):
                                         {"target_repr": "hidden_state"}))
     out.loss.backward()
     ids = eagle.last_artifacts["target_token_ids"].cpu()
-    assert float((ids == ref.target_token_ids).float().mean()) >= 0.995         # (CPU bf16 GEMM on the other side: exact ties may flip)
+    on = batch["loss_mask"].bool() if eagle.engine._teacher_compacted else torch.ones_like(ids, dtype=torch.bool)
+    assert float((ids == ref.target_token_ids)[on].float().mean()) >= 0.995         # (CPU bf16 GEMM on the other side: exact ties may flip)
     torch.testing.assert_close(torch.stack(out.metrics["plosses"]).float().cpu(), torch.stack([x.detach().float() for x in ref.plosses]),
                                rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(torch.stack(out.metrics["acc_denoms"]).cpu(), torch.stack(ref.acc_denoms).float())

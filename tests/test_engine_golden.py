@@ -342,6 +342,56 @@ def test_unmaterialised_soft_targets_equal_the_materialised_path(backend):
     torch.testing.assert_close(met_a["plosses"], torch.stack([x.detach().float() for x in ref.plosses]), rtol=3e-2, atol=3e-2)
 
 
+def test_teacher_runs_only_on_positions_with_a_loss_mask(backend):
+    """loss-row compaction, teacher side: with host-known row counts and a sparse loss mask the head GEMM + reduction run over the
+    gathered positions with loss_mask != 0 only (two chunks here) and their stored logits / row scalars are scattered back.  Against the
+    dense form of the same step: position mask everywhere, target ids where the loss mask is set, every metric bit for bit, gradients
+    to summation order (the lm_head weight gradient contracts a compact stash)."""
+    kw = dict(hidden_size=64, intermediate_size=96, num_attention_heads=2, num_key_value_heads=1, vocab_size=640,
+              draft_vocab_size=256, head_dim=64, target_hidden_size=512, max_position_embeddings=256, rms_norm_eps=1e-5)
+    B, S, T = 4, 160, 3
+    oc = O.DraftConfig(**kw)
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(18)
+    params = {k: (v.float() * 4).to(bf) if v.dim() > 1 else (1 + 0.1 * torch.randn(v.shape, generator=g)).to(bf)
+              for k, v in O.init_params(oc, seed=17).items()}
+    embed = (torch.randn(640, 64, generator=g) * 0.5).to(bf)
+    head_w = (torch.randn(640, 512, generator=g) * 0.2).to(bf)
+    t2d, d2t = O.make_vocab_mapping(640, 256, seed=15)
+    batch = O.make_batch(oc, B, S, seed=19, dtype=bf, lengths=[S, 150, 131, 100])
+    lm = batch["loss_mask"].clone()
+    lm[:, :8] = 0                          # (a prompt prefix without loss)
+    lm[1, 40:60] = 0
+
+    def run(compact):
+        model = LlamaForCausalLMEagle3(DraftConfig(**kw), device=backend)
+        sd = dict(params)
+        sd["embed_tokens.weight"], sd["t2d"], sd["d2t"] = embed, t2d, d2t
+        model.load_state_dict(sd)
+        eagle = OnlineEagle3Model(model, length=T).train()
+        eagle.engine.compact_loss_rows = compact
+        eagle.engine.teacher_rows = 320                                      # 2 chunks of the ~480 gathered positions
+        strat = Eagle3TrainStrategy(eagle, target_head=TargetHead(head_w.to(backend)))
+        out = strat.forward_loss(TrainBatch(dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], loss_mask=lm,
+                                                 hidden_state=batch["hidden_state"].to(backend), target=batch["target"].to(backend)),
+                                            {"target_repr": "hidden_state"}))
+        out.loss.backward()
+        assert eagle.engine._soft[0] == "zt" or str(backend) != "cpu"
+        mets = {k: torch.stack(v).float().cpu() for k, v in out.metrics.items() if isinstance(v, list)}
+        return mets, eagle.engine.flat.grad.float().cpu().clone(), eagle.last_artifacts["target_token_ids"].cpu(), \
+            eagle.last_artifacts["position_mask"].cpu(), "teacher_zc" in eagle.engine._arena
+
+    met_c, grad_c, ids_c, pm_c, used_c = run(True)
+    met_d, grad_d, ids_d, pm_d, used_d = run(False)
+    if str(backend) == "cpu":
+        assert used_c and not used_d
+    on = lm.bool()
+    assert torch.equal(pm_c, pm_d) and torch.equal(ids_c[on], ids_d[on]) and int(ids_c[~on].abs().sum()) == 0
+    for k in met_c:
+        assert torch.equal(met_c[k], met_d[k]), k
+    torch.testing.assert_close(grad_c, grad_d, rtol=2e-2, atol=4e-3 * float(grad_d.abs().max()))
+
+
 def test_variable_length_batches_share_one_arena(backend, golden_dir):
     """the collator pads every batch to its own longest sample, so real data brings a new (B, S)
     almost every step.  All shapes run inside the storage reserved for the largest one -- HBM does not grow -- and a
