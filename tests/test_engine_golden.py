@@ -379,14 +379,16 @@ def test_teacher_runs_only_on_positions_with_a_loss_mask(backend):
         assert eagle.engine._soft[0] == "zt" or str(backend) != "cpu"
         mets = {k: torch.stack(v).float().cpu() for k, v in out.metrics.items() if isinstance(v, list)}
         return mets, eagle.engine.flat.grad.float().cpu().clone(), eagle.last_artifacts["target_token_ids"].cpu(), \
-            eagle.last_artifacts["position_mask"].cpu(), "teacher_zc" in eagle.engine._arena
+            eagle.last_artifacts["position_mask"].cpu(), eagle.engine._teacher_compacted
 
     met_c, grad_c, ids_c, pm_c, used_c = run(True)
     met_d, grad_d, ids_d, pm_d, used_d = run(False)
     if str(backend) == "cpu":
         assert used_c and not used_d
     on = lm.bool()
-    assert torch.equal(pm_c, pm_d) and torch.equal(ids_c[on], ids_d[on]) and int(ids_c[~on].abs().sum()) == 0
+    assert torch.equal(pm_c, pm_d) and torch.equal(ids_c[on], ids_d[on])
+    if used_c:       # (a GPU takes the reduced head GEMM -- and with it the compact teacher -- for chip-filling shapes only)
+        assert int(ids_c[~on].abs().sum()) == 0
     for k in met_c:
         assert torch.equal(met_c[k], met_d[k]), k
     torch.testing.assert_close(grad_c, grad_d, rtol=2e-2, atol=4e-3 * float(grad_d.abs().max()))
