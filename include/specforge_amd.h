@@ -45,8 +45,8 @@ const char* sf_last_error(void);
 int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
                int K, float alpha, float beta, const void* R, long ldr, void* stream);
 /* sf_gemm_nt(alpha 1, beta 0) with an fp32 workspace (ABI 5): when the grid is under-filled -- at most half as many 256 x 256 tiles as CUs,
- * whole tiles, K in 2 or 4 chunks of >= 1024 -- the 4-wave kernel runs tiles x chunks work units (split-K: fp32 partials in `workspace`,
- * ksplit * M * N floats, fixed-order reduce: deterministic; the residual R joins after the single rounding as in sf_gemm_nt).  Any other
+ * N a multiple of 256 (M may be ragged), K in 2 or 4 chunks of >= 1024 -- the 4-wave kernel runs tiles x chunks work units (split-K: fp32
+ * partials in `workspace`, ksplit * roundup(M, 256) * N floats, fixed-order reduce: deterministic; the residual R joins after the single rounding as in sf_gemm_nt).  Any other
  * shape, a NULL / too small workspace: sf_gemm_nt.  Same result up to fp32 summation order. */
 int sf_gemm_nt_ws(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N, int K,
                   const void* R, long ldr, float* workspace, long workspace_floats, void* stream);
@@ -72,7 +72,9 @@ int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void* C, int c_
  * padded [B, S+T] positions (Cadd) and re-used by every step through this epilogue; the GEMM itself then
  * contracts over the hidden half only. */
 int sf_gemm_nt_rowadd(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
-                      int K, float alpha, const float* Cadd, long ldadd, int S, int Spad, int off, void* stream);
+                      int K, float alpha, const float* Cadd, long ldadd, int S, int Spad, int off,
+                      float* workspace, long workspace_floats,   /* optional (ABI 5): split-K of under-filled grids as in sf_gemm_nt_ws */
+                      void* stream);
 
 /* ---- fused soft-target CE step: loss + in-place dlogits + accuracy + acceptance -----------
  * replaces specforge/core/loss.py:173-228 (LogSoftmaxLoss fwd/bwd), eagle3/model.py:161-173

@@ -26,7 +26,7 @@ _SIGS = {
     "sf_gemm_nt_ws": (c_int, [P, c_long, P, c_long, P, c_int, c_long, c_int, c_int, c_int, P, c_long, P, c_long, P]),
     "sf_gemm_tn": (c_int, [P, c_long, P, c_long, P, c_int, c_long, c_int, c_int, c_int, c_float, c_float, P, c_long, c_int, P]),
     "sf_gemm_nt_rowadd": (c_int, [P, c_long, P, c_long, P, c_int, c_long, c_int, c_int, c_int, c_float, P, c_long, c_int,
-                                  c_int, c_int, P]),
+                                  c_int, c_int, P, c_long, P]),
     "sf_ce_fused": (c_int, [P, c_int, c_long, c_int, c_int, P, c_int, c_int, c_int, P, P, P, P, P, P, c_float, c_int,
                             P, P, P, P, P, P]),
     "sf_ce_lk_grad": (c_int, [P, c_int, c_long, c_int, c_int, P, c_int, c_int, c_int, P, P, P, c_int, c_float, c_float,

@@ -209,7 +209,7 @@ int sf_gemm_nt_256w4_splitk_launch(const void* A, long lda, const void* B, long 
                                    long workspace_floats, void* stream);
 
 // sf_gemm_nt with a workspace (ABI 5): C = A . B^T (+ R after the rounding), alpha 1, beta 0.  Under-filled grids take the split-K form of the
-// 4-wave kernel through `workspace` (>= 4 * M * N floats covers every split; less simply disables it); every other shape is sf_gemm_nt.
+// 4-wave kernel through `workspace` (>= 4 * roundup(M, 256) * N floats covers every split; less simply disables it); every other shape is sf_gemm_nt.
 extern "C" int sf_gemm_nt_ws(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N, int K,
                              const void* R, long ldr, float* workspace, long workspace_floats, void* stream) {
     if (int st = sf_gemm_check(lda, ldb, ldc, ldr, M, N, K, c_dtype, R)) return st;
@@ -360,7 +360,7 @@ extern "C" int sf_gemm_nt_teacher(const void* A, long lda, const void* Wp, long 
 
 extern "C" int sf_gemm_nt_rowadd(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M,
                                  int N, int K, float alpha, const float* Cadd, long ldadd, int S, int Spad, int off,
-                                 void* stream) {
+                                 float* workspace, long workspace_floats, void* stream) {
     if (int st = sf_gemm_check(lda, ldb, ldc, 0, M, N, K, c_dtype, nullptr)) return st;
     SF_CHECK_ARG(Cadd && ldadd % 4 == 0 && S > 0 && Spad >= S && off >= 0 && off + S <= Spad && M % S == 0,
                  "sf_gemm_nt_rowadd: bad addend layout");
@@ -369,5 +369,9 @@ extern "C" int sf_gemm_nt_rowadd(const void* A, long lda, const void* B, long ld
     e.C = C; e.ldc = ldc; e.R = nullptr; e.ldr = 0;
     e.Cadd = Cadd; e.ldadd = ldadd; e.add_S = S; e.add_Spad = Spad; e.add_off = off;
     e.M = M; e.N = N; e.alpha = alpha; e.beta = 0.f;
+    if (workspace && sf_gemm_use_256()) {       // under-filled grid (batch-1 recipes): split-K, the addend joins in the reduce (sf_gemm_nt_ws)
+        const int st = sf_gemm_nt_256w4_splitk_launch(A, lda, B, ldb, K, e, c_dtype, workspace, workspace_floats, stream);
+        if (st != -1) return st;
+    }
     return sf_gemm_dispatch(A, lda, B, ldb, K, e, c_dtype, stream);
 }

@@ -118,7 +118,8 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
 // residual like the plain epilogue does.  Returns -1 when the shape does not qualify (the caller dispatches as before).
 namespace {
 template <int OUT_F32>
-SF_GLOBAL void nt_splitk_reduce_kernel(const float* ws, int ksplit, void* C, long ldc, const sf_bf16* R, long ldr, int M, int N) {
+SF_GLOBAL void nt_splitk_reduce_kernel(const float* ws, int ksplit, long part_stride, void* C, long ldc, const sf_bf16* R, long ldr, int M, int N,
+                                       const float* Cadd, long ldadd, int add_S, int add_Spad, int add_off) {
     const long n8 = N / 8, total = (long)M * n8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long m = i / n8;
@@ -127,7 +128,14 @@ SF_GLOBAL void nt_splitk_reduce_kernel(const float* ws, int ksplit, void* C, lon
         SfVec8<float>::ld(ws + m * N + n, a);
         for (int y = 1; y < ksplit; ++y) {
             float b[8];
-            SfVec8<float>::ld(ws + (long)y * M * N + m * N + n, b);
+            SfVec8<float>::ld(ws + y * part_stride + m * N + n, b);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a[r] += b[r];
+        }
+        if (Cadd) {       // row-addend form: the fp32 addend joins before the single rounding, as in the fused epilogue
+            const long bb = m / add_S;
+            float b[8];
+            SfVec8<float>::ld(Cadd + (bb * add_Spad + (m - bb * add_S) + add_off) * ldadd + n, b);
 #pragma unroll
             for (int r = 0; r < 8; ++r) a[r] += b[r];
         }
@@ -149,9 +157,13 @@ SF_GLOBAL void nt_splitk_reduce_kernel(const float* ws, int ksplit, void* C, lon
 int sf_gemm_nt_256w4_splitk_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype,
                                    float* workspace, long workspace_floats, void* stream) {
     const int M = e.M, N = e.N;
-    if (!workspace || ((size_t)workspace & 15) || e.Cadd || e.sw_gu || e.sw_dgu || e.red_part || e.alpha != 1.0f || e.beta != 0.0f) return -1;
-    if (M % TM || N % TN || K % TK || (e.ldc & 7) || ((size_t)e.C & 15) || (e.R && ((e.ldr & 7) || ((size_t)e.R & 15)))) return -1;
-    const long tiles = (long)(M / TM) * (N / TN);
+    if (!workspace || ((size_t)workspace & 15) || e.sw_gu || e.sw_dgu || e.red_part || e.alpha != 1.0f || e.beta != 0.0f) return -1;
+    if (e.Cadd && ((e.ldadd & 3) || ((size_t)e.Cadd & 15) || e.R)) return -1;       // (the reduce reads the addend in 16-byte pieces)
+    // (M need not be whole tiles -- real batches are ragged: the partials are laid out in whole row tiles, see the kernel's epilogue)
+    if (M < 8 || N % TN || K % TK || (e.ldc & 7) || ((size_t)e.C & 15) || (e.R && ((e.ldr & 7) || ((size_t)e.R & 15)))) return -1;
+    const int tiles_m = (M + TM - 1) / TM;
+    const long Mpad = (long)tiles_m * TM;
+    const long tiles = (long)tiles_m * (N / TN);
     const long cus = sf_w4_grid(1L << 30);
 #ifdef SF_EMU
     const int min_chunk = 2 * TK;          // (interpreter: the multi-unit path at test sizes)
@@ -160,17 +172,18 @@ int sf_gemm_nt_256w4_splitk_launch(const void* A, long lda, const void* B, long 
 #endif
     int ksplit = 0;
     for (int c = 4; c >= 2; c >>= 1)
-        if (tiles * c <= cus && K % (c * TK) == 0 && K / c >= min_chunk && workspace_floats >= (long)c * M * N) { ksplit = c; break; }
+        if (tiles * c <= cus && K % (c * TK) == 0 && K / c >= min_chunk && workspace_floats >= (long)c * Mpad * N) { ksplit = c; break; }
     if (!ksplit) return -1;
     GemmW4Args p;
     p.A = (const sf_bf16*)A; p.lda = lda;
     p.B = (const sf_bf16*)B; p.ldb = ldb;
     p.e = e;
     p.e.C = workspace; p.e.ldc = N; p.e.R = nullptr; p.e.ldr = 0;
+    p.e.Cadd = nullptr;                     // (the addend of the row-addend form joins in the reduce)
     p.M = M; p.N = N; p.K = K / ksplit;
-    p.tiles_m = M / TM; p.tiles_n = N / TN;
+    p.tiles_m = tiles_m; p.tiles_n = N / TN;
     p.gm = 4;
-    p.ksplit = ksplit; p.ks_a = p.K; p.ks_b = p.K; p.ks_c = (long)M * N;
+    p.ksplit = ksplit; p.ks_a = p.K; p.ks_b = p.K; p.ks_c = Mpad * N;
 #ifdef SF_ABLATE
     p.cyc = 0; p.stagger = 0;
 #endif
@@ -182,8 +195,10 @@ int sf_gemm_nt_256w4_splitk_launch(const void* A, long lda, const void* B, long 
     const long work = (long)M * (N / 8);
     const int rgrid = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
     if (c_dtype == SF_F32)
-        SF_LAUNCH((nt_splitk_reduce_kernel<1>), dim3(rgrid), dim3(256), 0, stream, (const float*)workspace, ksplit, e.C, e.ldc, e.R, e.ldr, M, N);
+        SF_LAUNCH((nt_splitk_reduce_kernel<1>), dim3(rgrid), dim3(256), 0, stream, (const float*)workspace, ksplit, Mpad * N, e.C, e.ldc, e.R, e.ldr, M, N,
+                  e.Cadd, e.ldadd, e.add_S, e.add_Spad, e.add_off);
     else
-        SF_LAUNCH((nt_splitk_reduce_kernel<0>), dim3(rgrid), dim3(256), 0, stream, (const float*)workspace, ksplit, e.C, e.ldc, e.R, e.ldr, M, N);
+        SF_LAUNCH((nt_splitk_reduce_kernel<0>), dim3(rgrid), dim3(256), 0, stream, (const float*)workspace, ksplit, Mpad * N, e.C, e.ldc, e.R, e.ldr, M, N,
+                  e.Cadd, e.ldadd, e.add_S, e.add_Spad, e.add_off);
     return sf_check_launch("sf_gemm_nt(split-K)");
 }

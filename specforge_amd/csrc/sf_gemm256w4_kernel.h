@@ -427,7 +427,9 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     const int next = tile + (int)gridDim.x;
     const bool has_next = next < nunits;
     // the interior-tile fast path of the epilogue (workgroup-uniform; 16-byte row segments need 16-byte aligned rows)
-    const bool fast = SF_W4_FAST_EPI && mc + TM <= p.M && nc + TN <= p.N && p.e.beta == 0.f && !p.e.R && (p.e.ldc & 7) == 0 &&
+    // (split-K partials live in a workspace laid out in WHOLE row tiles: an edge tile stores all 256 rows there -- the rows past M come
+    //  from re-read operand rows and are never read back)
+    const bool fast = SF_W4_FAST_EPI && (mc + TM <= p.M || p.ksplit > 1) && nc + TN <= p.N && p.e.beta == 0.f && !p.e.R && (p.e.ldc & 7) == 0 &&
                       ((size_t)p.e.C & 15) == 0;
     // Row-addend form (round 3): the fp32 addend joins the accumulator in the EPILOGUE, before the single bf16 rounding.  Round 2
     // started the accumulators from it: 256 KiB of loads per tile in front of the first MFMA, every workgroup of a round at

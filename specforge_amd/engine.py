@@ -603,7 +603,7 @@ class Eagle3Engine:
         Np = b["Np"]
         ops.rmsnorm_fwd(self.model.embed_tokens.weight.data, f.view("midlayer.input_layernorm.weight"), eps, b["en"],
                         b["rstd_e1"], ids_pad=b["ids"], S=Spad, Spad=Spad, off=0, rows=b["Np_real"])
-        ops.gemm_nt(b["en"], self.w_qkv[:, :H], b["epart"])
+        ops.gemm_nt(b["en"], self.w_qkv[:, :H], b["epart"], workspace=b["nt_ws"])
         if train:
             b["en2"][Np:].copy_(b["en"])
         self._lm_compact_K = None
@@ -612,7 +612,7 @@ class Eagle3Engine:
             # q/k/v of cat(input_layernorm(embed(ids<<k)), hidden_norm(h_k))   (llama3_eagle.py:1625-1630)
             if k == 0 or not c.norm_output or cnt is not None:     # (else: the final norm of step k - 1 wrote hn[k] in the same pass over h[k])
                 ops.rmsnorm_fwd(b["h"][k], f.view("midlayer.hidden_norm.weight"), eps, hn, b["rstd_h"][k])
-            ops.gemm_nt_rowadd(hn, self.w_qkv[:, H:], qkv, b["epart"], S=S, Spad=Spad, off=k)
+            ops.gemm_nt_rowadd(hn, self.w_qkv[:, H:], qkv, b["epart"], S=S, Spad=Spad, off=k, workspace=b["nt_ws"])
             if self.mrope:
                 ops.rope_(qkv, nh + nkv, hd, b["cos_rows"][k], b["sin_rows"][k], b["pos"], 0)
             else:
@@ -895,7 +895,7 @@ class Eagle3Engine:
         # two-term expansion hi + lo for the weight gradient; input_layernorm.weight only needs the leading term (the
         # reference rounds every step's d(input) to bf16 before the norm backward, which is coarser than that).
         ops.shift_sum_split(b["dqkv_s"], b["ds_hi"], b["ds_lo"], T=T, B=B, S=S, Spad=Spad)   # sum over the steps, re-aligned, hi + lo
-        ops.gemm_nt(b["ds_hi"], self.wqkvT[:H], b["dE"])
+        ops.gemm_nt(b["ds_hi"], self.wqkvT[:H], b["dE"], workspace=b["nt_ws"])
         acc, a = nacc("midlayer.input_layernorm.weight")
         ops.rmsnorm_bwd(b["dE"][:b["Np_real"]], self.model.embed_tokens.weight.data, f.view("midlayer.input_layernorm.weight"),
                         b["rstd_e1"], dx=None, dw_acc=acc, dw_accumulate=a, workspace=b["nws_e"], ids_pad=b["ids"], S=Spad,

@@ -83,7 +83,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, alpha: float
 
 
 def gemm_nt_rowadd(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, addend: torch.Tensor, *, S: int, Spad: int, off: int,
-                   alpha: float = 1.0):
+                   alpha: float = 1.0, workspace: Optional[torch.Tensor] = None):
     """out[r] = round(alpha * a[r] @ b^T + addend[(r // S) * Spad + r % S + off]); addend fp32 [B*Spad, N]."""
     L = _lib.lib()
     M, K = a.shape
@@ -91,7 +91,8 @@ def gemm_nt_rowadd(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, addend: 
     assert K == K2 and out.shape == (M, N) and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
     assert addend.dtype == torch.float32 and addend.shape[1] == N and addend.shape[0] >= (M // S) * Spad
     _lib.check(L.sf_gemm_nt_rowadd(_p(a), _rowmajor(a), _p(b), _rowmajor(b), _p(out), _dt(out), _rowmajor(out), M, N, K,
-                                   alpha, _p(addend), _rowmajor(addend), S, Spad, off, _stream()), "sf_gemm_nt_rowadd")
+                                   alpha, _p(addend), _rowmajor(addend), S, Spad, off, _p(workspace),
+                                   0 if workspace is None else workspace.numel(), _stream()), "sf_gemm_nt_rowadd")
     return out
 
 

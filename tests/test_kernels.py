@@ -64,6 +64,28 @@ def test_gemm_nt_rowadd(backend, M, N, K, S, T, out_dtype):
         torch.testing.assert_close(out.float().cpu(), ref, rtol=tol, atol=tol * math.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K,S,T,ks", [(300, 512, 512, 100, 3, 2), (256, 512, 1024, 64, 2, 4), (512, 768, 256, 128, 2, 0)])
+def test_gemm_nt_rowadd_split_k(backend, M, N, K, S, T, ks):
+    """the row-addend form of an under-filled grid (batch-1 recipes): split-K through the workspace, the fp32 addend joins in the
+    fixed-order reduce before the single rounding -- the fused epilogue's result up to fp32 summation order; ragged M included"""
+    a, b = _rand((M, K), torch.bfloat16, 1), _rand((N, K), torch.bfloat16, 2)
+    B, Spad = M // S, S + T
+    add = _rand((B * Spad, N), torch.float32, 3, scale=3.0)
+    Mpad = (M + 255) // 256 * 256
+    for off in (0, T):
+        rows = (torch.arange(M) // S) * Spad + torch.arange(M) % S + off
+        ref = a.float() @ b.float().t() + add[rows]
+        ws = torch.full((4 * Mpad * N,), float("nan"), device=backend)
+        out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=backend)
+        ops.gemm_nt_rowadd(_dev(backend, a), _dev(backend, b), out, _dev(backend, add), S=S, Spad=Spad, off=off, workspace=ws)
+        fused = torch.empty_like(out)
+        ops.gemm_nt_rowadd(_dev(backend, a), _dev(backend, b), fused, _dev(backend, add), S=S, Spad=Spad, off=off)
+        torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-2, atol=2e-2 * math.sqrt(K))
+        torch.testing.assert_close(out.float().cpu(), fused.float().cpu(), rtol=1e-2, atol=0.13)      # (one bf16 ulp at |x| ~ 16-32)
+        if backend == "cpu":
+            assert int(torch.isfinite(ws).sum()) == ks * Mpad * N
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 48, 64), (200, 136, 128), (256, 256, 64), (520, 264, 192), (136, 1000, 320)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_tn(backend, M, N, K, out_dtype):
@@ -118,16 +140,19 @@ def test_gemm_nt_epilogues(backend):
     assert float(wide[:, :8].abs().max()) == 0 and float(wide[:, 8 + N:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("M,N,K,ks", [(512, 512, 512, 2), (256, 512, 1024, 4), (512, 768, 256, 0), (520, 512, 512, 0)])
+@pytest.mark.parametrize("M,N,K,ks", [(512, 512, 512, 2), (256, 512, 1024, 4), (512, 768, 256, 0), (520, 512, 512, 0), (300, 512, 512, 2),
+                                      (136, 512, 1024, 4)])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_nt_split_k_for_under_filled_grids(backend, M, N, K, ks, out_dtype):
     """sf_gemm_nt_ws: with at most half as many 256-tiles as CUs (interpreter: 8 "CUs") K is cut into 2 / 4 chunks -- tiles x chunks work
     units of the 4-wave kernel, fp32 partials, fixed-order reduce; the residual joins after the rounding like in sf_gemm_nt.  Shapes that
-    do not qualify (too many tiles, ragged M) and a missing workspace go the usual way.  ``ks`` = the split the shape should take."""
+    do not qualify (too many tiles) and a missing workspace go the usual way; a ragged M (real batches) splits too -- the partials are laid
+    out in whole row tiles.  ``ks`` = the split the shape should take."""
     a, b = _rand((M, K), torch.bfloat16, 1), _rand((N, K), torch.bfloat16, 2)
     res = _rand((M, N), torch.bfloat16, 3) if out_dtype == torch.bfloat16 else None
     ref = a.float() @ b.float().t()
-    ws = torch.full((4 * M * N,), float("nan"), device=backend)
+    Mpad = (M + 255) // 256 * 256
+    ws = torch.full((4 * Mpad * N,), float("nan"), device=backend)
     d = lambda t: None if t is None else _dev(backend, t)
     out = torch.full((M, N), 7.0, dtype=out_dtype, device=backend)
     ops.gemm_nt(d(a), d(b), out, residual=d(res), workspace=ws)
@@ -139,7 +164,7 @@ def test_gemm_nt_split_k_for_under_filled_grids(backend, M, N, K, ks, out_dtype)
     torch.testing.assert_close(out.float().cpu(), plain.float().cpu(), rtol=1e-2 if res is not None else 1e-5, atol=0.25 if res is not None else 1e-3)
     used = int(torch.isfinite(ws).sum())                   # the partials that were written say which split ran
     if backend == "cpu":
-        assert used == ks * M * N, (used, ks * M * N)
+        assert used == ks * Mpad * N, (used, ks * Mpad * N)
     again = torch.empty_like(out)
     ops.gemm_nt(d(a), d(b), again, residual=d(res), workspace=torch.zeros_like(ws))
     assert torch.equal(again.cpu(), out.cpu())             # run-to-run identical, whatever the workspace held
