@@ -258,7 +258,10 @@ extern "C" int sf_gemm_nt_swiglu_bwd(const void* A, long lda, const void* B, lon
     if (fuse && big && aligned && M >= 256 && I % 256 == 0 && K % 64 == 0 && sf_gemm_use_256()) {
         // ragged M (real data: the collator pads a batch to its own longest sample): the whole 256-row tiles take the fused kernel,
         // the last M % 256 rows the two steps -- same bits either way, so the split is invisible
-        const int Mf = M / 256 * 256, Mt = M - Mf;
+        // (M > 256, not whole tiles: ONE launch with the last row tile shifted up to end at row M -- GemmW4Args::mshift -- unless the
+        //  caller writes the gradients over gate|up; M < 256 never gets here)
+        const bool one = M % 256 == 0 || (M > 256 && (const void*)gu != (const void*)dgu && sf_knob("SF_GEMM_MSHIFT", 1));
+        const int Mf = one ? M : M / 256 * 256, Mt = M - Mf;
         SfGemmEpi ef = e;
         ef.M = Mf;
         ef.sw_gu = (const sf_bf16*)gu; ef.sw_ldgu = ldgu;
@@ -296,7 +299,10 @@ extern "C" int sf_gemm_nt_swiglu_fwd(const void* A, long lda, const void* Wgu, l
     static const int fuse = sf_knob("SF_GEMM_SWIGLU_FWD_FUSE", 1);
     const bool aligned = ((size_t)gu & 15) == 0 && ((size_t)act & 15) == 0;
     if (fuse && big && aligned && M >= 256 && I % 128 == 0 && K % 64 == 0 && (I + 256L) * ldw * 2 < (1L << 31) && sf_gemm_use_256()) {
-        const int Mf = M / 256 * 256, Mt = M - Mf;        // ragged M: whole tiles fused, the tail rows in two steps (same bits)
+        // ragged M: one launch with the last row tile shifted up to end at row M (GemmW4Args::mshift; the rows two tiles share get the
+        // same bits twice); with the knob off: whole tiles fused, the tail rows in two steps (same bits)
+        const bool one = M % 256 == 0 || (M > 256 && sf_knob("SF_GEMM_MSHIFT", 1));
+        const int Mf = one ? M : M / 256 * 256, Mt = M - Mf;
         SfGemmEpi ef = e;
         ef.M = Mf;
         ef.sw_dgu = (sf_bf16*)act; ef.sw_lddgu = ldact;   // (sw_gu stays null: that is what selects the forward form)

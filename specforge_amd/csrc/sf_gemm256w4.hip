@@ -46,6 +46,9 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
             nblk = (long)p.tiles_m * p.tiles_n;
         }
     }
+    // ragged M: the last row tile is shifted up to end at row M (GemmW4Args::mshift) unless the epilogue reads what it writes
+    p.mshift = (M > TM && M % TM != 0 && p.e.beta == 0.f && (const void*)p.e.R != (const void*)p.e.C &&
+                (!p.e.sw_gu || (const void*)p.e.sw_gu != (const void*)p.e.sw_dgu) && sf_knob("SF_GEMM_MSHIFT", 1)) ? 1 : 0;
     // the 32-bit per-lane byte offsets of the buffer-descriptor DMA cover one 256-row tile of either operand
     SF_CHECK_ARG(256L * lda * 2 < (1L << 31) && 256L * ldb * 2 < (1L << 31), "sf_gemm_nt: row stride too large for the 256-tile kernel");
     if (p.e.Cadd) SF_CHECK_ARG(p.e.alpha == 1.0f, "sf_gemm_nt_rowadd: the 4-wave kernel needs alpha == 1");
@@ -53,10 +56,10 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     const int add = p.e.Cadd ? 1 : (p.e.sw_gu ? 2 : (p.e.sw_dgu ? 3 : (p.e.red_part ? 4 : 0))), f32 = c_dtype == SF_F32 ? 1 : 0;
     SF_CHECK_ARG(add != 4 || (!f32 && p.e.alpha == 1.f && p.e.beta == 0.f && !p.e.R && p.e.red_n0 % TN == 0 && p.e.red_stride >= (N - p.e.red_n0 + 127) / 128),
                  "sf_gemm_nt_teacher: bf16 logits, alpha 1, reduced range on a tile boundary");
-    SF_CHECK_ARG(add != 3 || (!f32 && M % TM == 0 && N % TN == 0 && p.e.alpha == 1.f && p.e.beta == 0.f && !p.e.R &&
+    SF_CHECK_ARG(add != 3 || (!f32 && (M % TM == 0 || p.mshift) && N % TN == 0 && p.e.alpha == 1.f && p.e.beta == 0.f && !p.e.R &&
                               (p.e.ldc & 7) == 0 && ((size_t)p.e.C & 15) == 0 && (N / 2 + 256L) * ldb * 2 < (1L << 31)),
                  "sf_gemm_nt_swiglu_fwd: the fused form takes whole bf16 tiles only");
-    SF_CHECK_ARG(add != 2 || (!f32 && M % TM == 0 && N % TN == 0 && p.e.alpha == 1.f && p.e.beta == 0.f && !p.e.R),
+    SF_CHECK_ARG(add != 2 || (!f32 && (M % TM == 0 || p.mshift) && N % TN == 0 && p.e.alpha == 1.f && p.e.beta == 0.f && !p.e.R),
                  "sf_gemm_nt_swiglu_bwd: the fused form takes whole bf16 tiles only");
     // which operand's LDS half is released and re-staged first: B for narrow N, A for wide N (measured, see the header)
     int sched = N <= 8192 ? 12 : 13;

@@ -70,6 +70,10 @@ struct GemmW4Args {
     // (K here = the chunk length; ks_a / ks_b = element offsets of a chunk in A / B rows) into partial ks of C (ks_c floats apart)
     int ksplit = 1;
     long ks_a = 0, ks_b = 0, ks_c = 0;
+    // ragged M (round 4; real batches): 1 = the last row tile starts at row M - 256 instead of tiles_m * 256 - 256 -- it overlaps its
+    // neighbour, every tile is whole (fast / fused epilogues, no bounds), and the rows computed twice get the same bits twice (a row's
+    // accumulation order does not depend on the tile it is in).  Set by the launcher for M >= 256, beta == 0, no in-place residual.
+    int mshift = 0;
 #ifdef SF_ABLATE
     int stagger;
     int cyc;   // tools build: wave 0 of every workgroup overwrites C[m0][n0..n0+1] with its K-loop cycle count (fp32 bits)
@@ -260,6 +264,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
         if (p.ksplit > 1) { ks0 = t / nblk; t -= ks0 * nblk; }          // (split-K: the unit's K chunk)
         w4_tile_coords(t, nblk, p.tiles_m, p.tiles_n, p.gm, tm, tn);
         m0 = tm * TM;
+        if (p.mshift && m0 + TM > p.M) m0 = p.M - TM;
         n0 = tn * TN;
         const sf_bf16* Ab = p.A + (long)m0 * p.lda + ks0 * p.ks_a;
         const long brow0 = ADD == 3 ? (long)tn * (TN / 2) : (long)n0;   // (ADD = 3: the tile's first gate row)

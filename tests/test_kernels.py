@@ -714,7 +714,7 @@ def test_swiglu(backend, dtype, tol):
 
 
 @pytest.mark.parametrize("M,I,K", [(512, 768, 512),    # whole 256 x 256 tiles, long K: the fused epilogue of the 4-wave kernel (interpreter)
-                                   (600, 256, 512),    # ragged M: 2 fused row tiles + 88 tail rows in two steps
+                                   (600, 256, 512),    # ragged M: 3 fused row tiles, the last one shifted up to end at row 600 (mshift)
                                    (300, 264, 128)])   # everything else: gemm_nt + swiglu_bwd through the scratch
 def test_gemm_nt_swiglu_bwd_equals_the_two_steps(backend, M, I, K):
     """d(act) = dY . W_down with d(SwiGLU) in the GEMM epilogue == the same GEMM followed by swiglu_bwd (same roundings)"""
@@ -735,7 +735,7 @@ def test_gemm_nt_swiglu_bwd_equals_the_two_steps(backend, M, I, K):
 
 @pytest.mark.parametrize("M,I,K", [(512, 384, 512),    # whole tiles (3 n-tiles of 128 act columns), long K: the fused epilogue of the 4-wave kernel
                                    (768, 128, 576),    # one n-tile; K-tile count odd
-                                   (600, 256, 512),    # ragged M: 2 fused row tiles + 88 tail rows in two steps
+                                   (600, 256, 512),    # ragged M: 3 fused row tiles, the last one shifted up to end at row 600 (mshift)
                                    (300, 264, 128)])   # everything else: gemm_nt + swiglu_fwd
 def test_gemm_nt_swiglu_fwd_equals_the_two_steps(backend, M, I, K):
     """gate|up = x . Wgu^T with SwiGLU in the GEMM epilogue == the same GEMM followed by swiglu_fwd: gate|up bit-identical (the
