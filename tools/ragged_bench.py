@@ -39,6 +39,9 @@ def batch(S, seed, ragged):
         lens = [S] + [rnd.randint(int(0.6 * S), S) for _ in range(B - 1)]      # the longest sample defines S
         m = (torch.arange(S, device=dev)[None, :] < torch.tensor(lens, device=dev)[:, None]).long()
         b["attention_mask"], b["loss_mask"] = m, m.clone()
+        if "--no-compact" not in sys.argv:     # the per-step loss-row counts a loader computes from its host copy of the mask (loss-row compaction)
+            from specforge_amd.eagle3 import loss_mask_suffix_counts
+            return TrainBatch(b, {"target_repr": "hidden_state", "loss_mask_suffix_counts": loss_mask_suffix_counts(m.cpu())})
     return TrainBatch(b, {"target_repr": "hidden_state"})
 
 
