@@ -69,6 +69,23 @@ def test_driver_command_line_torchrun_rccl_world1():
     assert r["exposed_wait_ms_per_step"] is not None
 
 
+def test_sparse_loss_mask_legs_and_option():
+    """the default line carries the sparse-loss-mask pair (loss-row compaction on / off) beside the headline; ``--loss-mask-density``
+    makes it the timed workload (labelled as not the headline), ``--no-compact`` its dense form: same loss up to bf16 summation order"""
+    line = _run([sys.executable, "bench.py", "--small", "--batch", "2", "--seq", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                 "--no-dense-mask"])
+    sp = line["sparse_loss_mask"]
+    assert 0.3 < sp["loss_mask_density"] < 0.7 and sp["compact"]["ms_per_step"] > 0 and sp["dense"]["ms_per_step"] > 0
+    runs = []
+    for extra in ([], ["--no-compact"]):
+        l2 = _run([sys.executable, "bench.py", "--small", "--batch", "2", "--seq", "512", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                   "--no-dense-mask", "--no-feeds", "--loss-mask-density", "0.5"] + extra)
+        _check_line(l2, world=1, B=2, S=512, steps=2)
+        assert "NOT the headline" in l2["config"]["workload"] and "sparse_loss_mask" not in l2
+        runs.append(l2["final_loss"])
+    assert abs(runs[0] - runs[1]) <= 2e-2 * abs(runs[1])
+
+
 def test_feed_table_and_ingest_fed_timed_region():
     line = _run([sys.executable, "bench.py", "--small", "--batch", "2", "--seq", "512", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
                  "--no-dense-mask", "--feed", "ingest"])
