@@ -240,6 +240,9 @@ int sf_split_bf16(const float* in, long ldin, void* hi, void* lo, long ldout, lo
  * read-modify-write of the whole sum per step. */
 int sf_shift_sum_split(const void* src, long ldsrc, int T, int B, int S, int Spad, int C, void* hi, void* lo, long ldout,
                        void* stream);
+/* The inverse of a row compaction (ABI 5; loss-row compaction of the lm_head part, eagle3/model.py:364-433 scores row (b, s) of TTT step k
+ * only where loss_mask[b, s + k] != 0): dst [rows, C] = src row inv[r] where inv[r] >= 0, zeros elsewhere.  C % 8 == 0, 16-byte aligned rows. */
+int sf_rows_expand(const void* src, int dtype, long ld_src, const int* inv, void* dst, long ld_dst, long rows, int C, void* stream);
 /* y = (accumulate ? y : 0) + alpha*x, fp32: carries norm-weight gradients across micro-steps. */
 int sf_axpy_f32(long n, float alpha, const float* x, float* y, int accumulate, void* stream);
 int sf_cast_from_f32(const float* in, long ldin, void* out, int dtype, long ldout, long rows, int C, float scale,

@@ -47,6 +47,7 @@ _SIGS = {
     "sf_rmsnorm_bwd": (c_int, [P, c_int, c_long, P, c_long, P, c_int, c_int, c_int, P, P, c_int, c_int, P, c_long, P,
                                c_long, P, c_int, P, P]),
     "sf_colsum_accum": (c_int, [P, c_int, c_int, P, c_int, P]),
+    "sf_rows_expand": (c_int, [P, c_int, c_long, P, P, c_long, c_long, c_int, P]),
     "sf_rope": (c_int, [P, c_int, c_long, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
     "sf_swiglu_fwd": (c_int, [P, c_int, c_long, c_long, c_int, P, c_long, P]),
     "sf_swiglu_bwd": (c_int, [P, c_int, c_long, P, c_long, c_long, c_int, P, c_long, P]),

@@ -772,6 +772,33 @@ extern "C" int sf_add_bf16(long n, const void* a, const void* b, void* out, void
     return sf_check_launch("sf_add_bf16");
 }
 
+namespace {
+// dst[r][:] = inv[r] >= 0 ? src[inv[r]][:] : 0   (16-byte pieces; the inverse of a row compaction: rows that were left out come back as zeros)
+template <typename T>
+SF_GLOBAL void rows_expand_kernel(const T* src, long lds, const int* inv, T* dst, long ldd, long rows, int C8) {
+    const long total = rows * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C8;
+        const int c = (int)(i - r * C8) * 8;
+        const int j = inv[r];
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (j >= 0) SfVec8<T>::ld(src + (long)j * lds + c, v);        // (bf16 <-> fp32 widening is exact both ways)
+        SfVec8<T>::st(dst + r * ldd + c, v);
+    }
+}
+}  // namespace
+
+// The inverse of a row compaction (round 4, loss-row compaction): dst [rows, C] gets src row inv[r] where inv[r] >= 0 and zeros elsewhere --
+// one pass over dst instead of a fill plus an indexed copy.  C % 8 == 0, 16-byte aligned rows.
+extern "C" int sf_rows_expand(const void* src, int dtype, long ld_src, const int* inv, void* dst, long ld_dst, long rows, int C, void* stream) {
+    SF_CHECK_ARG(rows >= 0 && C >= 0 && C % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && inv && src && dst, "sf_rows_expand: bad shape");
+    SF_CHECK_ARG((((size_t)src | (size_t)dst) & 15) == 0, "sf_rows_expand: rows must be 16-byte aligned");
+    if (rows == 0 || C == 0) return 0;
+    SF_DISPATCH_T(dtype, SF_LAUNCH((rows_expand_kernel<T>), dim3(grid_for(rows * (C / 8))), dim3(256), 0, stream, (const T*)src, ld_src, inv,
+                                   (T*)dst, ld_dst, rows, C / 8));
+    return sf_check_launch("sf_rows_expand");
+}
+
 extern "C" int sf_axpy_f32(long n, float alpha, const float* x, float* y, int accumulate, void* stream) {
     SF_CHECK_ARG(n >= 0, "sf_axpy_f32: bad size");
     if (n == 0) return 0;

@@ -203,6 +203,7 @@ class Eagle3Engine:
         for nm in ("pod", "tids", "pm", "lm", "ids"):
             b[nm].zero_()
         b["kvlen"].zero_()
+        b["arange"].copy_(torch.arange(B * S, dtype=torch.int32, device=self.dev))
         TN = T * B * S
         for nm in self._stash_names:
             if b["Kp"] > TN:
@@ -325,6 +326,8 @@ class Eagle3Engine:
         # (+ 4096 floats at the tail: pace-keeping counters of sf_gemm_tn)
         b["tn_ws"] = cv("tn_ws", 2 * max(H * I, self.QW * H) + 4096, dtype=f32)
         # split-K partials of the plain NT GEMMs when their grids are under-filled (few tokens x narrow outputs: bs 1 recipes); else unused
+        b["inv"] = cv("inv", N, dtype=i32)                # loss-row compaction: token row -> compact row (or -1)
+        b["arange"] = cv("arange", N, dtype=i32)
         b["nt_ws"] = (cv("nt_ws", 4 * 128 * 65536, dtype=f32) if ((N + 255) // 256) * ((H + 255) // 256) <= 128 else None)
         nws = ops.attn_bwd_dkv_workspace_floats(B, S, nh, nkv, hdp)     # head-split partials (small B * nkv only; else 0)
         b["dkv_ws"] = cv("dkv_ws", nws, dtype=f32) if nws else None
@@ -665,8 +668,11 @@ class Eagle3Engine:
                 if train:
                     dlnc = b["dxh"][:Nc]            # (a backward work buffer, idle during the forward)
                     ops.gemm_nt(logc, self.wlmT, dlnc, workspace=b["nt_ws"])
-                    b["dln"][k].zero_()
-                    b["dln"][k].index_copy_(0, rows_k, dlnc)
+                    # back to token rows, zeros where no loss was taken: one pass (sf_rows_expand) instead of a fill + an indexed copy
+                    inv = b["inv"]
+                    inv.fill_(-1)
+                    inv.index_copy_(0, rows_k, b["arange"][:Nc])
+                    ops.rows_expand(dlnc, inv, b["dln"][k])
                 continue
             if c.norm_output:   # compute_logits (llama3_eagle.py:1772-1777)
                 ln = b["ln"][k]

@@ -96,6 +96,15 @@ def gemm_nt_rowadd(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, addend: 
     return out
 
 
+def rows_expand(src: torch.Tensor, inv: torch.Tensor, dst: torch.Tensor):
+    """dst[r] = src[inv[r]] where inv[r] >= 0, zeros elsewhere (the inverse of a row compaction); inv int32 [dst rows]"""
+    L = _lib.lib()
+    rows, C = dst.shape
+    assert inv.dtype == torch.int32 and inv.numel() >= rows and inv.is_contiguous() and src.shape[1] == C and src.dtype == dst.dtype
+    _lib.check(L.sf_rows_expand(_p(src), _dt(src), _rowmajor(src), _p(inv), _p(dst), _rowmajor(dst), rows, C, _stream()), "sf_rows_expand")
+    return dst
+
+
 def ce_fused(logits: torch.Tensor, target_pad: torch.Tensor, *, S: int, Spad: int, off: int, pos_mask_pad, loss_mask_pad,
              tgt_ids_pad=None, pod_scale_pad=None, tsum_pad=None, d2t=None, grad_scale: float = 1.0, write_grad: bool = True,
              row_loss, row_correct, row_accept, row_pred=None, row_map=None):

@@ -64,6 +64,23 @@ def test_gemm_nt_rowadd(backend, M, N, K, S, T, out_dtype):
         torch.testing.assert_close(out.float().cpu(), ref, rtol=tol, atol=tol * math.sqrt(K))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_rows_expand(backend, dtype):
+    """sf_rows_expand: the inverse of a row compaction -- compact rows back at their token rows, exact zeros elsewhere (strided views too)"""
+    N, C, Nc = 37, 48, 11
+    g = torch.Generator().manual_seed(3)
+    rows = torch.randperm(N, generator=g)[:Nc].sort().values
+    src = _rand((Nc, C + 8), dtype, 4)[:, :C]
+    inv = torch.full((N,), -1, dtype=torch.int32)
+    inv[rows] = torch.arange(Nc, dtype=torch.int32)
+    wide = torch.full((N, C + 16), 7.0, dtype=dtype, device=backend)
+    ops.rows_expand(_dev(backend, src.contiguous()), _dev(backend, inv), wide[:, 8:8 + C])
+    want = torch.zeros(N, C, dtype=dtype)
+    want[rows] = src
+    assert torch.equal(wide[:, 8:8 + C].cpu(), want)
+    assert float(wide[:, :8].float().min()) == 7.0 and float(wide[:, 8 + C:].float().min()) == 7.0
+
+
 @pytest.mark.parametrize("M,N,K,S,T,ks", [(300, 512, 512, 100, 3, 2), (256, 512, 1024, 64, 2, 4), (512, 768, 256, 128, 2, 0)])
 def test_gemm_nt_rowadd_split_k(backend, M, N, K, S, T, ks):
     """the row-addend form of an under-filled grid (batch-1 recipes): split-K through the workspace, the fp32 addend joins in the
