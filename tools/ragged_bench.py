@@ -17,7 +17,7 @@ from specforge_amd.training import BF16Optimizer, HipDPTrainingBackend  # noqa: 
 
 _lib.lib()
 dev = torch.device("cuda", 0)
-cfg, B, T = bench.LLAMA3_8B, 8, 7
+cfg, B, T = bench.LLAMA3_8B, (1 if "--bs1" in sys.argv else 8), 7      # --bs1: the reference recipes' batch size, a new length every step
 torch.manual_seed(0)
 model = LlamaForCausalLMEagle3(DraftConfig(**cfg), device=dev)
 t2d = torch.zeros(cfg["vocab_size"], dtype=torch.bool)
@@ -60,7 +60,13 @@ def run(seqs, ragged, steps):
     return dict(seqs=seqs, ragged=ragged, steps=steps, ms_per_step=1e3 * el / steps, tokens_per_s=tok / el, final_loss=float(out.loss))
 
 
-if "--ragged-only" in sys.argv:      # (for a kernel trace of the ragged steps alone)
+if "--bs1" in sys.argv:
+    # one sample per step: the same 8 lengths visited in turn (a new shape every step) vs each length repeated (no shape switch)
+    L = [1000, 1432, 771, 1999, 1203, 888, 1640, 1111]
+    res = [run(L, False, 32)] + [run([s], False, 4) for s in L]
+    fixed = sum(r["ms_per_step"] for r in res[1:]) / len(L)
+    res.append(dict(summary="bs 1, lengths " + str(L), switching_ms_per_step=res[0]["ms_per_step"], same_lengths_without_switching_ms_per_step=fixed))
+elif "--ragged-only" in sys.argv:      # (for a kernel trace of the ragged steps alone)
     res = [run([2048, 1999, 1873, 2011, 1777, 1931, 2047, 1685], True, 8)]
 else:
     res = [run([2048], False, 8),
