@@ -173,9 +173,18 @@ int sf_gemm_nt_256w4_splitk_launch(const void* A, long lda, const void* B, long 
 #else
     const int min_chunk = 16 * TK;         // a chunk of at least 1024: prologue + epilogue stay a small part of a unit
 #endif
-    int ksplit = 0;
-    for (int c = 4; c >= 2; c >>= 1)
-        if (tiles * c <= cus && K % (c * TK) == 0 && K / c >= min_chunk && workspace_floats >= (long)c * Mpad * N) { ksplit = c; break; }
+    // chunks: c = 2 .. 8 equal runs of K-tiles (the last one may be shorter), one round of tiles x c units; the cheapest by a simple
+    // model -- a unit is its K-tiles at ~1.3 us each + ~12 us of prologue / epilogue, the reduce streams (4 c + 4) bytes per element at
+    // ~4 TB/s.  (5 row tiles, 1025 .. 1280 tokens at batch 1: 80 tiles take 3 chunks = 240 units instead of 2 = 160.)
+    const int kt = K / TK;
+    int ksplit = 0, chunk_kt = 0;
+    double best = 0;
+    for (int c = 2; c <= 8; ++c) {
+        const int ck = (kt + c - 1) / c;
+        if (tiles * c > cus || (long)(c - 1) * ck >= kt || ck * TK < min_chunk || workspace_floats < (long)c * Mpad * N) continue;
+        const double cost = ck * 1.3 + 12.0 + (4.0 * c + 4.0) * (double)Mpad * N / 4e6;
+        if (!ksplit || cost < best) { ksplit = c; chunk_kt = ck; best = cost; }
+    }
     if (!ksplit) return -1;
     GemmW4Args p;
     p.A = (const sf_bf16*)A; p.lda = lda;
@@ -183,7 +192,8 @@ int sf_gemm_nt_256w4_splitk_launch(const void* A, long lda, const void* B, long 
     p.e = e;
     p.e.C = workspace; p.e.ldc = N; p.e.R = nullptr; p.e.ldr = 0;
     p.e.Cadd = nullptr;                     // (the addend of the row-addend form joins in the reduce)
-    p.M = M; p.N = N; p.K = K / ksplit;
+    p.M = M; p.N = N; p.K = chunk_kt * TK;
+    p.k_total = K;
     p.tiles_m = tiles_m; p.tiles_n = N / TN;
     p.gm = 4;
     p.ksplit = ksplit; p.ks_a = p.K; p.ks_b = p.K; p.ks_c = Mpad * N;

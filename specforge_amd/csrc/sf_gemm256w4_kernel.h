@@ -70,6 +70,7 @@ struct GemmW4Args {
     // (K here = the chunk length; ks_a / ks_b = element offsets of a chunk in A / B rows) into partial ks of C (ks_c floats apart)
     int ksplit = 1;
     long ks_a = 0, ks_b = 0, ks_c = 0;
+    int k_total = 0;      // split-K: the whole contraction length (the last chunk may be shorter than K); 0 = every chunk is K long
     // ragged M (round 4; real batches): 1 = the last row tile starts at row M - 256 instead of tiles_m * 256 - 256 -- it overlaps its
     // neighbour, every tile is whole (fast / fused epilogues, no bounds), and the rows computed twice get the same bits twice (a row's
     // accumulation order does not depend on the tile it is in).  Set by the launcher for M >= 256, beta == 0, no in-place residual.
@@ -245,7 +246,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     const int nunits = nblk * p.ksplit;           // work units of the walk (= tiles unless split-K)
     int tile = (int)blockIdx.x;
     int m0 = 0, n0 = 0, ks0 = 0;
-    const int nkt = p.K / TK;
+    int nkt = p.K / TK;                           // K-tiles of the current work unit (split-K: the last chunk may be shorter)
 
     // ---- DMA sources: this wave stages pieces 8*wave .. 8*wave+7 (8 rows x 128 B each) of A and of B through raw
     // buffer descriptors rooted at the tile origin: one 32-bit byte offset per piece and lane (constant over the K
@@ -261,7 +262,14 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     auto setup_tile = [&](int t) {   // tile origin, descriptors and per-lane source offsets of work unit t
         int tm, tn;
         ks0 = 0;
-        if (p.ksplit > 1) { ks0 = t / nblk; t -= ks0 * nblk; }          // (split-K: the unit's K chunk)
+        if (p.ksplit > 1) {                                             // (split-K: the unit's K chunk)
+            ks0 = t / nblk;
+            t -= ks0 * nblk;
+            if (p.k_total) {
+                const int left = p.k_total - ks0 * p.K;
+                nkt = (left < p.K ? left : p.K) / TK;
+            }
+        }
         w4_tile_coords(t, nblk, p.tiles_m, p.tiles_n, p.gm, tm, tn);
         m0 = tm * TM;
         if (p.mshift && m0 + TM > p.M) m0 = p.M - TM;
