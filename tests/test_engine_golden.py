@@ -148,7 +148,7 @@ def test_blocked_and_per_step_diagonal_backward_agree(backend, golden_dir):
     torch.testing.assert_close(grads[0], grads[1], rtol=2e-2, atol=4e-3 * float(grads[1].abs().max()))
 
 
-@pytest.mark.parametrize("mask", ["random", "head_only"])
+@pytest.mark.parametrize("mask", ["random", "head_only", "all_zero"])
 def test_loss_row_compaction_equals_the_dense_form(backend, golden_dir, mask):
     """engine.compact_loss_rows (round 4): lm_head / CE / lm_head gradients over the rows with loss_mask[b, s + k] != 0 only, from
     host-side row counts -- same losses, metrics and gradients as the dense form (masked rows contribute exact zeros there).
@@ -160,6 +160,8 @@ def test_loss_row_compaction_equals_the_dense_form(backend, golden_dir, mask):
     elif mask == "head_only":
         lm.zero_()
         lm[:, :3] = 1
+    elif mask == "all_zero":          # (a batch without any loss: every step compacts to zero rows, the loss and every gradient are zero)
+        lm.zero_()
     blob["batch"] = dict(blob["batch"], loss_mask=lm)
     runs = []
     for compact in (True, False):
@@ -171,6 +173,8 @@ def test_loss_row_compaction_equals_the_dense_form(backend, golden_dir, mask):
         out.loss.backward()
         runs.append((out, eagle.engine.flat.grad.float().cpu().clone()))
     (a, ga), (d, gd) = runs
+    if mask == "all_zero":
+        assert float(ga.abs().max()) == 0.0 and float(gd.abs().max()) == 0.0 and float(a.loss.detach()) == 0.0
     for key in ("plosses", "acces", "acceptance_rates", "acc_corrects", "acc_denoms"):
         torch.testing.assert_close(torch.stack(a.metrics[key]).float().cpu(), torch.stack(d.metrics[key]).float().cpu(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(ga, gd, rtol=2e-2, atol=4e-3 * float(gd.abs().max()))
