@@ -52,6 +52,8 @@ def _setup(golden_dir, emu_path):
                            num_key_value_heads=c["nkv"], vocab_size=c["Vt"], draft_vocab_size=c["Vd"], head_dim=c["hd"],
                            target_hidden_size=c["Ht"])
         b = O.make_batch(oc, 1, 16, seed=seed, dtype=torch.bfloat16)
+        b["loss_mask"][:, :3 + seed % 4] = 0      # a prompt prefix without loss, a different one per batch: every rank runs the loss-row
+        #                                           compaction of the lm_head part with its OWN row counts (engine.compact_loss_rows)
         return TrainBatch(dict(input_ids=b["input_ids"], attention_mask=b["attention_mask"], loss_mask=b["loss_mask"],
                                hidden_state=b["hidden_state"], target=b["target"]), {"target_repr": "hidden_state"})
 
