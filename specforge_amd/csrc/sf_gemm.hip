@@ -135,6 +135,17 @@ static bool sf_gemm_use_256() {
     return use;
 }
 
+#ifndef SF_EMU
+static int sf_gemm_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n >= 8 ? n : 256;
+    }();
+    return cus;
+}
+#endif
+
 static int sf_gemm_dispatch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype,
                             void* stream) {
     const int M = e.M, N = e.N;
@@ -146,7 +157,11 @@ static int sf_gemm_dispatch(const void* A, long lda, const void* B, long ldb, in
                 // both 256-tile kernels are exercised by the CPU suite
     const bool big = K >= 512;
 #else
-    const bool big = (long)((M + 255) / 256) * ((N + 255) / 256) >= 256 && K >= 512;
+    // (round 4: from MORE THAN HALF a tile per CU on -- 129 tiles; it was a whole tile per CU.  On grids of 144 ... 288 tiles the 4-wave
+    //  kernel is 3 - 26 % faster than the ping-pong kernel at every K tried, tools/w4_small_ab.py, profiles/r4_w4_small_ab.jsonl: DeepSeek-V3
+    //  dims at batch 1 are 8 x 28 = 224 tiles and spent 30 % of their step in the ping-pong kernel.  Up to half a tile per CU: the
+    //  128 x 128 kernel or split-K, below.)
+    const bool big = 2L * ((M + 255) / 256) * ((N + 255) / 256) > sf_gemm_cus() && K >= 512;
 #endif
     const bool w4_ok = !(e.Cadd && e.alpha != 1.0f);   // its addend path starts the accumulators from Cadd
 #ifndef SF_EMU
@@ -155,11 +170,7 @@ static int sf_gemm_dispatch(const void* A, long lda, const void* B, long ldb, in
     // by 8 ... 39 % (4096 x 2048 x {4096, 5120, 6144, 12288, 32000}, 2048 x 4096 x 4096); from 160 tiles up the 256-tile kernels are
     // faster again (tools/small_tile_ab.py, profiles/r4_small_tile_ab.jsonl).
     {
-        static const int cus = [] {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-            return n >= 8 ? n : 256;
-        }();
+        const int cus = sf_gemm_cus();
         static const int small_tiles = sf_knob("SF_GEMM_SMALL128", 1);
         if (small_tiles && 2L * ((M + 255) / 256) * ((N + 255) / 256) <= cus && sf_gemm_use_256())
             return sf_gemm_nt_128_launch(A, lda, B, ldb, K, e, c_dtype, stream);
@@ -251,7 +262,7 @@ extern "C" int sf_gemm_nt_swiglu_bwd(const void* A, long lda, const void* B, lon
 #ifdef SF_EMU
     const bool big = K >= 512;
 #else
-    const bool big = (long)(M / 256) * (I / 256) >= 256 && K >= 512;
+    const bool big = 2L * ((M + 255) / 256) * (I / 256) > sf_gemm_cus() && K >= 512;      // (more than half a tile per CU, as in sf_gemm_dispatch)
 #endif
     static const int fuse = sf_knob("SF_GEMM_SWIGLU_FUSE", 1);
     const bool aligned = ((size_t)gu & 15) == 0 && ((size_t)dgu & 15) == 0 && ((size_t)dact & 15) == 0;
@@ -294,7 +305,7 @@ extern "C" int sf_gemm_nt_swiglu_fwd(const void* A, long lda, const void* Wgu, l
 #ifdef SF_EMU
     const bool big = K >= 512;
 #else
-    const bool big = (long)(M / 256) * (I / 128) >= 256 && K >= 512;
+    const bool big = 2L * ((M + 255) / 256) * (I / 128) > sf_gemm_cus() && K >= 512;
 #endif
     static const int fuse = sf_knob("SF_GEMM_SWIGLU_FWD_FUSE", 1);
     const bool aligned = ((size_t)gu & 15) == 0 && ((size_t)act & 15) == 0;
