@@ -223,12 +223,13 @@ class Eagle3TrainStrategy:
     def forward_loss(self, batch, ctx=None) -> StepOutput:
         self.validate_batch(batch)
         # rows per TTT step that carry a loss (host integers): from the loader's metadata, or from the mask while it is still a CPU tensor
-        counts = getattr(batch, "metadata", {}).get("loss_mask_suffix_counts")
+        md = getattr(batch, "metadata", None) or {}
+        counts = md.get("loss_mask_suffix_counts")
         lm0 = batch.tensors.get("loss_mask")
         if counts is None and lm0 is not None and not lm0.is_cuda:
             counts = loss_mask_suffix_counts(lm0)
         t = self._resident(batch.tensors)
-        target_repr = getattr(batch, "metadata", {}).get("target_repr")
+        target_repr = md.get("target_repr")
         kwargs = {}
         if target_repr == "hidden_state":
             if self.target_head is None:
