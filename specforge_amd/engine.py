@@ -417,7 +417,8 @@ class Eagle3Engine:
         target id 0 (nothing reads its soft target; ``last_artifacts`` are meaningful where the loss mask is set).  -> False when a chunk
         would not take the reduced GEMM form (the caller runs the dense teacher)."""
         Vd, Vt, Ht = self.cfg.draft_vocab_size, head.shape[0], th.shape[1]
-        nch = max(1, -(-Nm // self.teacher_rows))
+        cap = min(self.teacher_rows, part.shape[0])        # (the head GEMM's per-row partials were carved for the dense teacher's chunk)
+        nch = max(1, -(-Nm // cap))
         m = -(-Nm // nch)
         sizes = [min(m, Nm - i * m) for i in range(nch)] if Nm else []
         if Nm and not all(x > 0 and ops.gemm_nt_teacher_reduces(x, Vt, Ht, Vd) for x in sizes):

@@ -346,14 +346,15 @@ def test_unmaterialised_soft_targets_equal_the_materialised_path(backend):
     torch.testing.assert_close(met_a["plosses"], torch.stack([x.detach().float() for x in ref.plosses]), rtol=3e-2, atol=3e-2)
 
 
-def test_teacher_runs_only_on_positions_with_a_loss_mask(backend):
+@pytest.mark.parametrize("B,S,teacher_rows", [(4, 160, 320), (4, 250, 400)])     # (second: S does not divide teacher_rows -- the chunk is capped by the partials' rows)
+def test_teacher_runs_only_on_positions_with_a_loss_mask(backend, B, S, teacher_rows):
     """loss-row compaction, teacher side: with host-known row counts and a sparse loss mask the head GEMM + reduction run over the
     gathered positions with loss_mask != 0 only (two chunks here) and their stored logits / row scalars are scattered back.  Against the
     dense form of the same step: position mask everywhere, target ids where the loss mask is set, every metric bit for bit, gradients
     to summation order (the lm_head weight gradient contracts a compact stash)."""
     kw = dict(hidden_size=64, intermediate_size=96, num_attention_heads=2, num_key_value_heads=1, vocab_size=640,
-              draft_vocab_size=256, head_dim=64, target_hidden_size=512, max_position_embeddings=256, rms_norm_eps=1e-5)
-    B, S, T = 4, 160, 3
+              draft_vocab_size=256, head_dim=64, target_hidden_size=512, max_position_embeddings=512, rms_norm_eps=1e-5)
+    T = 3
     oc = O.DraftConfig(**kw)
     bf = torch.bfloat16
     g = torch.Generator().manual_seed(18)
@@ -362,7 +363,7 @@ def test_teacher_runs_only_on_positions_with_a_loss_mask(backend):
     embed = (torch.randn(640, 64, generator=g) * 0.5).to(bf)
     head_w = (torch.randn(640, 512, generator=g) * 0.2).to(bf)
     t2d, d2t = O.make_vocab_mapping(640, 256, seed=15)
-    batch = O.make_batch(oc, B, S, seed=19, dtype=bf, lengths=[S, 150, 131, 100])
+    batch = O.make_batch(oc, B, S, seed=19, dtype=bf, lengths=[S, S - 10, S - 29, S - 60])
     lm = batch["loss_mask"].clone()
     lm[:, :8] = 0                          # (a prompt prefix without loss)
     lm[1, 40:60] = 0
@@ -374,7 +375,7 @@ def test_teacher_runs_only_on_positions_with_a_loss_mask(backend):
         model.load_state_dict(sd)
         eagle = OnlineEagle3Model(model, length=T).train()
         eagle.engine.compact_loss_rows = compact
-        eagle.engine.teacher_rows = 320                                      # 2 chunks of the ~480 gathered positions
+        eagle.engine.teacher_rows = teacher_rows                             # 2 chunks of the ~480 gathered positions / 4 of ~840
         strat = Eagle3TrainStrategy(eagle, target_head=TargetHead(head_w.to(backend)))
         out = strat.forward_loss(TrainBatch(dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], loss_mask=lm,
                                                  hidden_state=batch["hidden_state"].to(backend), target=batch["target"].to(backend)),
