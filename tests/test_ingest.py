@@ -62,6 +62,9 @@ def test_ingest_matches_reference_normaliser_collator_and_sharding(tmp_path, dev
                 n_got += 1
                 assert batch.metadata["sample_indices"] == g
                 ref = _reference_collate(files, g, max_len)
+                # the host-side loss-row counts of the engine's compaction: rows with loss_mask[b, s + k] != 0, per TTT step k
+                lm = ref["loss_mask"]
+                assert batch.metadata["loss_mask_suffix_counts"][:4] == [int((lm[:, k:] != 0).sum()) for k in range(4)]
                 for k, v in ref.items():
                     t = batch.tensors[k]
                     assert t.device.type == dev and t.is_contiguous() and t.shape == v.shape, (k, t.shape, v.shape)
