@@ -190,6 +190,36 @@ def test_loss_row_compaction_equals_the_dense_form(backend, golden_dir, mask):
             strat.forward_loss(batch).loss.backward()
 
 
+@pytest.mark.parametrize("B,S,density", [(3, 50, 0.5), (1, 37, 0.3), (5, 23, 0.7)])
+def test_loss_row_compaction_on_odd_shapes(backend, golden_dir, B, S, density):
+    """the compact form on batch shapes with nothing aligned (B * S not a multiple of 64, ragged lengths, a random mask): same step as dense"""
+    blob = torch.load(os.path.join(golden_dir, "eagle31_gqa_fp32.pt"), weights_only=False)
+    c = blob["cfg"]
+    oc = O.DraftConfig(hidden_size=c["H"], intermediate_size=c["I"], num_attention_heads=c["nh"], num_key_value_heads=c["nkv"],
+                       vocab_size=c["Vt"], draft_vocab_size=c["Vd"], head_dim=c["hd"], target_hidden_size=c["Ht"],
+                       max_position_embeddings=c["max_pos"], rms_norm_eps=c["eps"], fc_norm=c["fc_norm"], rope_scaling=c["rope_scaling"],
+                       norm_output=c.get("norm_output", True))
+    g = torch.Generator().manual_seed(B * 100 + S)
+    lens = [S] + [int(torch.randint(S // 2, S + 1, (1,), generator=g)) for _ in range(B - 1)]
+    b = O.make_batch(oc, B, S, seed=B + S, dtype=torch.float32, lengths=lens)
+    b["loss_mask"] = b["loss_mask"] * (torch.rand(B, S, generator=g) < density).to(b["loss_mask"].dtype)
+    blob["batch"] = {k: b[k] for k in ("input_ids", "attention_mask", "loss_mask", "hidden_state", "target")}
+    runs = []
+    for compact in (True, False):
+        cfg, model, eagle, strat = _build(blob, backend)
+        eagle.train()
+        eagle.engine.compact_loss_rows = compact
+        out = strat.forward_loss(_batch(blob, backend))
+        assert (eagle.engine._lm_compact_K is not None) == compact
+        out.loss.backward()
+        runs.append((out, eagle.engine.flat.grad.float().cpu().clone(), eagle.last_artifacts["position_mask"].cpu()))
+    (a, ga, pa), (d, gd, pd) = runs
+    assert torch.equal(pa, pd)
+    for key in ("plosses", "acces", "acceptance_rates", "acc_corrects", "acc_denoms"):
+        torch.testing.assert_close(torch.stack(a.metrics[key]).float().cpu(), torch.stack(d.metrics[key]).float().cpu(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ga, gd, rtol=2e-2, atol=4e-3 * float(gd.abs().max()))
+
+
 def test_accumulation_window_and_eval_mode(backend, golden_dir):
     """two micro-steps accumulate (DDP no_sync semantics, training/backend.py:310-320); eval forward leaves no state"""
     blob = torch.load(os.path.join(golden_dir, "eagle3_tiny_bf16.pt"), weights_only=False)
