@@ -160,7 +160,9 @@ def test_gemm_nt_epilogues(backend):
 @pytest.mark.parametrize("M,N,K,ks", [(512, 512, 512, 2), (256, 512, 1024, 4), (512, 768, 256, 0), (520, 512, 512, 0), (300, 512, 512, 2),
                                       (136, 512, 1024, 4),
                                       (256, 512, 640, 4),      # 10 K-tiles in chunks of 3, 3, 3, 1: the last chunk is a single K-tile
-                                      (256, 512, 704, 4)])     # 11 K-tiles: 3, 3, 3, 2
+                                      (256, 512, 704, 4),      # 11 K-tiles: 3, 3, 3, 2
+                                      (300, 512, 640, 2),      # ragged M (two row tiles, the second one padded in the workspace) x 10 K-tiles in 5, 5
+                                      (520, 256, 704, 2)])     # three row tiles x one column tile: 11 K-tiles in 6, 5
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_gemm_nt_split_k_for_under_filled_grids(backend, M, N, K, ks, out_dtype):
     """sf_gemm_nt_ws: with at most half as many 256-tiles as CUs (interpreter: 8 "CUs") K is cut into 2 / 4 chunks -- tiles x chunks work
