@@ -190,7 +190,7 @@ def test_loss_row_compaction_equals_the_dense_form(backend, golden_dir, mask):
             strat.forward_loss(batch).loss.backward()
 
 
-@pytest.mark.parametrize("B,S,density", [(3, 50, 0.5), (1, 37, 0.3), (5, 23, 0.7)])
+@pytest.mark.parametrize("B,S,density", [(3, 50, 0.5), (1, 37, 0.3)])
 def test_loss_row_compaction_on_odd_shapes(backend, golden_dir, B, S, density):
     """the compact form on batch shapes with nothing aligned (B * S not a multiple of 64, ragged lengths, a random mask): same step as dense"""
     blob = torch.load(os.path.join(golden_dir, "eagle31_gqa_fp32.pt"), weights_only=False)
@@ -376,7 +376,7 @@ def test_unmaterialised_soft_targets_equal_the_materialised_path(backend):
     torch.testing.assert_close(met_a["plosses"], torch.stack([x.detach().float() for x in ref.plosses]), rtol=3e-2, atol=3e-2)
 
 
-@pytest.mark.parametrize("B,S,teacher_rows", [(4, 160, 320), (4, 250, 400)])     # (second: S does not divide teacher_rows -- the chunk is capped by the partials' rows)
+@pytest.mark.parametrize("B,S,teacher_rows", [(4, 250, 400)])     # (S does not divide teacher_rows: the chunk is capped by the partials' rows -- 4 chunks)
 def test_teacher_runs_only_on_positions_with_a_loss_mask(backend, B, S, teacher_rows):
     """loss-row compaction, teacher side: with host-known row counts and a sparse loss mask the head GEMM + reduction run over the
     gathered positions with loss_mask != 0 only (two chunks here) and their stored logits / row scalars are scattered back.  Against the
