@@ -45,9 +45,11 @@ const char* sf_last_error(void);
 int sf_gemm_nt(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N,
                int K, float alpha, float beta, const void* R, long ldr, void* stream);
 /* sf_gemm_nt(alpha 1, beta 0) with an fp32 workspace (ABI 5): when the grid is under-filled -- at most half as many 256 x 256 tiles as CUs,
- * N a multiple of 256 (M may be ragged), K in 2 or 4 chunks of >= 1024 -- the 4-wave kernel runs tiles x chunks work units (split-K: fp32
- * partials in `workspace`, ksplit * roundup(M, 256) * N floats, fixed-order reduce: deterministic; the residual R joins after the single rounding as in sf_gemm_nt).  Any other
- * shape, a NULL / too small workspace: sf_gemm_nt.  Same result up to fp32 summation order. */
+ * N a multiple of 256 (M may be ragged) -- the 4-wave kernel runs tiles x c work units, c = 2 ... 8 runs of K-tiles of >= 1024 each (the last
+ * may be shorter), c picked by a small cost model among the splits with tiles x c <= CUs whose partials fit: split-K with fp32 partials in
+ * `workspace` (c * roundup(M, 256) * N floats: 8 * roundup(M, 256) * N covers every split the launcher can pick), fixed-order reduce:
+ * deterministic; the residual R joins after the single rounding as in sf_gemm_nt.  Any other shape, a NULL / too small workspace:
+ * sf_gemm_nt.  Same result up to fp32 summation order. */
 int sf_gemm_nt_ws(const void* A, long lda, const void* B, long ldb, void* C, int c_dtype, long ldc, int M, int N, int K,
                   const void* R, long ldr, float* workspace, long workspace_floats, void* stream);
 
@@ -174,7 +176,8 @@ int sf_rmsnorm_fwd2(const void* x, int dtype, long ldx, const void* w1, void* y1
 long sf_rmsnorm_bwd_workspace_floats(int rows, int H);
 /* dx (optional) = add (optional) + d/dx; dw_acc[H] (optional, fp32) = or += d/dw.
  * dw_accumulate == 2 (ABI 5, here and in sf_rmsnorm_bwd2): only the per-block partials are written -- workspace[nb, H] with
- * nb = sf_rmsnorm_bwd_workspace_floats(rows, H) / H -- and the column sum is the caller's (sf_colsum_accum, any stream, any time). */
+ * nb = sf_rmsnorm_bwd_workspace_floats(rows, H) / H -- and the column sum is the caller's (sf_colsum_accum, any stream, any time).  Mode 2 is NOT used by the engine (the side-stream
+ * experiment of round 4 was measured and removed); it stays for callers that schedule the column sum themselves. */
 int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* x, long ldx, const long long* ids_pad, int S,
                    int Spad, int off, const void* w, const float* rstd, int rows, int H, const void* add,
                    long ldadd, void* dx, long lddx, float* dw_acc, int dw_accumulate, float* workspace,
@@ -251,7 +254,7 @@ int sf_cast_from_f32(const float* in, long ldin, void* out, int dtype, long ldou
 /* ---- TTT attention (llama3_eagle.py:745-778; lse-merge blueprint 1024-1151) ----------------
  * q/o/dout/dq: [B*S, nh*hd] views; k0/v0 and the diagonal-branch kd[i]/vd[i]: [B*S, nkv*hd]
  * views (transposed operand fragments are taken from the same tiles with ds_read_b64_tr_b16);
- * lse/delta: [B,nh,S] fp32; kv_len: [B] valid (right-padded) key count or NULL.  hd in {64,128}. */
+ * lse/delta: [B,nh,S] fp32; kv_len: [B] valid (right-padded) key count or NULL.  hd in {64, 128, 256}. */
 int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, const void* v0, const void* const* kd,
                 const void* const* vd, int ndiag, const int* kv_len, void* o, long ldo, float* lse, int B, int S,
                 int nh, int nkv, int hd, float scale, void* stream);

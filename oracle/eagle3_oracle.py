@@ -193,6 +193,32 @@ def rope_tables(cfg: DraftConfig, n_pos: int, dtype=torch.float32) -> Tuple[torc
     return (emb.cos() * amp).to(dtype), (emb.sin() * amp).to(dtype)
 
 
+class RopeCache:
+    """The state of ``LlamaRotaryEmbedding`` (llama3_eagle.py:281-312): the cos / sin cache is built for max_pos + 20 positions and
+    REBUILT for exactly ``seq_len`` positions whenever a call asks for more (303-306; the attention asks for seq_len = q_len + lck,
+    733) -- for dynamic NTK the rebuild also re-derives the base from that length (362-371) -- and the rebuilt cache stays (it is a
+    module buffer), also for later forwards when the same object is passed again.  ``get(seq_len)`` returns the first ``seq_len``
+    rows as ``forward`` does (308-311), so a position id >= seq_len is an IndexError in ``apply_rope`` exactly like in the reference."""
+
+    def __init__(self, cfg: DraftConfig, dtype, device):
+        self.cfg, self.dtype, self.device = cfg, dtype, device
+        self.len = cfg.max_position_embeddings + 20
+        self.cos, self.sin = (t.to(device) for t in rope_tables(cfg, self.len, dtype))
+
+    def get(self, seq_len: int):
+        if seq_len > self.len:
+            self.len = seq_len
+            self.cos, self.sin = (t.to(self.device) for t in rope_tables(self.cfg, seq_len, self.dtype))
+        return self.cos[:seq_len], self.sin[:seq_len]
+
+    def plain_rows(self, n: int):
+        """mrope (llama3_eagle.py:389-427) computes its angles analytically from the ids -- no cache, no limit; this restatement
+        gathers them from the plain table, which is exact for any length"""
+        if n > self.cos.shape[0]:
+            self.cos, self.sin = (t.to(self.device) for t in rope_tables(self.cfg, n, self.dtype))
+        return self.cos, self.sin
+
+
 def rotate_half(x: torch.Tensor) -> torch.Tensor:
     h = x.shape[-1] // 2
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
@@ -268,7 +294,7 @@ def repeat_kv(x: torch.Tensor, n_rep: int) -> torch.Tensor:
     return x[:, :, None].expand(B, nkv, n_rep, S, hd).reshape(B, nkv * n_rep, S, hd)
 
 
-def decoder_layer(p, cfg: DraftConfig, emb, hidden, cache, add_mask, position_ids, cos, sin):
+def decoder_layer(p, cfg: DraftConfig, emb, hidden, cache, add_mask, position_ids, rope: "RopeCache"):
     """``LlamaDecoderLayer.forward`` + ``LlamaAttention.forward`` cache branch +
     ``LlamaMLP`` (llama3_eagle.py:1598-1650, 661-785, 1518-1549)."""
     B, S, H = hidden.shape
@@ -283,8 +309,10 @@ def decoder_layer(p, cfg: DraftConfig, emb, hidden, cache, add_mask, position_id
     lck = len(cache[0])
     rs = cfg.rope_scaling or {}
     if rs.get("rope_type", rs.get("type")) == "mrope":
+        cos, sin = rope.plain_rows(int(position_ids.max()) + lck + 1)
         q, k = apply_mrope(q, k, cos, sin, position_ids + lck, rs["mrope_section"])
     else:
+        cos, sin = rope.get(S + lck)                    # rotary_emb(x, seq_len=q_len + lck), llama3_eagle.py:733
         q, k = apply_rope(q, k, cos, sin, position_ids + lck)
     k = repeat_kv(k, nh // nkv)
     v = repeat_kv(v, nh // nkv)
@@ -398,6 +426,7 @@ def eagle3_forward(
     lk_loss_type: Optional[str] = None,
     kl_scale: float = 1.0,
     kl_decay: float = 1.0,
+    rope_cache: Optional[RopeCache] = None,
 ) -> Eagle3Out:
     """``Eagle3TrainStrategy.forward_loss`` -> ``OnlineEagle3Model.forward``
     (training/strategies/base.py:237-304; algorithms/eagle3/model.py:244-442),
@@ -424,7 +453,8 @@ def eagle3_forward(
         position_ids = torch.arange(0, S, dtype=torch.long).unsqueeze(0)
     position_ids = position_ids.to(dev)
     add_mask = additive_attention_mask(attention_mask.bool().cpu() if attention_mask is not None else torch.ones(B, S, dtype=torch.bool), S, dt).to(dev)
-    cos, sin = (t.to(dev) for t in rope_tables(cfg, cfg.max_position_embeddings + 20, dt))
+    rope = rope_cache if rope_cache is not None else RopeCache(cfg, dt, dev)   # (pass one object to several forwards to carry the
+    # rotary module's cache over, as the reference's draft model does)
     cache = [[], []]
     g_ids, g_pm, g_lm = input_ids, pos_mask, lm
     for idx in range(ttt_length):
@@ -432,7 +462,7 @@ def eagle3_forward(
         tpod = target_pod[:, idx : idx + S]
         tid = ids_p[:, idx : idx + S]
         emb = F.embedding(g_ids, embed_weight).to(dt)
-        hidden = decoder_layer(p, cfg, emb, hidden, cache, add_mask, position_ids, cos, sin)
+        hidden = decoder_layer(p, cfg, emb, hidden, cache, add_mask, position_ids, rope)
         logits = compute_logits(p, cfg, hidden)
         if keep_logits:
             out.logits.append(logits.detach())

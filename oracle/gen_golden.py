@@ -45,11 +45,11 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 
 def run_case(name, *, H, Ht, I, nh, nkv, hd, Vt, Vd, B, S, lengths, ttt, dtype, fc_norm=False, rope_scaling=None, seed=0,
-             lk_loss_type=None, kl_scale=1.0, kl_decay=1.0, norm_output=True, position_ids=None):
+             lk_loss_type=None, kl_scale=1.0, kl_decay=1.0, norm_output=True, position_ids=None, max_pos=128):
     torch.manual_seed(seed)
     cfg = LlamaConfig(
         hidden_size=H, intermediate_size=I, num_attention_heads=nh, num_key_value_heads=nkv,
-        num_hidden_layers=1, vocab_size=Vt, max_position_embeddings=128, rms_norm_eps=1e-5,
+        num_hidden_layers=1, vocab_size=Vt, max_position_embeddings=max_pos, rms_norm_eps=1e-5,
         pad_token_id=0, head_dim=hd, rope_theta=10000.0,
     )
     if rope_scaling is not None:
@@ -72,7 +72,7 @@ def run_case(name, *, H, Ht, I, nh, nkv, hd, Vt, Vd, B, S, lengths, ttt, dtype, 
     head_w = torch.randn(Vt, Ht).to(dtype)
     ocfg = DraftConfig(hidden_size=H, intermediate_size=I, num_attention_heads=nh, num_key_value_heads=nkv,
                        vocab_size=Vt, draft_vocab_size=Vd, head_dim=hd, target_hidden_size=Ht,
-                       max_position_embeddings=128, rms_norm_eps=1e-5, fc_norm=fc_norm, rope_scaling=rope_scaling,
+                       max_position_embeddings=max_pos, rms_norm_eps=1e-5, fc_norm=fc_norm, rope_scaling=rope_scaling,
                        norm_output=norm_output)
     batch = make_batch(ocfg, B, S, seed=seed + 1, dtype=dtype, lengths=lengths)
 
@@ -102,7 +102,7 @@ def run_case(name, *, H, Ht, I, nh, nkv, hd, Vt, Vd, B, S, lengths, ttt, dtype, 
              for n, p in model.named_parameters() if p.requires_grad}
     blob = dict(
         cfg=dict(H=H, Ht=Ht, I=I, nh=nh, nkv=nkv, hd=hd, Vt=Vt, Vd=Vd, ttt=ttt, eps=1e-5, fc_norm=fc_norm,
-                 max_pos=128, rope_scaling=rope_scaling, lk_loss_type=lk_loss_type, kl_scale=kl_scale, kl_decay=kl_decay,
+                 max_pos=max_pos, rope_scaling=rope_scaling, lk_loss_type=lk_loss_type, kl_scale=kl_scale, kl_decay=kl_decay,
                  norm_output=norm_output),
         dtype=str(dtype), params=params, grads=grads,
         embed=model.embed_tokens.weight.detach().clone(), head_w=head_w, t2d=t2d, d2t=d2t, batch=batch,
@@ -203,6 +203,12 @@ if __name__ == "__main__":
         pos3 = torch.stack([tt, hh, ww]) + torch.tensor([0, 3]).view(1, 2, 1)      # second sample offset
         run_case("eagle3_rope_mrope_fp32", rope_scaling=dict(rope_type="mrope", mrope_section=[8, 12, 12]), seed=12,
                  position_ids=pos3, **small)
+    if want("ropegrow"):  # sequences longer than the draft JSON's max_position_embeddings + 20: the rotary module rebuilds its cache
+        # per TTT step (llama3_eagle.py:303-306 via seq_len = q_len + lck at 733); dynamic NTK re-derives its base from each rebuilt length
+        small = dict(H=128, Ht=96, I=192, nh=4, nkv=2, hd=64, Vt=640, Vd=256, B=2, S=44, lengths=[44, 31], ttt=4,
+                     dtype=torch.float32, max_pos=16)
+        run_case("eagle3_rope_grow_fp32", seed=14, **small)
+        run_case("eagle3_rope_grow_dynamic_fp32", rope_scaling=dict(rope_type="dynamic", factor=2.0), seed=15, **small)
     if want("hd256"):  # head_dim 256 (configs/gemma3-1b-eagle3.json: 4 / 1 heads; qwen3-next-80b-a3b, qwen3.5-35b-a3b: 16 / 2):
         # nh * hd > H like those recipes; the reference's attention takes any head_dim (llama3_eagle.py:547-550)
         run_case("eagle3_hd256_fp32", H=128, Ht=64, I=192, nh=2, nkv=1, hd=256, Vt=384, Vd=128, B=2, S=40, lengths=[40, 27],

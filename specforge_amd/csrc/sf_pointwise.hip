@@ -531,7 +531,8 @@ extern "C" int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* 
 
 // The column sum of a norm backward's per-block partials as a call of its own (ABI 5): with dw_accumulate == 2 the two entry points above
 // only WRITE their partials (workspace: sf_rmsnorm_bwd_workspace_floats per weight vector) and the caller reduces them when and where it
-// likes -- the engine does it on a side stream, off the critical path of the sweep (22 launches of ~23 us + a launch gap each per step).
+// likes.  (The engine does NOT use this mode: reducing on a side stream was measured in round 4 and removed -- the persistent GEMMs hold every
+// CU, so the side-stream kernel only delays its neighbours; the entry point stays for callers that schedule the column sum themselves.)
 extern "C" int sf_colsum_accum(const float* partial, int nb, int H, float* acc, int accumulate, void* stream) {
     SF_CHECK_ARG(partial && acc && nb >= 0 && H > 0, "sf_colsum_accum: bad args");
     SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, partial, nb, H, acc, accumulate ? 1 : 0);

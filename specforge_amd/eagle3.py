@@ -52,8 +52,9 @@ class _TTTStep(torch.autograd.Function):
         # the launch of the backward behind the forward.
         gp_dev = grad_plosses.detach().float()
         nt = gp_dev.numel()
-        if eng._cnt_bad is not None:         # loss-row compaction ran on host-supplied row counts: their device-side check rides along
-            gp_dev = torch.cat([gp_dev.view(-1), eng._cnt_bad.float().view(1)])
+        # the engine's device-side input checks (host-supplied row counts, position ids) ride along -- always, so the pinned
+        # buffer keeps ONE shape whether or not a batch was checked
+        gp_dev = torch.cat([gp_dev.view(-1), eng._flags.to(gp_dev.device)])
         if gp_dev.is_cuda:
             host = getattr(eng, "_upstream_host", None)      # one pinned buffer for the engine's lifetime: allocating
             if host is None or host.shape != gp_dev.shape:   # pinned memory per step costs milliseconds of idle GPU
@@ -68,9 +69,7 @@ class _TTTStep(torch.autograd.Function):
             if ready is not None:
                 ready.synchronize()
             gp = host.tolist()
-            if len(gp) > nt and gp[nt] != 0.0:
-                raise RuntimeError("loss_counts passed to the forward do not match the loss mask (loss_counts[k] must be the number of "
-                                   "rows with loss_mask[b, s + k] != 0): the compacted lm_head rows of this step are wrong")
+            eng.check_flags(gp[nt:])
             gp = gp[:nt]
             g = gp[0]
             # The decay weights are baked into the fused CE gradients; the caller must use the same ones.
@@ -131,19 +130,23 @@ class OnlineEagle3Model(nn.Module):
 
     def forward(self, input_ids, attention_mask, target=None, loss_mask=None, hidden_states=None, past_key_values=None,
                 position_ids=None, target_hidden_for_compact=None, target_head_weight=None,
-                compact_teacher_chunk_size: Optional[int] = None, loss_counts=None):
+                compact_teacher_chunk_size: Optional[int] = None, loss_counts=None, position_span=None):
         """``loss_counts`` (optional, not in the reference's signature): loss_counts[k] = number of rows whose loss mask at position
-        s + k is set, as HOST integers -- lets the engine run lm_head / CE on those rows only (``loss_mask_suffix_counts``)."""
+        s + k is set, as HOST integers -- lets the engine run lm_head / CE on those rows only (``loss_mask_suffix_counts``).
+        ``position_span`` (optional): (min, max) of ``position_ids`` as host integers (range check / RoPE table growth without a
+        device read-back); CPU ``position_ids`` are measured here."""
         if past_key_values is not None:
             raise NotImplementedError("past_key_values is unused by EAGLE3 training (eagle3/model.py:262)")
         train = torch.is_grad_enabled() and self.training
         dev = self.engine.dev
+        if position_span is None and position_ids is not None and not position_ids.is_cuda and position_ids.numel():
+            position_span = (int(position_ids.min()), int(position_ids.max()))
         to = lambda t: None if t is None else t.to(dev)
         out = self.engine.forward(
             input_ids=to(input_ids), attention_mask=attention_mask, loss_mask=to(loss_mask), hidden_states=to(hidden_states),
             target_hidden=to(target_hidden_for_compact), target_head_weight=target_head_weight,
             target_logits=to(target) if target_hidden_for_compact is None else None, position_ids=to(position_ids), train=train,
-            loss_counts=loss_counts)
+            loss_counts=loss_counts, position_span=position_span)
         plosses = torch.stack(out["plosses"])
         if train:
             plosses = _TTTStep.apply(self._anchor, self.engine, plosses)
@@ -228,6 +231,8 @@ class Eagle3TrainStrategy:
         lm0 = batch.tensors.get("loss_mask")
         if counts is None and lm0 is not None and not lm0.is_cuda:
             counts = loss_mask_suffix_counts(lm0)
+        pid0 = batch.tensors.get("position_ids")
+        span = (int(pid0.min()), int(pid0.max())) if pid0 is not None and not pid0.is_cuda and pid0.numel() else None
         t = self._resident(batch.tensors)
         target_repr = md.get("target_repr")
         kwargs = {}
@@ -243,7 +248,7 @@ class Eagle3TrainStrategy:
             input_ids, target, loss_mask = t["input_ids"], t["target"], t["loss_mask"]
         plosses, acceptance_rates, acces, acc_corrects, acc_denoms, metric_losses, metric_loss_denoms = self.eagle3_model(
             input_ids=input_ids, attention_mask=t["attention_mask"], loss_mask=loss_mask, target=target,
-            hidden_states=t["hidden_state"], position_ids=t.get("position_ids"), loss_counts=counts, **kwargs)
+            hidden_states=t["hidden_state"], position_ids=t.get("position_ids"), loss_counts=counts, position_span=span, **kwargs)
         weights = [self.ploss_decay ** i for i in range(len(plosses))]
         loss = sum(weights[i] * plosses[i] for i in range(len(plosses)))
         d = lambda xs: [x.detach() for x in xs]

@@ -97,7 +97,6 @@ class Eagle3Engine:
         self.compact_loss_rows = True
         self._lm_compact_K = None                # rows of the compact lm_head stash of the last training forward (None: dense)
         self._teacher_compacted = False          # last forward: target ids / soft targets exist only where the loss mask is set
-        self._cnt_bad = None                     # device flag: the host-supplied row counts disagreed with the mask (read in backward)
         if not 1 <= self.T <= ops.MAX_DIAG + 1:
             raise ValueError(f"ttt_length must be in 1..{ops.MAX_DIAG + 1} (one diagonal branch per earlier TTT step)")
         self.decay = float(ploss_decay)
@@ -106,6 +105,13 @@ class Eagle3Engine:
         self.teacher_rows = teacher_rows
         cos, sin = rope_tables(c, torch.bfloat16)
         self.cos, self.sin = cos.to(self.dev), sin.to(self.dev)
+        # the reference's rotary module REBUILDS its cos / sin cache when a step's seq_len = S + k exceeds the cached length
+        # (llama3_eagle.py:303-306, called with seq_len = q_len + lck at 733): `_rope_len` is its max_seq_len_cached (_rope_steps)
+        self._rope_len = c.max_position_embeddings + 20
+        # device-side input checks whose verdict is read back with the upstream gradient at the END of the backward sweep (no host
+        # sync in the step): slot 0 = loss_counts disagree with the loss mask, slot 1 = position ids outside the reference's range
+        self._flags = torch.zeros(2, dtype=torch.float32, device=self.dev)
+        self._flags_set = False
         # multimodal rope (llama3_eagle.py:389-427, 145-182): [3, B, S] position ids; rotary channel d of a head takes its
         # angle from position axis mrope_axis[d].  The rope kernel is unchanged: per TTT step it is handed cos / sin tables
         # with ONE ROW PER TOKEN (gathered from the plain tables with torch indexing -- table preparation, [N, hd] bf16).
@@ -407,6 +413,49 @@ class Eagle3Engine:
             ops.transpose2d(f.view("fc.weight"), self.wfcT)
         self._wt_version = self.weights_version
 
+    FLAG_MESSAGES = (
+        "loss_counts passed to the forward do not match the loss mask (loss_counts[k] must be the number of rows with "
+        "loss_mask[b, s + k] != 0): the compacted lm_head rows of this step are wrong",
+        "position_ids outside the range the reference accepts (plain ids index cos[:S + k] at ids + k, llama3_eagle.py:303-311 / "
+        "134-139: 0 <= id < seq_length; mrope ids index the precomputed table: pass them as a CPU tensor so the table can grow, "
+        "or raise max_position_embeddings)",
+    )
+
+    def check_flags(self, values) -> None:
+        """raise for the device-side input checks of the last forward (``values`` = a host copy of ``_flags``)"""
+        for v, msg in zip(values, self.FLAG_MESSAGES):
+            if v != 0.0:
+                raise RuntimeError(msg)
+
+    def _rope_steps(self, S: int):
+        """(cos, sin) per TTT step.  Step k rotates with the table ``rotary_emb(x, seq_len=S + k)`` returns (llama3_eagle.py:733); when
+        that exceeds the cached length the reference rebuilds the cache for exactly S + k positions (303-306) and keeps it.  For every
+        variant but dynamic NTK the rebuilt rows equal the old ones, so the table just grows (in strides: real data brings a new S
+        almost every step); dynamic NTK derives its base from the rebuilt length (362-371), so each growing step gets its own table --
+        and, as in the reference, the last one stays cached for the following forwards."""
+        T, c = self.T, self.cfg
+        if S + T - 1 <= self._rope_len:
+            return [(self.cos, self.sin)] * T
+        rs = c.rope_scaling or {}
+        if rs.get("rope_type", rs.get("type")) != "dynamic":
+            self._grow_rope(S + T - 1)
+            return [(self.cos, self.sin)] * T
+        tabs = []
+        for k in range(T):
+            if S + k > self._rope_len:
+                cos, sin = rope_tables(c, torch.bfloat16, n_pos=S + k)
+                self.cos, self.sin, self._rope_len = cos.to(self.dev), sin.to(self.dev), S + k
+            tabs.append((self.cos, self.sin))
+        return tabs
+
+    def _grow_rope(self, rows: int) -> None:
+        """plain (non-dynamic) tables for at least ``rows`` positions: the rows already there keep their values"""
+        if rows > self.cos.shape[0]:
+            n = max(rows, self.cos.shape[0] + 1024, int(1.25 * self.cos.shape[0]))
+            cos, sin = rope_tables(self.cfg, torch.bfloat16, n_pos=n)
+            self.cos, self.sin = cos.to(self.dev), sin.to(self.dev)
+        self._rope_len = max(self._rope_len, rows)
+
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def _teacher_compact(self, b, th, Nm, zd, Vz, perm, head, part, cnt_probe, B, S, Spad) -> bool:
@@ -425,7 +474,9 @@ class Eagle3Engine:
             return False
         for nm in ("pm", "tids"):
             b[nm].zero_()
-        if Nm == 0:
+        if Nm == 0:     # (the count is checked like every other: no row may carry a loss)
+            probe = torch.nonzero_static(b["lm"][:, :S].reshape(-1), size=1, fill_value=-1).view(-1)
+            cnt_probe.append(torch.cat([probe.new_zeros(1), probe]))
             return True
         idx = torch.nonzero_static(b["lm"][:, :S].reshape(-1), size=Nm + 1, fill_value=-1).view(-1)
         cnt_probe.append(idx[Nm - 1:Nm + 1])
@@ -456,9 +507,11 @@ class Eagle3Engine:
         return True
 
     def forward(self, *, input_ids, attention_mask, loss_mask, hidden_states, target_hidden=None,
-                target_head_weight=None, target_logits=None, position_ids=None, train: bool = True, loss_counts=None):
+                target_head_weight=None, target_logits=None, position_ids=None, train: bool = True, loss_counts=None,
+                position_span=None):
         """One micro-step forward.  ``input_ids`` / ``target_*`` are already shifted by
         ``TargetHead.preprocess`` (target_head.py:103-108); ``loss_mask`` is [B,S] or [B,S,1].
+        ``position_span`` = (min, max) of ``position_ids`` as host integers when the caller still had them in host memory.
         Returns the metric dict of ``Eagle3TrainStrategy.forward_loss`` (lists of 0-dim tensors)."""
         c, T, f = self.cfg, self.T, self.flat
         for n in (f.names[0], f.names[-1]):      # the draft's parameters must still BE the flat buffer (a .to() / .float() /
@@ -471,8 +524,10 @@ class Eagle3Engine:
         H, I, hd, nh, nkv = c.hidden_size, c.intermediate_size, c.head_dim, c.num_attention_heads, c.num_key_value_heads
         Vd, Ht = c.draft_vocab_size, c.target_hidden_size
         eps, scale = c.rms_norm_eps, 1.0 / math.sqrt(hd)
-        if S + T > self.cos.shape[0]:
-            raise ValueError("sequence length exceeds the RoPE table (max_position_embeddings + 20)")
+        rope = self._rope_steps(S)          # per-step (cos, sin); grows the table like the reference's rotary cache
+        if self._flags_set:
+            self._flags.zero_()
+            self._flags_set = False
         loss_mask = loss_mask.reshape(B, S)
         if attention_mask is None:
             attention_mask = torch.ones(B, S, dtype=torch.int64, device=self.dev)
@@ -488,16 +543,27 @@ class Eagle3Engine:
         if self.mrope:
             if position_ids is None or position_ids.dim() != 3 or tuple(position_ids.shape) != (3, B, S):
                 raise ValueError("rope_type 'mrope' needs position_ids of shape [3, batch, seq_length] (eagle3/model.py:228-242)")
+            # the reference computes the angles analytically from the ids (llama3_eagle.py:719-733, no limit); this engine gathers
+            # rows of the precomputed plain table (exact for any length): with the ids' span known on the HOST the table grows to
+            # it; ids that arrive as a device tensor are checked by a device flag (read back at the end of the backward sweep --
+            # no host sync) and must fit the table as it is.  Ids past it must fail, never rotate by a clamped angle.
+            if position_span is None and not position_ids.is_cuda:
+                position_span = (int(position_ids.min()), int(position_ids.max()))
+            if position_span is not None:
+                lo, hi = position_span
+                if lo < 0:
+                    raise ValueError(f"mrope position_ids must be >= 0 (got {lo})")
+                self._grow_rope(hi + T)
+                rope = [(self.cos, self.sin)] * T
             pos3 = position_ids.to(self.dev).long().reshape(3, N)
-            lo, hi = (int(v) for v in torch.stack((pos3.min(), pos3.max())).tolist())   # one read-back, mrope batches only
-            if lo < 0 or hi + T - 1 >= self.cos.shape[0]:
-                # the reference computes the angles analytically from the ids (llama3_eagle.py:719-733, no limit); this engine
-                # gathers rows of the precomputed table -- ids past it must fail, not rotate by a clamped angle
-                raise ValueError(f"mrope position_ids span [{lo}, {hi}] (+{T - 1} TTT steps) but the RoPE table has {self.cos.shape[0]} "
-                                 "rows (max_position_embeddings + 20): raise max_position_embeddings in the draft config")
+            if position_span is None:
+                self._flags[1] = ((pos3 < 0) | (pos3 + (T - 1) >= self.cos.shape[0])).any()
+                self._flags_set = True
             cols = torch.arange(hd, device=self.dev)
             for k in range(T):   # step k rotates at position + k on every axis (llama3_eagle.py:719-733)
                 idx = (pos3 + k)[self._mrope_axis].t()      # [N, hd]
+                if position_span is None:                    # (device ids: a flagged batch must not fault in the gather either)
+                    idx = idx.clamp(0, self.cos.shape[0] - 1)
                 b["cos_rows"][k].copy_(self.cos[idx, cols])
                 b["sin_rows"][k].copy_(self.sin[idx, cols])
             b["pos"].copy_(torch.arange(N, device=self.dev))                                  # row r reads table row r
@@ -509,7 +575,19 @@ class Eagle3Engine:
         else:
             if position_ids.dim() != 2:
                 raise ValueError("position_ids must be [batch, seq_length] (three-axis ids need rope_type 'mrope')")
+            # the reference indexes cos[:S + k][position_ids + k] (llama3_eagle.py:303-311, 134-139): an id >= S is an IndexError
+            # there at every step (negative ids wrap around python-style; refused here).  Host tensors / a host-known span are
+            # checked now, device tensors by a device flag read back at the end of the backward sweep.
+            if position_span is None and not position_ids.is_cuda and position_ids.numel():
+                position_span = (int(position_ids.min()), int(position_ids.max()))
+            if position_span is not None:
+                if position_span[0] < 0 or position_span[1] >= S:
+                    raise IndexError(f"position_ids span [{position_span[0]}, {position_span[1]}] but must lie in [0, {S}): the reference "
+                                     "indexes its RoPE cache cos[:seq_length + k] at position_ids + k (llama3_eagle.py:303-311, 134-139)")
             b["pos"].copy_(position_ids.reshape(-1))
+            if position_span is None:
+                self._flags[1] = ((b["pos"] < 0) | (b["pos"] >= S)).any()
+                self._flags_set = True
             self._pos_default = None
         if self._t2d_u8 is None or self._t2d_u8.device != self.dev:
             self._t2d_u8 = self.model.t2d.to(self.dev).to(torch.uint8).contiguous()
@@ -528,7 +606,7 @@ class Eagle3Engine:
         if cnt is not None:
             for x in cnt:
                 cum.append(cum[-1] + x)
-        self._cnt_bad, cnt_probe = None, []
+        cnt_probe = []
         self._teacher_compacted = False
 
         # ---- teacher: target logits (chunked GEMM, bf16 like TargetHead.forward) -> soft targets
@@ -620,7 +698,7 @@ class Eagle3Engine:
             if self.mrope:
                 ops.rope_(qkv, nh + nkv, hd, b["cos_rows"][k], b["sin_rows"][k], b["pos"], 0)
             else:
-                ops.rope_(qkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k)
+                ops.rope_(qkv, nh + nkv, hd, rope[k][0], rope[k][1], b["pos"], k)
             if self.hdp == hd:
                 ops.attn_fwd(qkv[:, :nh * hd], b["qkv"][0][:, kcol], b["qkv"][0][:, vcol], [b["qkv"][i][:, kcol] for i in range(1, k + 1)],
                              [b["qkv"][i][:, vcol] for i in range(1, k + 1)], b["kvlen"], b["o"][k], b["lse"][k],
@@ -639,7 +717,9 @@ class Eagle3Engine:
             if cnt is not None:
                 # compact form: the rows of this step that carry a loss mask (lm_pad[b, s + k] != 0), in token order
                 Nc, lo = cnt[k], cum[k]
-                if Nc == 0:
+                if Nc == 0:     # (checked like every other count: no row of this step may carry a loss)
+                    probe = torch.nonzero_static(b["lm"][:, k:k + S].reshape(-1), size=1, fill_value=-1).view(-1)
+                    cnt_probe.append(torch.cat([probe.new_zeros(1), probe]))
                     b["metrics"][k].zero_()
                     if train:
                         b["dln"][k].zero_()
@@ -709,7 +789,11 @@ class Eagle3Engine:
 
         if cnt_probe:
             pr = torch.stack(cnt_probe)
-            self._cnt_bad = ((pr[:, 0] < 0) | (pr[:, 1] >= 0)).any()
+            self._flags[0] = ((pr[:, 0] < 0) | (pr[:, 1] >= 0)).any()
+            self._flags_set = True
+        self._rope_fwd = rope if train else None
+        if not train and self._flags_set:       # no backward will read the flags: an eval forward pays the read-back itself
+            self.check_flags(self._flags.tolist())
         if cnt is not None and train:
             # the compact lm_head stash: rows [0, cum[T]) of logits_s / ln_s, zero rows up to the next multiple of 64 (K of sf_gemm_tn)
             Kc = max(64, (cum[T] + 63) // 64 * 64)
@@ -883,7 +967,7 @@ class Eagle3Engine:
             if self.mrope:
                 ops.rope_(dqkv, nh + nkv, hd, b["cos_rows"][k], b["sin_rows"][k], b["pos"], 0, backward=True)
             else:
-                ops.rope_(dqkv, nh + nkv, hd, self.cos, self.sin, b["pos"], k, backward=True)
+                ops.rope_(dqkv, nh + nkv, hd, self._rope_fwd[k][0], self._rope_fwd[k][1], b["pos"], k, backward=True)
             ops.gemm_nt(dqkv, self.wqkvT[H:], b["dxh"], workspace=b["nt_ws"])                 # hidden half of the QKV dgrad
             if pair and k > 0:
                 pending = (b["dxh"], dh1)      # consumed at the top of step k - 1, before that step rewrites dxh

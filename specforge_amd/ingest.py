@@ -298,7 +298,17 @@ class HiddenStateIngest:
         groups = [list(g) for g in groups]
         if not groups:
             return
+        # an earlier stream() whose iterator was abandoned: its loader must be gone and the copies it queued must have left the
+        # pinned slots before this call refills them (a filled-but-never-consumed slot has no `released` event to wait on)
+        old = getattr(self, "_loader_thread", None)
+        if old is not None and old.is_alive():
+            old.join(timeout=120.0)
+            if old.is_alive():
+                raise RuntimeError("HiddenStateIngest.stream: the loader thread of an abandoned iterator is still reading (slow "
+                                   "storage?); a new stream would overwrite the staging slots under it")
         self._ensure_slots(groups[0][0])
+        if self._copy_stream is not None:
+            self._copy_stream.synchronize()
         nslots = len(self._slots)
         free: "queue.Queue[int]" = queue.Queue()
         ready: "queue.Queue" = queue.Queue()
@@ -328,7 +338,7 @@ class HiddenStateIngest:
             except BaseException as e:  # surface loader failures in the consumer
                 ready.put(e)
 
-        t = threading.Thread(target=loader, daemon=True)
+        t = self._loader_thread = threading.Thread(target=loader, daemon=True)
         t.start()
         prev = None
         try:
@@ -361,7 +371,7 @@ class HiddenStateIngest:
                 self._slots[prev].released = torch.cuda.Event()
                 self._slots[prev].released.record()
             free.put(None)
-            t.join(timeout=30.0)
+            t.join(timeout=30.0)       # (still alive after that: the next stream() waits for it, or refuses to start over it)
 
 
 class PinnedStager:

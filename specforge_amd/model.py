@@ -82,15 +82,17 @@ def _yarn_mscale(scale, mscale):
     return 1.0 if scale <= 1 else 0.1 * mscale * math.log(scale) + 1.0
 
 
-def rope_tables(cfg: DraftConfig, dtype=torch.bfloat16) -> Tuple[torch.Tensor, torch.Tensor]:
-    """cos/sin caches [max_pos+20, head_dim]: fp32 then cast to the activation dtype
+def rope_tables(cfg: DraftConfig, dtype=torch.bfloat16, n_pos: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cos/sin caches [n_pos (default max_pos+20), head_dim]: fp32 then cast to the activation dtype
     (llama3_eagle.py:218-312).  Variants: llama3 frequency smoothing (235-276), linear position scaling
     (315-344), dynamic NTK (347-386: the cache is pre-built for max_pos+20 > max_pos positions, so the base is
     already rescaled for that length), yarn (430-540: blended frequencies and an amplitude factor on cos/sin).
     mrope (llama3_eagle.py:389-427, 145-182) uses these plain tables too: the engine gathers one row per position AXIS
-    and interleaves the head's rotary channels by ``mrope_section`` (Eagle3Engine._rope_rows)."""
+    and interleaves the head's rotary channels by ``mrope_section`` (Eagle3Engine._rope_rows).
+    ``n_pos`` > max_pos+20: a table REBUILT for a longer sequence (``_set_cos_sin_cache(seq_len)``, llama3_eagle.py:303-306) --
+    the same rows for every variant but dynamic NTK, whose base is a function of that length (llama3_eagle.py:362-371)."""
     dim = cfg.head_dim
-    n_pos = cfg.max_position_embeddings + 20
+    n_pos = cfg.max_position_embeddings + 20 if n_pos is None else int(n_pos)
     inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, dim, 2).float() / dim))
     rs = cfg.rope_scaling or {}
     rtype = rs.get("rope_type", rs.get("type"))

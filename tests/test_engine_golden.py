@@ -73,7 +73,9 @@ def _oracle_bf16(blob):
 
 @pytest.mark.parametrize("name", ["eagle3_tiny_bf16", "eagle3_tiny_fp32", "eagle31_gqa_fp32", "eagle3_lk_alpha_fp32",
                                   "eagle3_lk_lambda_fp32", "eagle3_nonorm_fp32", "eagle3_rope_yarn_fp32",
-                                  "eagle3_rope_dynamic_fp32", "eagle3_rope_linear_fp32", "eagle3_rope_mrope_fp32", "eagle3_hd256_fp32"])
+                                  "eagle3_rope_dynamic_fp32", "eagle3_rope_linear_fp32", "eagle3_rope_mrope_fp32", "eagle3_hd256_fp32",
+                                  # sequences longer than max_position_embeddings + 20 (the RoPE table grows like the reference's cache)
+                                  "eagle3_rope_grow_fp32", "eagle3_rope_grow_dynamic_fp32"])
 def test_micro_step_matches_reference_run(backend, golden_dir, name):
     blob = torch.load(os.path.join(golden_dir, f"{name}.pt"), weights_only=False)
     if "fp32" in name:
@@ -188,6 +190,99 @@ def test_loss_row_compaction_equals_the_dense_form(backend, golden_dir, mask):
         batch.metadata["loss_mask_suffix_counts"] = wrong
         with pytest.raises(RuntimeError, match="loss_counts"):
             strat.forward_loss(batch).loss.backward()
+        # a count of ZERO where rows do carry a loss (a step -- or the teacher -- would be skipped silently): refused as well
+        for zeroed in ([2], [1, 2], [0]):
+            cfg, model, eagle, strat = _build(blob, backend)
+            eagle.train()
+            batch = _batch(blob, backend)
+            wrong = loss_mask_suffix_counts(lm)
+            for k in zeroed:
+                assert wrong[k] > 0
+                wrong[k] = 0
+            batch.metadata["loss_mask_suffix_counts"] = wrong
+            with pytest.raises(RuntimeError, match="loss_counts"):
+                strat.forward_loss(batch).loss.backward()
+        # ... and an eval forward (no backward to read the flag in) checks it itself
+        cfg, model, eagle, strat = _build(blob, backend)
+        eagle.train()
+        wrong = loss_mask_suffix_counts(lm)
+        wrong[1] = 0
+        b0 = _batch(blob, backend).tensors
+        from specforge_amd.eagle3 import TargetHead as TH
+        ids, tgt, lmask = TH.preprocess(b0["input_ids"], b0["target"], b0["loss_mask"])
+        kw = dict(input_ids=ids.to(backend), attention_mask=b0["attention_mask"], loss_mask=lmask.to(backend),
+                  hidden_states=b0["hidden_state"], target_hidden=tgt, target_head_weight=strat.target_head.fc.weight.data)
+        eagle.engine.forward(train=False, loss_counts=loss_mask_suffix_counts(lm), **kw)       # eval never compacts: counts unused, fine
+        with pytest.raises(RuntimeError, match="loss_counts"):
+            eagle.engine.forward(train=True, loss_counts=wrong, **kw)
+            eagle.engine.backward(lambda: eagle.engine.check_flags(eagle.engine._flags.tolist()) or 1.0)
+
+
+def test_position_ids_outside_the_reference_range_are_refused(backend, golden_dir):
+    """plain [B, S] position ids: the reference indexes cos[:S + k] at ids + k (llama3_eagle.py:303-311, 134-139), so an id >= S is an
+    IndexError there.  Here: host ids are checked on the host (IndexError), device ids by a device flag read back at the end of the
+    backward sweep (RuntimeError) -- never a rotation by a clamped angle.  In-range custom ids still run and equal the default ids."""
+    blob = torch.load(os.path.join(golden_dir, "eagle3_tiny_fp32.pt"), weights_only=False)
+    B, S = blob["batch"]["input_ids"].shape
+    ok = torch.arange(S).repeat(B, 1)
+    bad = ok.clone()
+    bad[1, S - 1] = S                                   # one id past the end
+    neg = ok.clone()
+    neg[0, 0] = -1
+    cfg, model, eagle, strat = _build(blob, backend)
+    eagle.train()
+    base = strat.forward_loss(_batch(blob, backend))
+    base.loss.backward()
+    g0 = eagle.engine.flat.grad.clone()
+    eagle.engine.end_window()                            # (what the optimizer does: the next backward overwrites flat.grad)
+    # host tensors
+    batch = _batch(blob, backend)
+    batch.tensors["position_ids"] = ok
+    out = strat.forward_loss(batch)
+    out.loss.backward()
+    assert torch.equal(eagle.engine.flat.grad, g0) and float(out.loss.detach()) == float(base.loss.detach())
+    for ids in (bad, neg):
+        batch = _batch(blob, backend)
+        batch.tensors["position_ids"] = ids
+        with pytest.raises(IndexError, match="position_ids"):
+            strat.forward_loss(batch)
+    # ids that are already on the engine's device when they reach it (no host copy to look at): the device flag
+    b0 = _batch(blob, backend).tensors
+    from specforge_amd.eagle3 import TargetHead as TH
+    ids_in, tgt, lmask = TH.preprocess(b0["input_ids"], b0["target"], b0["loss_mask"])
+    kw = dict(input_ids=ids_in.to(backend), attention_mask=b0["attention_mask"], loss_mask=lmask.to(backend),
+              hidden_states=b0["hidden_state"], target_hidden=tgt, target_head_weight=strat.target_head.fc.weight.data)
+    eng = eagle.engine
+    if backend != "cpu":            # (under the interpreter every tensor is a host tensor: the host check above is what runs)
+        eng.forward(train=True, position_ids=bad.to(backend), **kw)
+        with pytest.raises(RuntimeError, match="position_ids"):
+            eng.backward(lambda: eng.check_flags(eng._flags.tolist()) or 1.0)
+        eng.forward(train=True, position_ids=ok.to(backend), **kw)       # the flag is cleared by the next forward
+        eng.backward(lambda: eng.check_flags(eng._flags.tolist()) or 1.0)
+        with pytest.raises(RuntimeError, match="position_ids"):
+            eng.forward(train=False, position_ids=bad.to(backend), **kw)   # eval: checked at the end of the forward
+    with pytest.raises(IndexError, match="position_ids"):
+        eng.forward(train=True, position_ids=bad.to(backend), position_span=(0, S), **kw)   # a caller-supplied host span
+
+
+@pytest.mark.parametrize("rope_scaling", [None, dict(rope_type="dynamic", factor=2.0), dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0,
+                                                                                         high_freq_factor=4.0, original_max_position_embeddings=64)])
+def test_rope_table_grows_like_the_reference_cache(backend, rope_scaling):
+    """The rotary module of the reference rebuilds its cache when seq_len = S + k exceeds it and KEEPS the rebuilt one
+    (llama3_eagle.py:303-306): the engine's per-step tables must equal the oracle's RopeCache (pinned to the reference by the
+    eagle3_rope_grow* goldens) row for row, over a sequence of forwards with growing, shrinking and repeated lengths."""
+    kw = dict(hidden_size=64, intermediate_size=64, num_attention_heads=2, num_key_value_heads=1, vocab_size=64, draft_vocab_size=32,
+              head_dim=64, target_hidden_size=64, max_position_embeddings=16, rms_norm_eps=1e-5, rope_scaling=rope_scaling)
+    from specforge_amd.engine import Eagle3Engine
+    model = LlamaForCausalLMEagle3(DraftConfig(**kw), device=backend)
+    eng = Eagle3Engine(model, ttt_length=4)
+    rc = O.RopeCache(O.DraftConfig(**kw), torch.bfloat16, "cpu")
+    for S in (20, 33, 40, 38, 40, 120, 64, 3000, 20):
+        tabs = eng._rope_steps(S)
+        for k in range(4):
+            cos, sin = rc.get(S + k)
+            assert tabs[k][0].shape[0] >= S + k
+            assert torch.equal(tabs[k][0][:S + k].cpu(), cos) and torch.equal(tabs[k][1][:S + k].cpu(), sin), (S, k)
 
 
 @pytest.mark.parametrize("B,S,density", [(3, 50, 0.5), (1, 37, 0.3)])
@@ -460,3 +555,36 @@ def test_variable_length_batches_share_one_arena(backend, golden_dir):
     p1, g1 = run(full)
     assert torch.equal(p0, p1) and torch.equal(g0, g1)
     assert eng.arena_bytes() == reserved
+
+
+def test_mrope_ids_past_the_table_grow_it(backend, golden_dir):
+    """three-axis ids far beyond max_position_embeddings + 20: the reference computes mrope angles analytically from the ids
+    (llama3_eagle.py:389-427: no cache, no limit); the engine's plain table grows to the host-known span, and ids that are already on
+    the device and do not fit are refused by the device flag instead of rotating by a clamped angle"""
+    blob = torch.load(os.path.join(golden_dir, "eagle3_rope_mrope_fp32.pt"), weights_only=False)
+    blob["batch"] = dict(blob["batch"], position_ids=blob["batch"]["position_ids"] + 700)
+    blob = _oracle_bf16(blob)
+    cfg, model, eagle, strat = _build(blob, backend)
+    eagle.train()
+    rows0 = eagle.engine.cos.shape[0]
+    out = strat.forward_loss(_batch(blob, backend))
+    out.loss.backward()
+    assert eagle.engine.cos.shape[0] > rows0 >= 128
+    torch.testing.assert_close(torch.stack(out.metrics["plosses"]).float().cpu(), blob["plosses"], rtol=2e-2, atol=2e-2)
+    named = dict(model.named_parameters())
+    worst = {k: float((named[k].grad.float().cpu() - g.float()).abs().max()) / float(g.float().abs().max().clamp_min(1e-8))
+             for k, g in blob["grads"].items()}
+    assert max(worst.values()) <= 5e-2, worst
+    neg = blob["batch"]["position_ids"].clone()
+    neg[1, 0, 0] = -2
+    b = _batch(blob, backend)
+    b.tensors["position_ids"] = neg
+    with pytest.raises(ValueError, match="mrope"):
+        strat.forward_loss(b)
+    if backend != "cpu":
+        cfg, model, eagle, strat = _build(blob, backend)       # a fresh engine: table at max_position_embeddings + 20 rows
+        eagle.train()
+        b = _batch(blob, backend)
+        b.tensors["position_ids"] = b.tensors["position_ids"].to(backend)
+        with pytest.raises(RuntimeError, match="position_ids"):
+            strat.forward_loss(b).loss.backward()

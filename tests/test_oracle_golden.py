@@ -36,7 +36,9 @@ def _run(blob):
                                       ("eagle3_lk_alpha_fp32", 1e-5), ("eagle3_lk_lambda_fp32", 1e-5),
                                       ("eagle3_nonorm_fp32", 1e-5), ("eagle3_rope_yarn_fp32", 1e-5),
                                       ("eagle3_rope_dynamic_fp32", 1e-5), ("eagle3_rope_linear_fp32", 1e-5), ("eagle3_hd256_fp32", 1e-5),
-                                      ("eagle3_rope_mrope_fp32", 1e-5)])
+                                      ("eagle3_rope_mrope_fp32", 1e-5),
+                                      # S = 44 against max_position_embeddings 16: the rotary cache is rebuilt per TTT step (RopeCache)
+                                      ("eagle3_rope_grow_fp32", 1e-5), ("eagle3_rope_grow_dynamic_fp32", 1e-5)])
 def test_oracle_matches_reference_run(golden_dir, name, tol):
     blob = torch.load(os.path.join(golden_dir, f"{name}.pt"), weights_only=False)
     p, out = _run(blob)
