@@ -60,6 +60,14 @@ CONFIGS = {
     "deepseek-v3": (DEEPSEEK_V3, 1, 2048, "DeepSeek-V3 671B EAGLE3 offline draft (H 7168, I 40960, Vt 129280)"),
     "qwen3-next-80b-a3b": (QWEN3_NEXT_80B_A3B, 8, 2048, "Qwen3-Next-80B-A3B EAGLE3 offline draft (head_dim 256, 16 / 2 heads)"),
 }
+# The legs of the default line's `configs` object (every BASELINE.json configuration and the batch-1 recipe shape
+# under the driver's clock): (key, CONFIGS entry, batch, seq, what it is)
+CONFIG_LEGS = [
+    ("qwen3-8b_8x2048", "qwen3-8b", 8, 2048, "BASELINE.json configs[2] per-GPU shape (Qwen3-8B draft dims, 8 x 2048)"),
+    ("qwen3-30b-a3b-eagle31_1x4096", "qwen3-30b-a3b-eagle31", 1, 4096, "configs[3] at its recipe's shape (EAGLE3.1, fc_norm; batch 1 x 4096)"),
+    ("deepseek-v3_1x2048", "deepseek-v3", 1, 2048, "configs[4] at its recipe's shape (H 7168, I 40960, Vt 129280; batch 1 x 2048)"),
+    ("llama3-8b_1x4096", "llama3-8b", 1, 4096, "the reference's own Llama recipe (examples/configs/llama3.1-8b-eagle3-offline.yaml: batch 1, max_length 4096)"),
+]
 SMALL = dict(hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=2, vocab_size=4096,
              draft_vocab_size=1024, head_dim=128, target_hidden_size=512, max_position_embeddings=2048, rms_norm_eps=1e-5)
 PEAK_BF16_TFLOPS = 2500.0
@@ -217,6 +225,52 @@ def cpu_baseline(cfg, S, ttt, threads):
                        f"container's 8 cores: profiles/r3_reference_cpu_trainer.jsonl / BASELINE.md section 5")
 
 
+def f_draft_per_token(cfg, S, ttt):
+    """F_draft = 3 (T F_step + 2 * 3Ht * H) flop per token"""
+    H, I, hd, nh, nkv = (cfg[k] for k in ("hidden_size", "intermediate_size", "head_dim", "num_attention_heads", "num_key_value_heads"))
+    f_step = 2.0 * (2 * H * nh * hd + 2 * 2 * H * nkv * hd + nh * hd * H + 3 * H * I + H * cfg["draft_vocab_size"]) + 4.0 * nh * hd * (S / 2.0)
+    return 3.0 * (ttt * f_step + 2.0 * 3 * cfg["target_hidden_size"] * H)
+
+
+def config_leg(cfg, B, S, ttt, nsteps, dev, rank, world, timed, KernelTimer, ops, K):
+    """one `configs` leg: a fresh draft + engine + fused optimizer at ``cfg``'s dims, B x S synthetic HBM-resident batches, 2 warm-up +
+    ``nsteps`` timed optimizer steps -> {ms_per_step, tokens_per_s, draft_frac, nt_frac, kernel fractions}"""
+    if S + ttt > cfg["max_position_embeddings"] + 20:
+        cfg = dict(cfg, max_position_embeddings=S + ttt)
+    torch.manual_seed(0)
+    model = K["LlamaForCausalLMEagle3"](K["DraftConfig"](**cfg), device=dev)
+    t2d = torch.zeros(cfg["vocab_size"], dtype=torch.bool)
+    ids = torch.randperm(cfg["vocab_size"], generator=torch.Generator().manual_seed(0))[:cfg["draft_vocab_size"]].sort().values
+    t2d[ids] = True
+    model.load_vocab_mapping_tensors(t2d, ids - torch.arange(cfg["draft_vocab_size"]))
+    eagle = K["OnlineEagle3Model"](model, length=ttt).train()
+    head = K["TargetHead"]((torch.randn(cfg["vocab_size"], cfg["target_hidden_size"], device=dev) * 0.02).to(torch.bfloat16))
+    strat = K["Eagle3TrainStrategy"](eagle, target_head=head)
+    be = K["HipDPTrainingBackend"](optimizer_factory=lambda m: K["BF16Optimizer"](m, lr=1e-4, max_grad_norm=0.5, total_steps=10_000))
+    be.prepare_model(eagle)
+    lm = torch.ones(B, S, dtype=torch.int64)
+    bt = [K["TrainBatch"](make_batch(cfg, B, S, dev, 100 + rank * 10 + i, lm),
+                          {"target_repr": "hidden_state", "loss_mask_suffix_counts": K["counts"](lm)}) for i in range(2)]
+    nb = lambda i: bt[i % 2]
+    timed(strat, 2, next_batch=nb, be=be)
+    timer = KernelTimer()
+    el, out = timed(strat, nsteps, timer, next_batch=nb, be=be)
+    tokens = world * B * S * nsteps
+    res = {"batch": B, "seq_len": S, "ms_per_step": 1e3 * el / nsteps, "tokens_per_s": tokens / el,
+           "draft_frac": f_draft_per_token(cfg, S, ttt) * (tokens / world) / el / 1e12 / PEAK_BF16_TFLOPS,
+           "final_loss": float(out.loss.detach()), "hbm_gb": eagle.engine.arena_bytes() / 1e9}
+    fr = {}
+    for name in ("gemm_nt", "gemm_nt_swiglu_bwd", "gemm_nt_rowadd", "gemm_nt_swiglu_fwd", "gemm_nt_teacher", "gemm_tn", "attn_fwd", "attn_bwd_dq",
+                 "attn_bwd_dkv"):
+        w, ms, n = timer.summary(name)
+        if n and ms > 0:
+            fr[name] = {"frac": w / ms / 1e9 / PEAK_BF16_TFLOPS, "ms_per_step": ms / nsteps}
+    res["nt_frac"] = fr.get("gemm_nt", {}).get("frac")
+    res["kernels"] = fr
+    del bt, be, strat, head, eagle, model
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,6 +305,9 @@ def main():
                     help="fraction of positions that carry a loss (default 1.0 = the headline workload: all ones).  < 1: chat-like spans; "
                          "the engine runs lm_head / CE / lm_head gradients on those rows only (see --no-compact)")
     ap.add_argument("--no-compact", action="store_true", help="A/B: the dense lm_head part also for sparse loss masks")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` legs (cfg 3 / 4 / 5 and the batch-1 recipe shape beside the headline)")
+    ap.add_argument("--configs", action="store_true", help="run the `configs` legs also when world > 1 or with a non-default --config / shape")
+    ap.add_argument("--config-steps", type=int, default=4, help="timed steps per `configs` leg (2 warm-up steps before them)")
     ap.add_argument("--materialise-targets", action="store_true",
                     help="A/B: write the fp32 soft targets [B, S+T, Vd] instead of re-forming them in the fused CE from the teacher's draft logits")
     args = ap.parse_args()
@@ -366,15 +423,18 @@ def main():
 
             shutil.rmtree(feed_state.pop("dir"), ignore_errors=True)
 
-    def timed(strategy, nsteps, timer=None, next_batch=None):
+    rank_spread = {}      # (world > 1) slowest / fastest rank of the last timed() call: a straggler shows up in the scaling record
+
+    def timed(strategy, nsteps, timer=None, next_batch=None, be=None):
         """W warm-up steps were done by the caller; times exactly nsteps optimizer steps: barrier + synchronize on
         both sides, MAX over ranks."""
         nb = next_batch or (lambda i: batches[i % 2])
+        be = be or backend
 
         def step(i):
             out = strategy.forward_loss(nb(i))
-            backend.backward(out.loss, is_boundary=True)
-            backend.step()
+            be.backward(out.loss, is_boundary=True)
+            be.step()
             return out
 
         if timer is not None:
@@ -393,9 +453,10 @@ def main():
         if timer is not None:
             timer.unwrap(ops)
         if world > 1:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            t = torch.tensor([elapsed, -elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            rank_spread["max_s"], rank_spread["min_s"], rank_spread["steps"] = float(t[0]), -float(t[1]), nsteps
+            elapsed = float(t[0].item())
         return elapsed, out
 
     main_strat, main_next, main_close = make_feed(args.feed)
@@ -404,6 +465,8 @@ def main():
     backend.comm_wait_events = []                    # (N > 1) event pairs around the waits for the bucket all-reduces
     elapsed, out = timed(main_strat, args.steps, timer, next_batch=main_next)
     main_close()
+    main_spread = dict(rank_spread)
+    hbm_peak_main = torch.cuda.max_memory_allocated(dev) / 1e9
     loss = float(out.loss.detach())
     mask_density = float(eagle.last_artifacts["position_mask"].float().mean())   # of the timed steps (before the dense-mask variant)
     fl, gemm_ms, nlaunch = timer.summary("gemm_nt")
@@ -500,6 +563,32 @@ def main():
         except Exception as e:      # the evidence leg runs AFTER the timed region: a failure here must not cost the line
             rccl = {"backend": args.dist_backend, "rccl_ranks": world, "error": f"{type(e).__name__}: {e}"[:300]}
 
+    # ---- the other BASELINE.json configurations and the batch-1 recipe shape, same process, same box, same method (a fresh model + engine +
+    # optimizer per leg; 2 warm-up + --config-steps timed optimizer steps with the HIP-event kernel timers on).  Beside the headline, never
+    # instead of it; every leg in its own try/except.
+    configs_out = None
+    default_shape = (args.config == "llama3-8b" and not args.small and args.batch is None and args.seq is None and args.ttt == 7
+                     and args.loss_mask_density >= 1.0 and args.feed == "hbm")
+    if not args.no_configs and ((world == 1 and default_shape) or args.configs):
+        configs_out = {"steps_per_leg": args.config_steps, "warmup_per_leg": 2,
+                       "note": "ms_per_step = one optimizer step (teacher + 7 TTT steps fwd/bwd + grad-norm/clip/AdamW) on HBM-resident synthetic "
+                               "batches; draft_frac = SURVEY 8d F_draft against 2500 TFLOP/s; the per-kernel fractions are HIP-event timed like `kernels`"}
+        del batches, main_strat, main_next
+        eagle.engine._arena.clear()          # the headline model's 50 GB of step buffers: the legs bring their own
+        eagle.engine._views.clear()
+        torch.cuda.empty_cache()
+        for key, cname, Bc, Sc, what in CONFIG_LEGS:
+            try:
+                configs_out[key] = config_leg(CONFIGS[cname][0], Bc, Sc, args.ttt, args.config_steps, dev, rank, world, timed, KernelTimer, ops,
+                                              dict(Eagle3TrainStrategy=Eagle3TrainStrategy, OnlineEagle3Model=OnlineEagle3Model, TargetHead=TargetHead,
+                                                   TrainBatch=TrainBatch, DraftConfig=DraftConfig, LlamaForCausalLMEagle3=LlamaForCausalLMEagle3,
+                                                   BF16Optimizer=BF16Optimizer, HipDPTrainingBackend=HipDPTrainingBackend,
+                                                   counts=loss_mask_suffix_counts))
+                configs_out[key]["what"] = what
+            except Exception as e:
+                configs_out[key] = {"ms_per_step": None, "what": what, "error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
+
     if rank == 0:
         ach = fl / gemm_ms / 1e9 if gemm_ms > 0 else 0.0
         # HBM-side traffic of the GEMM kernel per launch: from the committed rocprofv3 --pmc passes of this same
@@ -552,9 +641,7 @@ def main():
         }
         fus = kernels["gemm_nt_swiglu_bwd"] or {}
         # the step as a whole against the MFMA roofline: SURVEY 8d's F_draft = 3 * (T * F_step + 2 * 3Ht * H) per token
-        H, I, hd, nh, nkv = (cfg[k] for k in ("hidden_size", "intermediate_size", "head_dim", "num_attention_heads", "num_key_value_heads"))
-        f_step = 2.0 * (2 * H * nh * hd + 2 * 2 * H * nkv * hd + nh * hd * H + 3 * H * I + H * cfg["draft_vocab_size"]) + 4.0 * nh * hd * (S / 2.0)
-        f_draft = 3.0 * (args.ttt * f_step + 2.0 * 3 * cfg["target_hidden_size"] * H)
+        f_draft = f_draft_per_token(cfg, S, args.ttt)
         draft_tflops = f_draft * (tokens / world) / elapsed / 1e12
         line = {
             "metric": ("EAGLE3 draft train tokens/sec, Llama-3-8B target, seq2048 at 1/2/4/8 MI355X" if args.config == "llama3-8b" else
@@ -580,8 +667,13 @@ def main():
             "draft_fwd_bwd": {"tflops_per_gpu": draft_tflops, "frac_of_mfma_peak": draft_tflops / PEAK_BF16_TFLOPS,
                               "flop_per_token": f_draft, "formula": "SURVEY 8d F_draft = 3 (T F_step + 2 * 3Ht * H)"},
             "final_loss": loss,
-            "hbm_peak_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
+            "hbm_peak_gb": hbm_peak_main,
         }
+        if main_spread:
+            line["rank_ms_per_step"] = {"min": 1e3 * main_spread["min_s"] / main_spread["steps"], "max": 1e3 * main_spread["max_s"] / main_spread["steps"],
+                                        "note": "fastest / slowest rank's own wall time over the timed region (value uses the max)"}
+        if configs_out is not None:
+            line["configs"] = configs_out
         line["feed"] = args.feed
         if feeds is not None:
             line["feeds"] = feeds

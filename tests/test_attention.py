@@ -23,19 +23,21 @@ def _mk(B, S, nh, nkv, hd, nsteps, seed):
     return q, ks, vs, do
 
 
-def _oracle(q, ks, vs, do, B, S, nh, nkv, hd, lengths):
-    """fp32 oracle on the bf16-rounded inputs"""
-    qf = q.float().view(B, S, nh, hd).transpose(1, 2).requires_grad_(True)
-    kf = [k.float().view(B, S, nkv, hd).transpose(1, 2).requires_grad_(True) for k in ks]
-    vf = [v.float().view(B, S, nkv, hd).transpose(1, 2).requires_grad_(True) for v in vs]
+def _oracle(q, ks, vs, do, B, S, nh, nkv, hd, lengths, device="cpu"):
+    """fp32 oracle on the bf16-rounded inputs (``device``: the long-sequence cases run the same restatement on the GPU -- [B, nh, S, S + k]
+    fp32 scores with autograd are tens of GB and minutes on the host at S 8192); results come back as CPU tensors"""
+    lead = lambda t, n: t.to(device).float().view(B, S, n, hd).transpose(1, 2)
+    qf = lead(q, nh).requires_grad_(True)
+    kf = [lead(k, nkv).requires_grad_(True) for k in ks]
+    vf = [lead(v, nkv).requires_grad_(True) for v in vs]
     am = torch.zeros(B, S, dtype=torch.long)
     for b, L in enumerate(lengths):
         am[b, :L] = 1
-    add_mask = O.additive_attention_mask(am.bool(), S, torch.float32)
+    add_mask = O.additive_attention_mask(am.bool(), S, torch.float32).to(device)
     rep = nh // nkv
     out = O.ttt_attention(qf, [O.repeat_kv(k, rep) for k in kf], [O.repeat_kv(v, rep) for v in vf], add_mask, hd)
-    out.backward(do.float().view(B, S, nh, hd).transpose(1, 2))
-    flat = lambda t: t.transpose(1, 2).reshape(B * S, -1)
+    out.backward(lead(do, nh))
+    flat = lambda t: t.transpose(1, 2).reshape(B * S, -1).cpu()
     return flat(out.detach()), flat(qf.grad), [flat(k.grad) for k in kf], [flat(v.grad) for v in vf]
 
 

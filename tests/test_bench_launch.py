@@ -54,6 +54,48 @@ def test_bare_gpus2_self_launch_two_ranks_over_gloo():
     assert "dense_mask" not in line and "feeds" not in line and "cpu_baseline" not in line       # N > 1: the timed region only
 
 
+def test_bare_gpus8_self_launch_eight_ranks_over_gloo():
+    """world 8 -- the driver's largest scaling point -- without 8 GPUs: eight ranks share the box's one GPU through gloo.  The cold run must
+    not die: one JSON line, all eight ranks' tokens counted, the 7 gradient buckets all-reduced and their waits timed, per-rank spread
+    reported (a straggler would show in the scaling record)."""
+    line = _run([sys.executable, "bench.py", "--gpus", "8", "--small", "--batch", "1", "--seq", "256", "--dist-backend", "gloo",
+                 "--share-gpu", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], timeout=1500)
+    _check_line(line, world=8, B=1, S=256, steps=2)
+    r = line["rccl"]
+    assert r["rccl_ranks"] == 8 and r["backend"] == "gloo" and len(r["buckets"]) == 7
+    assert r["exposed_wait_ms_per_step"] is not None and r["exposed_wait_ms_per_step"] >= 0
+    sp = line["rank_ms_per_step"]
+    assert 0 < sp["min"] <= sp["max"] and abs(sp["max"] - line["ms_per_step"]) <= 1e-6 * sp["max"]
+    assert "configs" not in line and "feeds" not in line and "cpu_baseline" not in line
+
+
+def test_eight_concurrent_ingest_processes_smoke():
+    """eight loader processes (one per would-be rank of a node) over shards of the same feature files into their own pinned slots and on
+    to the GPU, at small size: what the ranks of an 8-GPU run do to one host (tools/ingest_procs.py is the measurement at full size)"""
+    r = subprocess.run([sys.executable, "tools/ingest_procs.py", "--procs", "8", "--files", "64", "--seq", "128", "--hidden", "256"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep["procs"] == 8 and rep["device"]["aggregate_GBps"] > 0 and len(rep["device"]["per_proc_GBps"]) == 8
+
+
+def test_default_line_carries_the_configs_legs():
+    """plumbing of the `configs` object (cfg 3 / 4 / 5 + the batch-1 recipe shape beside the headline): with --small dims every leg
+    runs the tiny model at its own (batch, seq); the real dims are what the default `python bench.py` line runs"""
+    line = _run([sys.executable, "bench.py", "--small", "--configs", "--config-steps", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                 "--seq", "512", "--no-cpu-baseline", "--no-dense-mask", "--no-feeds"], timeout=1500)
+    cf = line["configs"]
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert {k for k, *_ in bench.CONFIG_LEGS} <= set(cf)
+    for key, cname, B, S, what in bench.CONFIG_LEGS:
+        leg = cf[key]
+        assert leg.get("error") is None, leg
+        assert leg["batch"] == B and leg["seq_len"] == S and leg["ms_per_step"] > 0 and 0 < leg["draft_frac"] < 1 and 0 < leg["nt_frac"] < 1
+        assert abs(leg["tokens_per_s"] - B * S / (leg["ms_per_step"] / 1e3)) <= 1e-6 * leg["tokens_per_s"]
+
+
 def test_driver_command_line_torchrun_rccl_world1():
     import socket
 

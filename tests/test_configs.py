@@ -164,13 +164,29 @@ REAL = {
     # configs/deepseek-v3-671b-eagle3.json (3*Ht = 21504 fusion input, I 40960, 129k vocabulary)
     "cfg5_deepseek_v3": dict(H=7168, Ht=7168, I=40960, nh=56, nkv=8, hd=128, Vt=129280, Vd=32000, B=1, S=512, ttt=7, eps=1e-5,
                              max_pos=163840, lengths=[509]),
+    # round 5: the recipes' own sequence lengths.  cfg 3 at S 2048 (BASELINE.json: seq 2048), a ragged pair
+    "cfg3_qwen3_8b_s2048": dict(H=4096, Ht=4096, I=12288, nh=32, nkv=8, hd=128, Vt=151936, Vd=32000, B=2, S=2048, ttt=7, eps=1e-6,
+                                max_pos=40960, rope_theta=1000000.0, lengths=[2048, 1203]),
+    # cfg 5 at its recipe's shape (examples/configs/deepseek-v3-671b-eagle3-offline.yaml: batch 1 x 2048): the H 7168 / I 40960 GEMMs
+    # at N = 2048 rows (224-tile grids), a prompt region without loss (loss-row compaction + compact teacher)
+    "cfg5_deepseek_v3_s2048": dict(H=7168, Ht=7168, I=40960, nh=56, nkv=8, hd=128, Vt=129280, Vd=32000, B=1, S=2048, ttt=7, eps=1e-5,
+                                   max_pos=163840, lengths=[2048], prompt=300),
+    # configs/qwen3-next-80b-a3b-eagle3.json (head_dim 256, 16 / 2 heads, nh * hd = 2H) at its recipe's shape
+    # (examples/configs/qwen3-next-80b-a3b-eagle3-online.yaml: batch 1, max_length 4096)
+    "qwen3_next_80b_a3b_s4096": dict(H=2048, Ht=2048, I=16384, nh=16, nkv=2, hd=256, Vt=151936, Vd=32000, B=1, S=4096, ttt=7, eps=1e-6,
+                                     max_pos=8192, rope_theta=10000000.0, lengths=[4096], prompt=700),
+    # configs/qwen3.5-35b-a3b-eagle3.json (head_dim 256, 248k target vocabulary) at examples/configs/qwen3.5-35b-a3b-eagle3-online.yaml's
+    # max_length 8192: the longest sequence any shipped EAGLE3 recipe trains at
+    "qwen3_5_35b_a3b_s8192": dict(H=2048, Ht=2048, I=16384, nh=16, nkv=2, hd=256, Vt=248320, Vd=32000, B=1, S=8192, ttt=7, eps=1e-6,
+                                  max_pos=8192, rope_theta=10000000.0, lengths=[8192]),
 }
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(REAL))
 def test_real_dims_match_oracle(name):
-    """cfg 3 / 4 / 5 at the reference's own model dimensions (S = 512) vs the pinned oracle in fp32 on the GPU"""
+    """cfg 3 / 4 / 5 (S 512, and at their recipes' sequence lengths) and the head_dim-256 recipes at the reference's own model
+    dimensions vs the pinned oracle in fp32 on the GPU"""
     from tests._parity import compare
 
     compare(name, REAL[name])

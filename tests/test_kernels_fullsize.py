@@ -232,19 +232,22 @@ def test_gemm_bitwise_determinism(form, M, N, K):
         assert torch.equal(o, first), f"run {i + 1} differs from run 0"
 
 
-@pytest.mark.parametrize("S,lengths", [(1024, [1024, 651]), (2048, [2048, 1675]), (4096, [4096, 2817])])
+@pytest.mark.parametrize("S,lengths", [(1024, [1024, 651]), (2048, [2048, 1675]), (4096, [4096, 2817]), (8192, [8192, 5003])])
 @pytest.mark.parametrize("nsteps", [1, 7])
 def test_ttt_attention_long(S, lengths, nsteps):
     # S 4096 (cfg 4's recipe: bs 1 x 4096): 128 query blocks per (batch, kv head) -- twice what one XCD holds of the
-    # pair-major forward / dQ work order, 64 key tiles per query row
+    # pair-major forward / dQ work order, 64 key tiles per query row.  S 8192: the longest `max_length` among the reference's
+    # recipes (examples/configs/qwen3.5-35b-a3b-eagle3-online.yaml:11), 256 query blocks per pair, a ragged second sample
     _attn_long(S, lengths, nsteps, 128)
 
 
+@pytest.mark.parametrize("S,lengths", [(1024, [1024, 651]), (4096, [4096, 2817]), (8192, [8192, 5003])])
 @pytest.mark.parametrize("nsteps", [1, 7])
-def test_ttt_attention_long_head_dim_256(nsteps):
+def test_ttt_attention_long_head_dim_256(S, lengths, nsteps):
     """head_dim 256 (gemma3-1b / qwen3-next-80b-a3b / qwen3.5-35b-a3b recipes): one workgroup per CU for forward / dQ, the
-    role-split dK/dV kernel, 32 lanes per token row in the diagonal-branch kernel"""
-    _attn_long(1024, [1024, 651], nsteps, 256)
+    role-split dK/dV kernel, 32 lanes per token row in the diagonal-branch kernel -- at the sequence lengths those recipes train at
+    (qwen3.5-35b-a3b-eagle3-{offline,online}.yaml: max_length 4096 / 8192; qwen3-next-80b-a3b-eagle3-online.yaml: 4096)"""
+    _attn_long(S, lengths, nsteps, 256)
 
 
 def _attn_long(S, lengths, nsteps, hd):
@@ -252,7 +255,8 @@ def _attn_long(S, lengths, nsteps, hd):
 
     B, nh, nkv = 2, 4, 2
     q, ks, vs, do = _mk(B, S, nh, nkv, hd, nsteps, seed=S + nsteps)
-    o_ref, dq_ref, dk_ref, dv_ref = _oracle(q, ks, vs, do, B, S, nh, nkv, hd, lengths)
+    o_ref, dq_ref, dk_ref, dv_ref = _oracle(q, ks, vs, do, B, S, nh, nkv, hd, lengths, device=DEV if S >= 4096 else "cpu")
+    torch.cuda.empty_cache()
     d = lambda t: t.to(DEV)
     scale = 1.0 / math.sqrt(hd)
     N = B * S

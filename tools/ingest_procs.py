@@ -22,7 +22,7 @@ def arg(name, dflt):
     return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else dflt
 
 
-Ht, S, B, Vt = 4096, 2048, 8, 128256
+Ht, S, B, Vt = arg("--hidden", 4096), arg("--seq", 2048), 8, 128256      # (--hidden / --seq: the small smoke form of tests/test_bench_launch.py)
 bytes_per_batch = B * S * 4 * Ht * 2 + 3 * B * S * 8
 
 if "--worker" in sys.argv:
@@ -75,7 +75,7 @@ for mode in (("device", "host_only") if torch.cuda.is_available() else ("host_on
     for f in os.listdir(d):
         if f.startswith("ready."):
             os.remove(os.path.join(d, f))
-    ps = [subprocess.Popen([sys.executable, __file__, "--worker", d, "--rank", str(r), "--procs", str(procs)] +
+    ps = [subprocess.Popen([sys.executable, __file__, "--worker", d, "--rank", str(r), "--procs", str(procs), "--hidden", str(Ht), "--seq", str(S)] +
                            (["--host-only"] if mode == "host_only" else []), stdout=subprocess.PIPE, text=True) for r in range(procs)]
     outs = [json.loads(p.communicate(timeout=600)[0].strip().splitlines()[-1]) for p in ps]
     res[mode] = dict(per_proc_GBps=[o["GBps"] for o in outs], aggregate_GBps=round(sum(o["GBps"] for o in outs), 2),
