@@ -29,22 +29,6 @@ namespace {
 #define SF_ATTN_DBG(p, bit) false
 #endif
 
-struct AttnFwdArgs {
-    const sf_bf16* q; long ldq;        // [B*S, nh*hd] view, row stride ldq
-    const sf_bf16* k0; long ldk;       // step-0 keys [B*S, nkv*hd] view
-    const sf_bf16* v0;                 // step-0 values [B*S, nkv*hd] view (row stride ldk)
-    const sf_bf16* kd[kMaxDiag];       // diagonal-branch keys of steps 1..ndiag (views, stride ldk)
-    const sf_bf16* vd[kMaxDiag];       // diagonal-branch values
-    int ndiag;
-    const int* kv_len;                 // [B] number of valid (non-padding) keys
-    sf_bf16* o; long ldo;              // [B*S, nh*hd]
-    float* lse;                        // [B, nh, S] natural-log lse over all S+k columns
-    int B, S, nh, nkv;
-    float scale;
-    int l2_map;  // pair-major work order (attn_work_index); 0 only in the tools build's A/B
-    int dbg;  // profiling experiments only (SF_ATTN_DBG): 1 = stage tile 0 only, 2 = skip the MFMA/softmax work
-};
-
 // ------------------------------------------------------------------ forward
 // -inf where the tile-relative key index `c` is past `rel` (= last visible key - first key of the block - 4 * hi)
 SF_DEVICE void mask_scores(sf_v16f& s, int rel) {
@@ -802,6 +786,8 @@ extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, co
     if (sf_knob("SF_ATTN_FWD_W4", 0))   // tools build: the measured-and-rejected one-wave-per-SIMD variant
         return sfattn_w4::attn_fwd(q, ldq, k0, ldk, v0, kd, vd, ndiag, kv_len, o, ldo, lse, B, S, nh, nkv, hd, scale, stream);
 #endif
+    // head_dim 256: one wave per SIMD, slot-planned (sf_attn_w1.hip); the generic instantiation stays as the tools build's A/B
+    if (hd == 256 && sf_knob("SF_ATTN_W1", 1)) return attn_fwd_w1_launch(p, hd, stream);
     SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_fwd_kernel<HD, NW>), 2 * 128 * HD * 2);
                    SF_LAUNCH((attn_fwd_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
     return sf_check_launch("sf_attn_fwd");
@@ -926,6 +912,7 @@ extern "C" int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long ld
                  "sf_attn_bwd_dq: S * ld exceeds the 2 GiB range of a buffer descriptor");
     constexpr int NW = kAttnFwdWaves;
     dim3 grid(attn_grid((long)((S + NW * 32 - 1) / (NW * 32)) * nh * B, p.l2_map));
+    if (hd == 256 && sf_knob("SF_ATTN_W1", 1)) return attn_bwd_dq_w1_launch(p, hd, stream);    // (sf_attn_w1.hip)
     SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dq_kernel<HD, NW>), 2 * 128 * HD * 2);
                    SF_LAUNCH((attn_bwd_dq_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));
     return sf_check_launch("sf_attn_bwd_dq");

@@ -29,6 +29,22 @@ SF_DEVICE int attn_work_index(int bid, int total, int l2_map) {
 }
 static inline unsigned attn_grid(long total, int l2_map) { return (unsigned)(l2_map ? 8 * ((total + 7) / 8) : total); }
 
+struct AttnFwdArgs {
+    const sf_bf16* q; long ldq;        // [B*S, nh*hd] view, row stride ldq
+    const sf_bf16* k0; long ldk;       // step-0 keys [B*S, nkv*hd] view
+    const sf_bf16* v0;                 // step-0 values [B*S, nkv*hd] view (row stride ldk)
+    const sf_bf16* kd[kMaxDiag];       // diagonal-branch keys of steps 1..ndiag (views, stride ldk)
+    const sf_bf16* vd[kMaxDiag];       // diagonal-branch values
+    int ndiag;
+    const int* kv_len;                 // [B] number of valid (non-padding) keys
+    sf_bf16* o; long ldo;              // [B*S, nh*hd]
+    float* lse;                        // [B, nh, S] natural-log lse over all S+k columns
+    int B, S, nh, nkv;
+    float scale;
+    int l2_map;  // pair-major work order (attn_work_index); 0 only in the tools build's A/B
+    int dbg;  // profiling experiments only (SF_ATTN_DBG): 1 = stage tile 0 only, 2 = skip the MFMA/softmax work
+};
+
 struct AttnBwdArgs {
     const sf_bf16* q; long ldq;      // natural
     const sf_bf16* dout; long lddo;  // natural
@@ -309,6 +325,12 @@ template <int PROF> struct SfProf {
         }                                                                                                   \
     } while (0)
 #endif
+
+namespace sfattn {
+// sf_attn_w1.hip: the one-wave-per-SIMD, slot-planned forward / dQ kernels (head_dim 256)
+int attn_fwd_w1_launch(const AttnFwdArgs& p, int hd, void* stream);
+int attn_bwd_dq_w1_launch(const AttnBwdArgs& p, int hd, void* stream);
+}  // namespace sfattn
 
 #define SF_HD_DISPATCH(hd, CALL)                                  \
     do {                                                          \
