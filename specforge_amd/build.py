@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
-SOURCES = ["sf_core.hip", "sf_loss.hip", "sf_pointwise.hip", "sf_gemm.hip", "sf_gemm256.hip", "sf_gemm256w4.hip", "sf_gemm256w4_i0.hip", "sf_gemm256w4_i1.hip", "sf_gemm256w4_i2.hip", "sf_gemm256w4_i3.hip", "sf_gemm256w4_i4.hip", "sf_gemm256w4_i5.hip", "sf_gemm256w4_i6.hip", "sf_gemm256tn.hip", "sf_attn.hip", "sf_attn_dkv.hip", "sf_attn_w1.hip"]
+SOURCES = ["sf_core.hip", "sf_loss.hip", "sf_pointwise.hip", "sf_gemm.hip", "sf_gemm256.hip", "sf_gemm256w4.hip", "sf_gemm256w4_i0.hip", "sf_gemm256w4_i1.hip", "sf_gemm256w4_i2.hip", "sf_gemm256w4_i3.hip", "sf_gemm256w4_i4.hip", "sf_gemm256w4_i5.hip", "sf_gemm256w4_i6.hip", "sf_gemm256tn.hip", "sf_attn.hip", "sf_attn_dkv.hip", "sf_attn_w1.hip", "sf_attn_w1_dkv.hip"]
 HIP_LIB = os.path.join(PKG, "libsfhip.so")
 EMU_LIB = os.path.join(ROOT, "tests", "emu", "libsfhip_emu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -50,7 +50,12 @@ def _run(cmd):
 # per-file extra flags.  sf_attn.hip: without -fno-honor-nans every fmaxf on an MFMA result is preceded by a canonicalising
 # v_max_f32 x, x (the compiler cannot prove the accumulator is not a signalling NaN): 32 extra VALU per 64-key tile in the
 # online softmax.  Infinities keep their meaning (the causal mask is -inf).
-EXTRA_FLAGS = {"sf_attn.hip": ["-fno-honor-nans"], "sf_attn_dkv.hip": ["-fno-honor-nans"], "sf_attn_w1.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {"sf_attn.hip": ["-fno-honor-nans"], "sf_attn_dkv.hip": ["-fno-honor-nans"], 
+               # one wave per SIMD, slot-planned: -O3's SLP vectoriser pairs the per-element softmax / dS arithmetic of DIFFERENT slots into
+               # v_pk_* instructions placed where the later operand appears -- the pack slots then carry 14-16 instructions (the matrix pipe
+               # idles) and packed fp32 VALU beside MFMAs is an anti-lever by itself (MI355X_MICROARCH.md)
+               "sf_attn_w1.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
+               "sf_attn_w1_dkv.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
 
 def _build(lib, objdir, compile_cmd, link_cmd, force=False):
     os.makedirs(objdir, exist_ok=True)

@@ -165,11 +165,12 @@ SF_DEVICE sf_v8s frag_tr(const char* lds, int db, int r0, const FragOff<HD>& fo)
     const sf_v4s up = sf_ds_read_tr16(lds + r0 * (HD * 2) + fo.tr_off(db, 1));
     return sf_v8s{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
 }
-SF_DEVICE sf_v8s pack_bf16x8(const sf_v16f& p, int r0) {
-    sf_v8s o;
+SF_DEVICE sf_v8s pack_bf16x8(const sf_v16f& p, int r0) {      // four v_cvt_pk_bf16_f32 (scalar casts rely on the SLP vectoriser to pair up:
+    typedef unsigned sf_v4u_ __attribute__((ext_vector_type(4)));   // without it they are 8 conversions + 4 v_perm)
+    sf_v4u_ o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (short)sf_f2bf(p[r0 + i]);
-    return o;
+    for (int i = 0; i < 4; ++i) o[i] = sf_pack2_bf16(p[r0 + 2 * i], p[r0 + 2 * i + 1]);
+    return __builtin_bit_cast(sf_v8s, o);
 }
 // row index inside a 32x32 MFMA result tile held by this lane in register r
 SF_DEVICE int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -228,6 +229,7 @@ struct AgprBank {
     template <int A> SF_DEVICE void mfma_acc(sf_v8s a, sf_v8s b) { acc[A] = sf_mfma32(a, b, acc[A]); }   // acc[A] += a . b
     template <int A> SF_DEVICE sf_v16f get() { return acc[A]; }
     template <int A> SF_DEVICE void scale(float f) { for (int r = 0; r < 16; ++r) acc[A][r] *= f; }
+    template <int A> SF_DEVICE void axpy(float f, const sf_v16f& x) { for (int r = 0; r < 16; ++r) acc[A][r] = acc[A][r] * f + x[r]; }
     SF_DEVICE void drain() {}
 #else
     // (the clobber makes the kernel descriptor allocate the bank)
@@ -272,6 +274,17 @@ struct AgprBank {
             float v;
             asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(16 * A + i));
             v *= f;
+            asm volatile("v_accvgpr_write_b32 a[%c1], %0" : : "v"(v), "i"(16 * A + i));
+        });
+    }
+    // acc[A] = acc[A] * f + x, lane-wise, in place (the forward's diagonal-branch epilogue: the accumulators never leave the bank); same
+    // distance rules as scale()
+    template <int A> SF_DEVICE void axpy(float f, const sf_v16f& x) {
+        static_for<0, 16>([&](auto I) SF_LAMBDA_INLINE {
+            constexpr int i = decltype(I)::value;
+            float v;
+            asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(v) : "i"(16 * A + i));
+            v = fmaf(v, f, x[i]);
             asm volatile("v_accvgpr_write_b32 a[%c1], %0" : : "v"(v), "i"(16 * A + i));
         });
     }
@@ -330,6 +343,8 @@ namespace sfattn {
 // sf_attn_w1.hip: the one-wave-per-SIMD, slot-planned forward / dQ kernels (head_dim 256)
 int attn_fwd_w1_launch(const AttnFwdArgs& p, int hd, void* stream);
 int attn_bwd_dq_w1_launch(const AttnBwdArgs& p, int hd, void* stream);
+// sf_attn_w1_dkv.hip: dK / dV at head_dim 256, a pair of waves per 32 keys splitting the score products (p.hsplit etc. set by the caller)
+int attn_bwd_dkv_w1_launch(const AttnBwdArgs& p, int hd, void* stream);
 }  // namespace sfattn
 
 #define SF_HD_DISPATCH(hd, CALL)                                  \

@@ -85,11 +85,13 @@ struct DkvTile {
     }
     template <int E> SF_DEVICE void element(int qb) {   // element E = 4 j + t of block qb
         constexpr int j = E / 4, t = E % 4;
-        float pv = sf_exp2_raw(fmaf(s[qb][E], sc, -kLog2e * l4[qb][j][t]));
-        if (MASK) {   // arithmetic select: a conditional assignment compiles to an exec-masked branch per element
+        float x = fmaf(s[qb][E], sc, -kLog2e * l4[qb][j][t]);
+        if (MASK) {   // a select on the EXPONENT (exp2(-inf) == 0), as a value expression: a conditional assignment compiles to an exec-masked
+            // branch per element, and a 0 / 1 factor on the probability turns a masked score far above the row's lse (exp2 -> inf) into NaN
             const int C = qb * 32 + 8 * j + t;
-            pv *= (C >= lo && C < up) ? 1.0f : 0.0f;
+            x = (C >= lo && C < up) ? x : -INFINITY;
         }
+        const float pv = sf_exp2_raw(x);
         s[qb][E] = pv;
         dp[qb][E] = pv * (dp[qb][E] - d4[qb][j][t]);
         if constexpr (E % 8 == 7) {
@@ -526,8 +528,13 @@ extern "C" int sf_attn_bwd_dkv(const void* q, long ldq, const void* dout, long l
     if (hd == 256) {
         constexpr int HD = 256, NW = 4;       // 2 key sub-blocks x 2 roles: 64 keys per workgroup
         dim3 grid(attn_grid((long)((S + NW * 16 - 1) / (NW * 16)) * nkv * B * hsplit, p.l2_map));
-        SF_ALLOW_SMEM((attn_bwd_dkv_rs_kernel<HD, NW>), 2 * (128 * HD * 2 + 512));
-        SF_LAUNCH((attn_bwd_dkv_rs_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (128 * HD * 2 + 512), stream, p);
+        if (sf_knob("SF_ATTN_W1", 1)) {     // the wave-pair kernel of sf_attn_w1_dkv.hip (same grid, same partial-sum layout)
+            const int st = attn_bwd_dkv_w1_launch(p, hd, stream);
+            if (st) return st;
+        } else {                            // (tools build A/B: round 2's role-split kernel)
+            SF_ALLOW_SMEM((attn_bwd_dkv_rs_kernel<HD, NW>), 2 * (128 * HD * 2 + 512));
+            SF_LAUNCH((attn_bwd_dkv_rs_kernel<HD, NW>), grid, dim3(NW * 64), 2 * (128 * HD * 2 + 512), stream, p);
+        }
         if (hsplit > 1) {
             const int W = nkv * hd;
             const long n4 = (long)B * S * (W / 4);

@@ -38,6 +38,7 @@ struct Fwd1Bank : AgprBank<HD / 32, HD / 16> {
     template <int I, bool FIRST> SF_DEVICE void mfma_s(sf_v16f& s, sf_v8s a) { Base::template mfma_vb<I, FIRST>(s, a); }
     template <int D> SF_DEVICE void mfma_o(sf_v8s a, sf_v8s b) { Base::template mfma_acc<D>(a, b); }
     template <int D> SF_DEVICE sf_v16f get_o() { return Base::template get<D>(); }
+    template <int D> SF_DEVICE void axpy_o(float f, const sf_v16f& x) { Base::template axpy<D>(f, x); }
     SF_DEVICE void rescale(float f) {
         static_for<0, DB>([&](auto D) SF_LAMBDA_INLINE { Base::template scale<decltype(D)::value>(f); });
     }
@@ -78,9 +79,9 @@ struct Fwd1Tile {
     }
     template <int U, int CH> SF_DEVICE void max_chunk() {       // chunk CH of 2: 8 scores of block U
         constexpr int r0 = CH * 8;
-        if (MASK && CH == 0) {                                  // -inf past the last visible key
+        if (MASK) {                                             // -inf past the last visible key (this chunk's 8 scores)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[U][r] = (U * 32 + (r & 3) + 8 * (r >> 2) > rel) ? -INFINITY : s[U][r];
+            for (int r = r0; r < r0 + 8; ++r) s[U][r] = (U * 32 + (r & 3) + 8 * (r >> 2) > rel) ? -INFINITY : s[U][r];
         }
         float x = CH == 0 ? s[U][r0] : fmaxf(mt[U], s[U][r0]);
 #pragma unroll
@@ -263,13 +264,13 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_fwd_w1_kernel(AttnFwdArgs p) {
     }
     sf_wait_vm0();   // (the stand-in pieces of the last iteration may still be in flight: LDS must not be reused or released under them)
     bank.drain();
-    sf_v16f acc_o[DB];
-    static_for<0, DB>([&](auto D) SF_LAMBDA_INLINE { acc_o[decltype(D)::value] = bank.template get_o<decltype(D)::value>(); });
     float l = sf_pair_sum(lpart);
 
     // diagonal branch terms: one extra key per later TTT step at the query's own position.  A wave only ever needs the K_i / V_i rows
     // of its OWN 32 queries, so each wave stages them into a private slice of the (now free) tile buffers -- no workgroup barrier per
-    // branch; the rows are consumed from LDS a few registers at a time (the accumulators and the Q fragments are 192 registers)
+    // branch.  The output accumulators STAY in the AGPR bank (O = O alpha + e V_i is a read-modify-write of one 16-register tile at a
+    // time): the compiler's registers hold the Q fragments and little else, so it never looks for spill space in the bank's AGPRs
+    // (tests/test_isa_invariants.py)
     if (p.ndiag > 0) {
         constexpr int PRIV = 2 * TILE / NW;             // bytes of LDS per wave: K_i rows | V_i rows
         static_assert(PRIV >= 2 * 32 * HD * 2, "a wave's slice of the tile buffers holds 32 rows of K_i and of V_i");
@@ -304,32 +305,34 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_fwd_w1_kernel(AttnFwdArgs p) {
             m = mn;
             l = l * alpha + e;
             const char* vrow = mine + 32 * HD * 2 + c * (HD * 2) + 8 * hi;
-#pragma unroll
-            for (int d = 0; d < DB; ++d)
+            static_for<0, DB>([&](auto D) SF_LAMBDA_INLINE {
+                constexpr int d = decltype(D)::value;
+                sf_v16f ev;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const sf_v4s vv = *reinterpret_cast<const sf_v4s*>(vrow + (((4 * d + j) ^ swz<HD>(c)) << 4));
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc_o[d][4 * j + t] = acc_o[d][4 * j + t] * alpha + e * sf_bf2f((sf_bf16)vv[t]);
+                    for (int t = 0; t < 4; ++t) ev[4 * j + t] = e * sf_bf2f((sf_bf16)vv[t]);
                 }
-#pragma unroll
-            for (int d = 0; d < DB; ++d) sf_pin(acc_o[d]);       // every LDS read of this branch has returned
+                bank.template axpy_o<d>(alpha, ev);     // (the asm reads ev: every LDS read of this tile has returned)
+            });
             if (i + 1 < p.ndiag) stage_diag(i + 1);
         }
     }
     if (!qok) return;
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     sf_bf16* orow = p.o + qrow * p.ldo + h * HD;
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
+    static_for<0, DB>([&](auto D) SF_LAMBDA_INLINE {
+        constexpr int d = decltype(D)::value;
+        const sf_v16f a = bank.template get_o<d>();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             sf_v4s ov;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) ov[t] = (short)sf_f2bf(acc_o[d][4 * j + t] * inv);
+            for (int t = 0; t < 4; ++t) ov[t] = (short)sf_f2bf(a[4 * j + t] * inv);
             *reinterpret_cast<sf_v4s*>(orow + d * 32 + 8 * j + 4 * hi) = ov;
         }
+    });
     if (hi == 0) p.lse[((long)b * p.nh + h) * S + qi] = l > 0.f ? (m + log2f(l)) * kLn2 : kNegBig;
 }
 

@@ -126,6 +126,43 @@ def test_ttt_attention_fwd_bwd(backend, hd, B, S, nh, nkv, lengths, nsteps):
 
 
 @pytest.mark.parametrize("hd", [64, 128, 256])
+@pytest.mark.parametrize("grow", ["block1", "block0", "both"])
+def test_forward_online_softmax_rescale_paths(backend, hd, grow):
+    """Scores that keep growing along the keys, so the running row max rises by more than 2^8 again and again: in the SECOND 32-key block of
+    a tile (the head_dim-256 kernel takes that block's exponentials speculatively and must redo them after draining the PV products
+    of the first block -- sf_attn_w1.hip fixup1), in the first block of a tile (the deferred rescale), or in both; plus the backward
+    kernels on the lse that comes out of it."""
+    B, S, nh, nkv, nsteps = 1, 330, 2, 1, 2
+    lengths = [301]
+    q, ks, vs, do = _mk(B, S, nh, nkv, hd, nsteps, seed=17 + hd)
+    blk = torch.arange(S) // 32
+    on = {"block1": blk % 2 == 1, "block0": blk % 2 == 0, "both": torch.ones(S, dtype=torch.bool)}[grow]
+    gain = 1.0 + 60.0 * torch.cumsum(on.float() * (torch.arange(S) % 32 == 0).float(), 0)    # +60 per selected 32-key block: the row max rises by ~100 nats each time -- an exponential taken against the old max overflows
+    k0 = (ks[0].float().view(B, S, nkv, hd) * gain.view(1, S, 1, 1)).to(torch.bfloat16).view(B, S, nkv * hd)
+    ks = [k0] + ks[1:]
+    o_ref, dq_ref, dk_ref, dv_ref = _oracle(q, ks, vs, do, B, S, nh, nkv, hd, lengths)
+    d = lambda t: t.to(backend)
+    N, scale = B * S, 1.0 / math.sqrt(hd)
+    qv, dout = d(q.view(N, -1)), d(do.view(N, -1))
+    K, V = [d(t.view(N, -1)) for t in ks], [d(t.view(N, -1)) for t in vs]
+    kv_len = d(torch.tensor(lengths, dtype=torch.int32))
+    o = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=backend)
+    lse = torch.empty(B, nh, S, device=backend)
+    ops.attn_fwd(qv, K[0], V[0], K[1:], V[1:], kv_len, o, lse, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+    torch.testing.assert_close(o.float().cpu(), o_ref, rtol=2e-2, atol=2e-2)
+    delta = torch.empty(B, nh, S, device=backend)
+    dq_init = torch.zeros(N, nh * hd, device=backend)
+    dk_acc = [torch.zeros(N, nkv * hd, device=backend) for _ in range(nsteps)]
+    dv_acc = [torch.zeros(N, nkv * hd, device=backend) for _ in range(nsteps)]
+    ops.attn_bwd_pre(qv, o, dout, K[1:], V[1:], dk_acc[1:], dv_acc[1:], lse, delta, dq_init, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+    dq = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=backend)
+    ops.attn_bwd_dq(qv, dout, K[0], V[0], kv_len, lse, delta, dq_init, dq, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+    ops.attn_bwd_dkv(qv, dout, K[0], V[0], kv_len, lse, delta, dk_acc[0], dv_acc[0], B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+    for got, ref, what in ((dq, dq_ref, "dq"), (dk_acc[0], dk_ref[0], "dk0"), (dv_acc[0], dv_ref[0], "dv0")):
+        assert float((got.float().cpu() - ref).abs().max()) <= 3e-2 * float(ref.abs().max()) + 1e-6, what
+
+
+@pytest.mark.parametrize("hd", [64, 128, 256])
 def test_dkv_head_split_equals_unsplit(backend, hd):
     """B * nkv * ceil(S / 128) < 512 (a bs 1 recipe): the dK/dV kernel divides the query heads of a kv group over several
     workgroups whose partial sums go through a workspace (sf_attn_bwd_dkv, ABI 5) -- same gradients as the unsplit launch

@@ -26,7 +26,8 @@ def _asm(src):
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         tmp = f"{out}.{os.getpid()}.tmp"       # (parallel test workers compile the same unit: publish the result atomically)
         subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-I", CSRC, "-ffp-contract=fast",
-                        "-fno-honor-nans", "-w", "-S", "--cuda-device-only", "-o", tmp, os.path.join(CSRC, src)], check=True)
+                        "-fno-honor-nans", "-w", "-S", "--cuda-device-only", "-o", tmp, os.path.join(CSRC, src)]
+                       + (["-fno-slp-vectorize"] if src.startswith("sf_attn_w1") else []), check=True)     # (specforge_amd/build.py EXTRA_FLAGS)
         os.replace(tmp, out)
     return open(out).read()
 
