@@ -222,6 +222,7 @@ struct AgprBank {
             for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
     }
     template <int I> SF_DEVICE void set_b(sf_v8s v) { bf[I] = v; }
+    template <int I> SF_DEVICE sf_v8s get_b() { return bf[I]; }
     template <int I, bool FIRST> SF_DEVICE void mfma_vb(sf_v16f& c, sf_v8s a) {   // c (+)= a . bf[I]   (c compiler-owned)
         if (FIRST) for (int r = 0; r < 16; ++r) c[r] = 0.f;
         c = sf_mfma32(a, bf[I], c);
@@ -247,6 +248,15 @@ struct AgprBank {
         asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\t"
                      "v_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
                      : : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "i"(B), "i"(B + 1), "i"(B + 2), "i"(B + 3));
+    }
+    template <int I> SF_DEVICE sf_v8s get_b() {          // fragment I back out of the bank (epilogues: 4 reads instead of 4 live registers)
+        typedef int v4i_ __attribute__((ext_vector_type(4)));
+        constexpr int B = kBf + 4 * I;
+        int w0, w1, w2, w3;
+        asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\t"
+                     "v_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+                     : "=v"(w0), "=v"(w1), "=v"(w2), "=v"(w3) : "i"(B), "i"(B + 1), "i"(B + 2), "i"(B + 3));
+        return __builtin_bit_cast(sf_v8s, v4i_{w0, w1, w2, w3});
     }
     template <int I, bool FIRST> SF_DEVICE void mfma_vb(sf_v16f& c, sf_v8s a) {
         constexpr int B = kBf + 4 * I;

@@ -28,6 +28,8 @@ using namespace sfattn;
 
 namespace {
 
+constexpr int kAheadEpi = 8;   // transposed V_i fragments in flight in the forward's diagonal-branch epilogue
+
 // ================================================================================================================= forward
 // AGPR map (HD = 256): a[0:127] O^T (8 x 16), a[128:191] Q fragments (16 x 4).
 template <int HD>
@@ -35,6 +37,7 @@ struct Fwd1Bank : AgprBank<HD / 32, HD / 16> {
     static constexpr int KS = HD / 16, DB = HD / 32;
     using Base = AgprBank<DB, KS>;
     template <int I> SF_DEVICE void set_q(sf_v8s v) { Base::template set_b<I>(v); }
+    template <int I> SF_DEVICE sf_v8s get_q() { return Base::template get_b<I>(); }
     template <int I, bool FIRST> SF_DEVICE void mfma_s(sf_v16f& s, sf_v8s a) { Base::template mfma_vb<I, FIRST>(s, a); }
     template <int D> SF_DEVICE void mfma_o(sf_v8s a, sf_v8s b) { Base::template mfma_acc<D>(a, b); }
     template <int D> SF_DEVICE sf_v16f get_o() { return Base::template get<D>(); }
@@ -264,60 +267,91 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_fwd_w1_kernel(AttnFwdArgs p) {
     }
     sf_wait_vm0();   // (the stand-in pieces of the last iteration may still be in flight: LDS must not be reused or released under them)
     bank.drain();
-    float l = sf_pair_sum(lpart);
 
-    // diagonal branch terms: one extra key per later TTT step at the query's own position.  A wave only ever needs the K_i / V_i rows
-    // of its OWN 32 queries, so each wave stages them into a private slice of the (now free) tile buffers -- no workgroup barrier per
-    // branch.  The output accumulators STAY in the AGPR bank (O = O alpha + e V_i is a read-modify-write of one 16-register tile at a
-    // time): the compiler's registers hold the Q fragments and little else, so it never looks for spill space in the bank's AGPRs
-    // (tests/test_isa_invariants.py)
+    // diagonal branch terms: one extra key per later TTT step at the query's own position -- for the wave's 32 queries a 32-key block
+    // whose score matrix is DIAGONAL.  So a branch runs through the same machinery as a key block: the diagonal scores q_t . k_i,t by
+    // VALU dot products, the deferred-rescale decision, P^T = diag(exp2(s - m)) packed to bf16 (the rounding every other probability
+    // gets), and O^T += V_i^T . P^T as 2 DB MFMAs on the otherwise idle matrix pipe -- the accumulators never leave the bank.  (Round 4's
+    // form, O = O alpha + e V_i in VALU, was ~850 instructions per branch and wave at this head width against ~180 + 16 MFMAs.)
+    // A wave only ever needs the K_i / V_i rows of its OWN 32 queries: each wave stages them into a private slice of the (now free)
+    // tile buffers -- no workgroup barrier per branch.
+    float l = sf_pair_sum(lpart);
     if (p.ndiag > 0) {
         constexpr int PRIV = 2 * TILE / NW;             // bytes of LDS per wave: K_i rows | V_i rows
+        constexpr int NG = 2 * DB;
         static_assert(PRIV >= 2 * 32 * HD * 2, "a wave's slice of the tile buffers holds 32 rows of K_i and of V_i");
         char* mine = smem + wave * PRIV;
-        sf_v8s qf[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            qf[ks] = *reinterpret_cast<const sf_v8s*>(p.q + qrow * p.ldq + h * HD + 16 * ks + 8 * hi);
+        const char* vslice = mine + 32 * HD * 2;
+        sf_v8s qf[KS];          // the Q fragments, back out of the bank (no global load: nothing here is a load the compiler counts)
+        static_for<0, KS>([&](auto I) SF_LAMBDA_INLINE { qf[decltype(I)::value] = bank.template get_q<decltype(I)::value>(); });
         TileStage<HD, 32, 1> ds;
         ds.init(p.ldk, 0, lane);
+        constexpr int NIE = TileStage<HD, 32, 1>::NI;   // DMA pieces of a K_i (or V_i) slice
         const unsigned my_rows = (unsigned)((long)qw0 * p.ldk * 2);
         sf_syncthreads();                               // every wave is done with the last K/V tile
-        auto stage_diag = [&](int i) {
-            const long slice = (long)b * S * p.ldk + g * HD;
-            ds.issue(rows_buf<HD>(p.kd[i] + slice, p.ldk, S), my_rows, mine);
-            ds.issue(rows_buf<HD>(p.vd[i] + slice, p.ldk, S), my_rows, mine + 32 * HD * 2);
+        // K_i and V_i are staged separately, each as soon as its half of the slice has been read: K_{i+1} arrives under the V_i work,
+        // V_{i+1} under the K_{i+1} wait and dot products.  Past the last branch the same pieces go out against an empty descriptor
+        // (zeros into a slice nobody reads), so the counted waits stay exact.
+        const long slice = (long)b * S * p.ldk + g * HD;
+        auto stage_k = [&](int i) SF_LAMBDA_INLINE {
+            const bool real = i < p.ndiag;
+            ds.issue(sf_bufb_if(rows_buf<HD>(p.kd[real ? i : 0] + slice, p.ldk, S), real), my_rows, mine);
         };
-        stage_diag(0);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) sf_pin(qf[ks]);
+        auto stage_v = [&](int i) SF_LAMBDA_INLINE {
+            const bool real = i < p.ndiag;
+            ds.issue(sf_bufb_if(rows_buf<HD>(p.vd[real ? i : 0] + slice, p.ldk, S), real), my_rows, mine + 32 * HD * 2);
+        };
+        stage_k(0);
+        stage_v(0);
+        // the diagonal element of the 32 x 32 block in the C layout: key row c sits in register (c & 3) + 4 (c >> 3) of the lane whose
+        // half `hi` equals bit 2 of c (crow(r, hi) = (r & 3) + 8 (r >> 2) + 4 hi)
+        const int rsel = ((c >> 2) & 1) == hi ? (c & 3) + 4 * (c >> 3) : -1;
         for (int i = 0; i < p.ndiag; ++i) {
-            sf_wait_vm0();
+            sf_wait_vmcnt<NIE>();  // K_i landed (V_i may still be in flight)
             sf_wave_lockstep();   // (interpreter only: the other lanes' pieces of this wave's DMA have been copied)
             float dp = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) dp += dot8(qf[ks], frag_rows<HD>(mine, 0, ks, fo));
+            sf_pin(dp);           // every read of the K half has returned
+            stage_k(i + 1);
             dp = sf_pair_sum(dp);
             const float s2 = dp * sc;
-            const float mn = fmaxf(m, s2);
-            const float alpha = sf_exp2(m - mn);
-            const float e = sf_exp2(s2 - mn);
-            m = mn;
-            l = l * alpha + e;
-            const char* vrow = mine + 32 * HD * 2 + c * (HD * 2) + 8 * hi;
-            static_for<0, DB>([&](auto D) SF_LAMBDA_INLINE {
-                constexpr int d = decltype(D)::value;
-                sf_v16f ev;
+            if (!sf_all(s2 - m <= 8.0f)) {      // deferred rescale, as in the tile loop (the branch MFMAs before it have to be complete)
+                bank.drain();
+                const float mn = fmaxf(m, s2);
+                const float alpha = sf_exp2_raw(m - mn);
+                m = mn;
+                l *= alpha;
+                bank.rescale(alpha);
+                bank.drain();
+            }
+            const float e = sf_exp2_raw(s2 - m);
+            l += e;
+            sf_v16f pd;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const sf_v4s vv = *reinterpret_cast<const sf_v4s*>(vrow + (((4 * d + j) ^ swz<HD>(c)) << 4));
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) ev[4 * j + t] = e * sf_bf2f((sf_bf16)vv[t]);
-                }
-                bank.template axpy_o<d>(alpha, ev);     // (the asm reads ev: every LDS read of this tile has returned)
+            for (int r = 0; r < 16; ++r) pd[r] = r == rsel ? e : 0.f;
+            sf_v8s pf[2] = {pack_bf16x8(pd, 0), pack_bf16x8(pd, 8)};
+            sf_wait_vmcnt<NIE>();  // V_i landed (K_{i+1} may still be in flight)
+            sf_wave_lockstep();
+            sf_v8s gf[kAheadEpi];
+            static_for<0, kAheadEpi>([&](auto I) SF_LAMBDA_INLINE {
+                constexpr int M = decltype(I)::value;
+                gf[M] = frag_tr<HD>(vslice, M % DB, 16 * (M / DB), fo);
             });
-            if (i + 1 < p.ndiag) stage_diag(i + 1);
+            sf_valu_to_mfma(pf[0]);
+            sf_valu_to_mfma(pf[1]);
+            SF_SCHED_FENCE();
+            static_for<0, NG>([&](auto I) SF_LAMBDA_INLINE {
+                constexpr int M = decltype(I)::value, jp = M / DB, d = M % DB;
+                bank.template mfma_o<d>(gf[M % kAheadEpi], pf[jp]);
+                if constexpr (M + kAheadEpi < NG) gf[M % kAheadEpi] = frag_tr<HD>(vslice, (M + kAheadEpi) % DB, 16 * ((M + kAheadEpi) / DB), fo);
+                SF_SCHED_FENCE();
+            });
+            // (every read of the V half has been consumed by an MFMA above: it may be overwritten)
+            stage_v(i + 1);
         }
+        sf_wait_vm0();          // (the stand-in pieces of the last branch: LDS must not be released under them)
+        bank.drain();
     }
     if (!qok) return;
     const float inv = l > 0.f ? 1.0f / l : 0.f;

@@ -37,10 +37,20 @@ struct PairBank : AgprBank<HD / 32, HD / 16> {       // a[0 : 16 DB) the wave's 
 
 constexpr int kAhead = 8;
 
+// The first kAhead transposed fragments of a gradient phase (G-slot M: d = M % DB, rows 16 (M / DB) ..)
+template <int HD, int M>
+SF_DEVICE sf_v8s grad_frag(const char* lds_x, const FragOff<HD>& fo) {
+    constexpr int DB = HD / 32;
+    return frag_tr<HD>(lds_x, M % DB, 16 * (M / DB), fo);
+}
+
 // score phase: c = rows(lds_rows) . bank fragments (KS MFMAs); `fill(slot)` supplies the fillers.  MFMA = false: the fillers alone (the
-// pipeline's last bodies: nothing left to score, the previous tile's arithmetic still due)
-template <int HD, bool MFMA, class Bank, class Fill>
-SF_DEVICE void score_phase(Bank& bank, const char* lds_rows, const FragOff<HD>& fo, sf_v16f& c, Fill&& fill) {
+// pipeline's last bodies: nothing left to score, the previous tile's arithmetic still due).  PRE: the gradient phase follows -- its first
+// kAhead fragments (of lds_x) are read in this phase's last kAhead slots, so it starts without a read burst of its own (a body is only
+// 32 MFMAs: each exposed burst is ~10 % of it)
+template <int HD, bool MFMA, bool PRE, class Bank, class Fill>
+SF_DEVICE void score_phase(Bank& bank, const char* lds_rows, const char* lds_x, const FragOff<HD>& fo, sf_v16f& c, sf_v8s (&gf)[kAhead],
+                           Fill&& fill) {
     constexpr int KS = HD / 16;
     static_assert(KS >= kAhead, "plan: head_dim >= 128");
     sf_v8s rf[kAhead];
@@ -54,29 +64,51 @@ SF_DEVICE void score_phase(Bank& bank, const char* lds_rows, const FragOff<HD>& 
             bank.template mfma_score<S, S == 0>(c, rf[S % kAhead]);
             if constexpr (S + kAhead < KS) rf[S % kAhead] = frag_rows<HD>(lds_rows, 0, S + kAhead, fo);
         }
+        if constexpr (PRE && S >= KS - kAhead) gf[S - (KS - kAhead)] = grad_frag<HD, S - (KS - kAhead)>(lds_x, fo);
         fill(std::integral_constant<int, S>{});
         SF_SCHED_FENCE();
     });
 }
 
-// gradient phase: acc[d] += tr(lds_x)(d, 16 jp) . f[jp]   (2 DB MFMAs)
-template <int HD, class Bank, class Fill>
-SF_DEVICE void grad_phase(Bank& bank, const char* lds_x, const FragOff<HD>& fo, const sf_v8s (&f)[2], Fill&& fill) {
+// gradient phase: acc[d] += tr(lds_x)(d, 16 jp) . f[jp]   (2 DB MFMAs); PRE: gf already holds the first kAhead fragments
+template <int HD, bool PRE, class Bank, class Fill>
+SF_DEVICE void grad_phase(Bank& bank, const char* lds_x, const FragOff<HD>& fo, const sf_v8s (&f)[2], sf_v8s (&gf)[kAhead], Fill&& fill) {
     constexpr int DB = HD / 32, NG = 2 * DB;
     static_assert(NG >= kAhead, "plan: head_dim >= 128");
-    sf_v8s gf[kAhead];
-    static_for<0, kAhead>([&](auto I) SF_LAMBDA_INLINE {
-        constexpr int M = decltype(I)::value;
-        gf[M] = frag_tr<HD>(lds_x, M % DB, 16 * (M / DB), fo);
-    });
-    SF_SCHED_FENCE();
+    if constexpr (!PRE) {
+        static_for<0, kAhead>([&](auto I) SF_LAMBDA_INLINE { gf[decltype(I)::value] = grad_frag<HD, decltype(I)::value>(lds_x, fo); });
+        SF_SCHED_FENCE();
+    }
     static_for<0, NG>([&](auto I) SF_LAMBDA_INLINE {
         constexpr int M = decltype(I)::value, jp = M / DB, d = M % DB;
         bank.template mfma_grad<d>(gf[M % kAhead], f[jp]);
-        if constexpr (M + kAhead < NG) gf[M % kAhead] = frag_tr<HD>(lds_x, (M + kAhead) % DB, 16 * ((M + kAhead) / DB), fo);
+        if constexpr (M + kAhead < NG) gf[M % kAhead] = grad_frag<HD, M + kAhead>(lds_x, fo);
         fill(std::integral_constant<int, M>{});
         SF_SCHED_FENCE();
     });
+}
+
+// one body of a role: [score (+ the previous tile's arithmetic as fillers)] [gradient (+ the DMA pieces as fillers)], either part optional
+template <int HD, class Bank, class FillS, class FillG, class Pieces>
+SF_DEVICE void pair_body(Bank& bank, bool do_s, bool do_e, const char* lds_rows, const char* lds_x, const FragOff<HD>& fo, sf_v16f& c,
+                         const sf_v8s (&f)[2], FillS&& fill_s, FillG&& fill_g, Pieces&& all_pieces) {
+    sf_v8s gf[kAhead];
+    if (do_s && do_e) {                 // the steady state
+        score_phase<HD, true, true>(bank, lds_rows, lds_x, fo, c, gf, fill_s);
+        grad_phase<HD, true>(bank, lds_x, fo, f, gf, fill_g);
+    } else if (do_e) {                  // the pipeline's tail: nothing left to score
+        score_phase<HD, false, true>(bank, lds_rows, lds_x, fo, c, gf, fill_s);
+        grad_phase<HD, true>(bank, lds_x, fo, f, gf, fill_g);
+    } else {
+        if (do_s) {                     // the pipeline's head (or a tile before this pair's keys behind it)
+            score_phase<HD, true, false>(bank, lds_rows, lds_x, fo, c, gf, fill_s);
+            // the scores are copied right behind this (no gradient phase in between): an MFMA result in VGPRs is read by VALU only after
+            // the matrix pipe has delivered it -- the asm MFMAs are invisible to the compiler's hazard recogniser (on the steady path the
+            // distance is 16+ MFMA slots)
+            sf_mfma_drain();
+        }
+        all_pieces();
+    }
 }
 
 template <int HD>
@@ -132,41 +164,46 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_pair_kernel(AttnBwdArgs p) 
     const sf_bf16* dob_base = p.dout + (long)b * S * p.lddo + (long)h_first * HD;
     const float* lse_base = p.lse + ((long)b * p.nh + h_first) * S;
     const float* dlt_base = p.delta + ((long)b * p.nh + h_first) * S;
-    auto q0_of = [&](int t) SF_LAMBDA_INLINE { return (qt_first + (t % per_head)) * QT; };
     char* const q_ring = smem;
     char* const do_ring = smem + NQ * SLOT;
+    // Tile t of the head-major walk = (head hh, 32-query tile qt).  Three walkers run ahead of each other -- the Q stream (tile n + 3 in
+    // body n), the dO stream (n + 2), the arithmetic (n + 1) -- each advanced by one tile per body with a compare and an add: a division
+    // per coordinate and body was ~150 scalar / vector instructions between the last MFMA of a body and the first of the next.
+    struct Walk {
+        int t, hh, qt, slot;            // tile index (may start below 0), its coordinates (those of tile 0 while t <= 0), its ring slot
+    };
+    auto advance = [&](Walk& w, int nslots) SF_LAMBDA_INLINE {
+        ++w.t;
+        if (w.t > 0 && ++w.qt == nqt) { w.qt = qt_first; ++w.hh; }
+        if (++w.slot == nslots) w.slot = 0;
+    };
+    auto real = [&](const Walk& w) SF_LAMBDA_INLINE { return w.t >= 0 && w.t < n_it; };
     // DMA group m (issued in body m; before the loop for m = -3, -2): Q(m+3) + delta(m+3) into Q slot (m+3) % NQ, dO(m+2) + lse(m+2) into dO
     // slot (m+2) % ND.  Every wave issues NGRP pieces per group whatever the tile indices (an empty descriptor outside [0, n_it): zeros
     // into a slot nobody reads), so the counted wait at the top of a body stays exact.  The 4-byte piece covers 64 queries: the second
     // half belongs to the next tile (or is past the sequence: zeros) and is not read.
-    auto coords = [&](int t, bool& real, int& hh, int& qt) SF_LAMBDA_INLINE {
-        real = t >= 0 && t < n_it;
-        const int tt = real ? t : 0;
-        hh = tt / per_head;
-        qt = qt_first + (tt - hh * per_head);
-    };
+    Walk wq{0, 0, qt_first, 0}, wd{-1, 0, qt_first, ND - 1};
     struct Grp { SfBufB q, dout, aux; unsigned qoff, dooff, auxoff; char* qdst; char* ddst; char* adst; };
-    auto group = [&](int m) SF_LAMBDA_INLINE {      // descriptors / offsets / destinations of group m (scalar work, once per body)
-        bool rq, rd;
-        int hq, tq, hd_, td;
-        coords(m + 3, rq, hq, tq);
-        coords(m + 2, rd, hd_, td);
+    auto group = [&]() SF_LAMBDA_INLINE {      // descriptors / offsets / destinations of the next group (scalar work, once per body)
+        const bool rq = real(wq), rd = real(wd);
         Grp r;
-        r.qdst = q_ring + ((m + 3 + NQ) % NQ) * SLOT;
-        r.ddst = do_ring + ((m + 2 + ND) % ND) * SLOT;
-        r.q = sf_bufb_if(rows_buf<HD>(qb_base + hq * HD, p.ldq, S), rq);
-        r.dout = sf_bufb_if(rows_buf<HD>(dob_base + hd_ * HD, p.lddo, S), rd);
-        r.qoff = (unsigned)tq * qtile;
-        r.dooff = (unsigned)td * dotile;
+        r.qdst = q_ring + wq.slot * SLOT;
+        r.ddst = do_ring + wd.slot * SLOT;
+        r.q = sf_bufb_if(rows_buf<HD>(qb_base + wq.hh * HD, p.ldq, S), rq);
+        r.dout = sf_bufb_if(rows_buf<HD>(dob_base + wd.hh * HD, p.lddo, S), rd);
+        r.qoff = (unsigned)wq.qt * qtile;
+        r.dooff = (unsigned)wd.qt * dotile;
         if (wave & 1) {     // delta(m+3) (waves 1 and 3 write the same bytes), lse(m+2) (waves 0 and 2)
-            r.aux = sf_bufb_if(sf_make_bufb(dlt_base + (long)hq * S, (unsigned)S * 4u), rq);
-            r.auxoff = (unsigned)(tq * QT + lane) * 4u;
+            r.aux = sf_bufb_if(sf_make_bufb(dlt_base + (long)wq.hh * S, (unsigned)S * 4u), rq);
+            r.auxoff = (unsigned)(wq.qt * QT + lane) * 4u;
             r.adst = r.qdst + ROWS;
         } else {
-            r.aux = sf_bufb_if(sf_make_bufb(lse_base + (long)hd_ * S, (unsigned)S * 4u), rd);
-            r.auxoff = (unsigned)(td * QT + lane) * 4u;
+            r.aux = sf_bufb_if(sf_make_bufb(lse_base + (long)wd.hh * S, (unsigned)S * 4u), rd);
+            r.auxoff = (unsigned)(wd.qt * QT + lane) * 4u;
             r.adst = r.ddst + ROWS;
         }
+        advance(wq, NQ);
+        advance(wd, ND);
         return r;
     };
     auto piece = [&](const Grp& r, int k) SF_LAMBDA_INLINE {   // piece k of NGRP (compile-time k at every call site)
@@ -174,12 +211,12 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_pair_kernel(AttnBwdArgs p) 
         else if (k < 2 * NI) sf_bufb_glds16(r.dout, stdo.off[k - NI] + r.dooff, r.ddst + (stdo.piece0 + k - NI) * 1024);
         else sf_bufb_glds4(r.aux, r.auxoff, r.adst);
     };
-    auto stage = [&](int m) SF_LAMBDA_INLINE {
-        const Grp r = group(m);
+    auto stage = [&]() SF_LAMBDA_INLINE {
+        const Grp r = group();
         static_for<0, NGRP>([&](auto K) SF_LAMBDA_INLINE { piece(r, decltype(K)::value); });
     };
-    stage(-3);
-    stage(-2);
+    stage();        // groups -3, -2
+    stage();
 
     char* xch = smem + (NQ + ND) * SLOT + sub * XCH;         // + parity * 2 * XCH
     sf_v16f s_cur, s_next, dp_prev, dp_cur;                  // A: S(n), S(n+1)   |   B: dP(n-1), dP(n)
@@ -189,29 +226,35 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_pair_kernel(AttnBwdArgs p) 
     f[0] = sf_v8s{0, 0, 0, 0, 0, 0, 0, 0};
     f[1] = f[0];
 
+    // the arithmetic's walker (tile n + 1 in body n) and what it leaves behind for tiles n and n - 1: liveness -- a tile whose 32 queries
+    // all lie before this pair's keys contributes nothing (wave-uniform, the same for both roles) -- and the first query of tile n
+    Walk wc{0, 0, qt_first, 0};
+    bool lv_0 = false, lv_m1 = false;
+    int q0_0 = 0, slot_q_m1 = NQ - 2, slot_do_0 = ND - 1, par = 1;     // body -1: Q(-2) -> slot 3, dO(-1) -> slot 2, parity of n = -1
     for (int n = -1; n <= n_it; ++n) {
         sf_wait_vmcnt<NGRP>();  // group n - 2 landed (Q(n+1), delta(n+1), dO(n), lse(n)); group n - 1 may be in flight
         sf_syncthreads();       // ... for everyone; Q slot (n+3) % 5, dO slot (n+2) % 3 and exchange parity n & 1 are no longer being read
         // group n's DMA pieces are fillers of the gradient phase's first slots (a body without one issues them on the spot)
-        const Grp grp = group(n);
+        const Grp grp = group();
         auto dma = [&](auto Sl) SF_LAMBDA_INLINE {
             constexpr int k = decltype(Sl)::value;
             if constexpr (k < NGRP) piece(grp, k);
         };
-        const char* q_m1 = q_ring + ((n - 1 + NQ) % NQ) * SLOT;          // Q(n-1) | delta(n-1)
-        const char* q_p1 = q_ring + ((n + 1 + NQ) % NQ) * SLOT;          // Q(n+1)
-        const char* do_0 = do_ring + ((n + ND) % ND) * SLOT;             // dO(n) | lse(n)
-        // a tile whose 32 queries all lie before this pair's keys contributes nothing (wave-uniform, the same for both roles)
-        auto live = [&](int t) SF_LAMBDA_INLINE { return t >= 0 && t < n_it && q0_of(t) + QT - 1 >= kw0; };
+        auto all_pieces = [&]() SF_LAMBDA_INLINE { static_for<0, NGRP>([&](auto K) SF_LAMBDA_INLINE { piece(grp, decltype(K)::value); }); };
+        const char* q_m1 = q_ring + slot_q_m1 * SLOT;                    // Q(n-1) | delta(n-1)
+        const char* q_p1 = q_ring + wc.slot * SLOT;                      // Q(n+1)
+        const char* do_0 = do_ring + slot_do_0 * SLOT;                   // dO(n) | lse(n)
+        const int q0_p1 = wc.qt * QT;
+        const bool lv_p1 = real(wc) && q0_p1 + QT - 1 >= kw0;
         if (role == 0) {
             // ---- A: S(n+1) beside exp(n); then dV(n)
-            const bool do_s = live(n + 1), do_e = live(n);
-            const int q0 = do_e ? q0_of(n) : 0;
+            const bool do_s = lv_p1, do_e = lv_0;
+            const int q0 = q0_0;
             const int lo = key_lo - q0 - 4 * hi, up = S - q0 - 4 * hi;
             const float* ll = reinterpret_cast<const float*>(do_0 + ROWS);
-            char* xw = xch + (n & 1) * 2 * XCH + lane * 16;
+            char* xw = xch + par * 2 * XCH + lane * 16;
             sf_v4f l4[4];
-            // exp(n) as fillers of the score slots: lse reads in slots 0, 1; the 16 elements over slots 4 .. 11; P to the partner (fp32, this
+            // exp(n) as fillers of the score slots: lse reads in slots 0, 1; the 16 elements over slots 3 .. 14; P to the partner (fp32, this
             // lane's own 16 bytes of row block j) after every fourth, packed for the own dV MFMAs after every eighth.  MASK: only tiles that
             // touch the diagonal, the padding or the end of the sequence pay for the select (wave-uniform)
             auto fill_for = [&](auto MaskTag) SF_LAMBDA_INLINE {
@@ -222,8 +265,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_pair_kernel(AttnBwdArgs p) 
                         l4[2 * sl] = *reinterpret_cast<const sf_v4f*>(ll + 8 * (2 * sl) + 4 * hi);
                         l4[2 * sl + 1] = *reinterpret_cast<const sf_v4f*>(ll + 8 * (2 * sl + 1) + 4 * hi);
                     }
-                    if constexpr (sl >= 4 && sl < 4 + 8) {
-                        static_for<2 * (sl - 4), 2 * (sl - 4) + 2>([&](auto EE) SF_LAMBDA_INLINE {
+                    if constexpr (sl >= 3 && sl < 3 + 12) {          // 16 elements over 12 slots
+                        static_for<(sl - 3) * 16 / 12, (sl - 2) * 16 / 12>([&](auto EE) SF_LAMBDA_INLINE {
                             constexpr int E = decltype(EE)::value, j = E / 4, t = E % 4;
                             float x = fmaf(s_cur[E], sc, -kLog2e * l4[j][t]);
                             if constexpr (MASK) {
@@ -239,25 +282,15 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_pair_kernel(AttnBwdArgs p) 
                 };
             };
             const bool need_mask = (q0 < kw0 + 32) || (kw0 + 31 >= kvlen) || (q0 + QT - 1 >= S);      // wave-uniform
-            if (do_e || do_s) {
-                if (need_mask) {
-                    auto fill = fill_for(std::true_type{});
-                    if (do_s) score_phase<HD, true>(bank, q_p1, fo, s_next, fill);
-                    else score_phase<HD, false>(bank, q_p1, fo, s_next, fill);
-                } else {
-                    auto fill = fill_for(std::false_type{});
-                    if (do_s) score_phase<HD, true>(bank, q_p1, fo, s_next, fill);
-                    else score_phase<HD, false>(bank, q_p1, fo, s_next, fill);
-                }
-            }
-            if (do_e) grad_phase<HD>(bank, do_0, fo, f, dma);              // dV^T += dO(n)^T . P(n)
-            else static_for<0, NGRP>([&](auto K) SF_LAMBDA_INLINE { piece(grp, decltype(K)::value); });
+            // S(n+1) = Q(n+1) . K^T beside exp(n); then dV^T += dO(n)^T . P(n)
+            if (need_mask) pair_body<HD>(bank, do_s, do_e, q_p1, do_0, fo, s_next, f, fill_for(std::true_type{}), dma, all_pieces);
+            else pair_body<HD>(bank, do_s, do_e, q_p1, do_0, fo, s_next, f, fill_for(std::false_type{}), dma, all_pieces);
             s_cur = s_next;
         } else {
             // ---- B: dP(n) beside dS(n-1); then dK(n-1)
-            const bool do_s = live(n), do_e = live(n - 1);
+            const bool do_s = lv_0, do_e = lv_m1;
             const float* dd = reinterpret_cast<const float*>(q_m1 + ROWS);
-            const char* xr = xch + ((n - 1) & 1) * 2 * XCH + lane * 16;
+            const char* xr = xch + (par ^ 1) * 2 * XCH + lane * 16;
             sf_v4f d4[4], p4[4];
             auto fill = [&](auto Sl) SF_LAMBDA_INLINE {
                 constexpr int sl = decltype(Sl)::value;
@@ -277,14 +310,17 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_pair_kernel(AttnBwdArgs p) 
                     });
                 }
             };
-            if (do_e || do_s) {
-                if (do_s) score_phase<HD, true>(bank, do_0, fo, dp_cur, fill);
-                else score_phase<HD, false>(bank, do_0, fo, dp_cur, fill);
-            }
-            if (do_e) grad_phase<HD>(bank, q_m1, fo, f, dma);               // dK^T += Q(n-1)^T . dS(n-1)
-            else static_for<0, NGRP>([&](auto K) SF_LAMBDA_INLINE { piece(grp, decltype(K)::value); });
+            // dP(n) = dO(n) . V^T beside dS(n-1); then dK^T += Q(n-1)^T . dS(n-1)
+            pair_body<HD>(bank, do_s, do_e, do_0, q_m1, fo, dp_cur, f, fill, dma, all_pieces);
             dp_prev = dp_cur;
         }
+        lv_m1 = lv_0;
+        lv_0 = lv_p1;
+        q0_0 = q0_p1;
+        advance(wc, NQ);
+        if (++slot_q_m1 == NQ) slot_q_m1 = 0;
+        if (++slot_do_0 == ND) slot_do_0 = 0;
+        par ^= 1;
     }
     sf_wait_vm0();   // (the stand-in pieces of the last bodies are still in flight: LDS must not be released under them)
     bank.drain();

@@ -140,6 +140,8 @@ def test_forward_online_softmax_rescale_paths(backend, hd, grow):
     gain = 1.0 + 60.0 * torch.cumsum(on.float() * (torch.arange(S) % 32 == 0).float(), 0)    # +60 per selected 32-key block: the row max rises by ~100 nats each time -- an exponential taken against the old max overflows
     k0 = (ks[0].float().view(B, S, nkv, hd) * gain.view(1, S, 1, 1)).to(torch.bfloat16).view(B, S, nkv * hd)
     ks = [k0] + ks[1:]
+    if grow == "both":      # ... and a diagonal branch whose scores tower over the block-0 maximum for half of the rows (the epilogue's rescale)
+        ks[1] = (ks[1].float() * 400.0).to(torch.bfloat16)
     o_ref, dq_ref, dk_ref, dv_ref = _oracle(q, ks, vs, do, B, S, nh, nkv, hd, lengths)
     d = lambda t: t.to(backend)
     N, scale = B * S, 1.0 / math.sqrt(hd)

@@ -16,7 +16,8 @@ import torch
 sys.path.insert(0, ".")
 from specforge_amd import _lib, ops  # noqa: E402
 
-_lib._inject_library_for_tests(os.path.join("tools", "experiments", "libsfhip_ablate.so"))
+_LIB = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--lib=")), os.path.join("tools", "experiments", "libsfhip_ablate.so"))
+_lib._inject_library_for_tests(_LIB)       # (--lib=...: another build of the tools library, e.g. other compiler flags)
 _lib._emulated = False
 dev = "cuda"
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
