@@ -129,6 +129,30 @@ def test_dkv_register_bank_is_untouched_by_the_compiler():
         assert md["vgpr_count"] - bank <= 256 and md["vgpr_count"] <= 512, (name, md["vgpr_count"])
 
 
+@hipcc
+@pytest.mark.parametrize("src,pattern,bank", [("sf_attn_w1.hip", "attn_fwd_w1_kernel", 192), ("sf_attn_w1.hip", "attn_bwd_dq_w1_kernel", 256),
+                                              ("sf_attn_w1_dkv.hip", "attn_bwd_dkv_pair_kernel", 192)])
+def test_head_dim_256_kernels_keep_the_compiler_out_of_their_register_bank(src, pattern, bank):
+    """The one-wave-per-SIMD head_dim-256 kernels (round 5) keep their accumulators and B-operand fragments in asm-owned AGPRs
+    (AgprBank).  hipcc does not know the bank is taken: the moment its own pressure passes 256 VGPRs anywhere in the kernel it
+    spills into a0.. -- the accumulators -- silently (seen twice while the forward's epilogue was written: 48 address values parked in
+    a0..a47 for the whole tile loop).  So: no compiler-emitted instruction may name an AGPR, no scratch, no spills, the only vmcnt
+    waits between the first and the last MFMA are the kernels' own, and every MFMA is one of the planned stream."""
+    ks = _kernels(_asm(src), pattern)
+    assert len(ks) == 1, list(ks)
+    (name, (body, md)), = ks.items()
+    assert md["vgpr_spill_count"] == 0 and md["sgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0, md
+    ins = list(_compiler_lines(body))
+    bad = [t for t, inasm in ins if not inasm and ("accvgpr" in t or re.search(r"[\s,\[]a\[?\d", t))]
+    assert not bad, (name, bad[:4])
+    assert md["vgpr_count"] - bank <= 256 and md["vgpr_count"] <= 512, md["vgpr_count"]     # the bank + what the compiler uses
+    mf = [i for i, (t, _) in enumerate(ins) if "v_mfma" in t]
+    inner = ins[mf[0]:mf[-1]]
+    assert not [t for t, inasm in inner if not inasm and t.startswith("s_waitcnt") and "vmcnt" in t], name
+    assert [t for t, inasm in ins if inasm and t.startswith("s_waitcnt") and "vmcnt" in t], (name, "the loop's own vmcnt wait is missing")
+    assert not [t for t, _ in ins if t.startswith("scratch_")], name
+
+
 _W4_UNITS = ["sf_gemm256w4_i%d.hip" % i for i in range(7)]
 _w4_compiled = []
 
