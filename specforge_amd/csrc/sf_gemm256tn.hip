@@ -577,7 +577,7 @@ extern "C" int sf_gemm_tn(const void* A, long lda, const void* B, long ldb, void
     }
 #endif
     // plan: which operand's LDS halves are released / re-staged first (0 = B, 1 = A).  Measured on the step's shapes
-    // (profiles/r2_gemm_tn_ab.jsonl): A first wins for wide X (down-proj, N = 14336), B first elsewhere; both beat the
+    // (profiles/old/r2_gemm_tn_ab.jsonl): A first wins for wide X (down-proj, N = 14336), B first elsewhere; both beat the
     // round-1 schedule (tools build: SF_GEMM_TN_PLAN=-1) by 3-8 %.
     const int plan = sf_knob("SF_GEMM_TN_PLAN", N > 8192 ? 1 : 0);
     const bool f32_main = p.ksplit > 1 || c_dtype == SF_F32;

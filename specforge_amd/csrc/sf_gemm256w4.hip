@@ -17,7 +17,7 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     // GM = m-tiles per group of the tile order (a group walks its m-tiles fastest, then the n-tiles; an XCD runs 32 consecutive
     // tiles at a time, so GM sets how many A / B panels its L2 holds at once).  A per-shape choice was measured and rejected
     // (round 3): on one box GM = 1 gained 3-4 % on narrow-N / mid-K shapes and 8 gained 0.5-0.9 % on wide N, on the next box the
-    // same sweep showed nothing, and in-step the per-shape table was 0.3 ms SLOWER than 4 everywhere (profiles/r3_gemm_gm_ab.jsonl).
+    // same sweep showed nothing, and in-step the per-shape table was 0.3 ms SLOWER than 4 everywhere (profiles/old/r3_gemm_gm_ab.jsonl).
     p.gm = sf_knob("SF_GEMM_GM", 4);
     if (p.gm < 1) p.gm = 1;
     long nblk = (long)p.tiles_m * p.tiles_n;

@@ -23,13 +23,13 @@
 //                        iteration's 16 pieces stay in flight.  DMA lead: 1.1 .. 1.7 iterations (2400 .. 3700 cycles).
 //       slots 110..126 : the 16 fragment reads of (t+1, k-half 0)
 //     Two plans differ in which operand goes first: B first is faster when N is narrow (<= 8192: +4..6 % over A
-//     first), A first when N is wide (+2..4 %) -- measured, profiles/r2_gemm_ab.jsonl; the launcher picks by N.
+//     first), A first when N is wide (+2..4 %) -- measured, profiles/old/r2_gemm_ab.jsonl; the launcher picks by N.
 //     RAW: a tile is read only after (own pieces landed: counted vmcnt) + barrier.  WAR: an operand half is re-staged
 //     only after (own reads returned: lgkmcnt(0)) + barrier; its k-half-0 fragments were read in iteration t-1.
 //   * round-1 schedule (one barrier per K-tile, groups of 4 MFMAs + 2 reads, DMA in the second half-step, vmcnt(0)):
-//     30 % more cycles than hipBLASLt on the same shape; this one 10 % (SQ_WAVE_CYCLES, profiles/r2_gemm_pmc.txt).
+//     30 % more cycles than hipBLASLt on the same shape; this one 10 % (SQ_WAVE_CYCLES, profiles/old/r2_gemm_pmc.txt).
 //     Cycles per K-tile read inside the kernel (tools build, SF_GEMM_CYC): MFMAs alone 2083, this loop 2251
-//     (profiles/r2_gemm_cycles.jsonl).
+//     (profiles/old/r2_gemm_cycles.jsonl).
 //     It and the intermediate plans live in tools/experiments/sf_gemm256w4_sched.inc (tools build only).
 #pragma once
 #include "sf_api_internal.h"

@@ -57,7 +57,7 @@ def normalize_offline_sample(raw: Dict[str, torch.Tensor], max_len: int) -> Dict
 # 64-byte-aligned record ``<name>/data/<key>`` per storage.  For the ingest that is all that is needed: the byte range of every
 # tensor.  ``torch.load(mmap=True)`` + normalise + ``copy_`` went through three Python-level tensor passes per sample and an
 # OpenMP team per copy; eight loader processes on one host (one per rank) reached 7.5 GB/s together where the ranks need 20
-# (tools/ingest_procs.py, profiles/r3_ingest_procs.json).  Here the file's bytes go from the page cache into the pinned staging
+# (tools/ingest_procs.py, profiles/old/r3_ingest_procs.json).  Here the file's bytes go from the page cache into the pinned staging
 # slot with ONE ``preadv`` per tensor (the GIL is released for its duration, so a small thread pool reads the samples of a
 # batch concurrently), and nothing else touches them.
 _STORAGE_DTYPES = {"BFloat16Storage": torch.bfloat16, "LongStorage": torch.int64, "FloatStorage": torch.float32,
