@@ -48,8 +48,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, AttnOcc<HD>::kWgPerCu) attn_fwd_kernel(
     int qbi, h, b, g;
     if (p.l2_map) {   // pair-major: (batch, kv head) -> query block (last = heaviest first) -> query head of the group
         const int nrep = p.nh / p.nkv, W = nrep * nqb;
-        const int v = attn_work_index((int)blockIdx.x, W * p.nkv * p.B, 1);
-        if (v >= W * p.nkv * p.B) return;
+        const int v = attn_pair_major_index((int)blockIdx.x, W, p.nkv * p.B);
+        if (v < 0) return;
         const int pr = v / W, w = v - pr * W;
         b = pr / p.nkv; g = pr - b * p.nkv;
         qbi = nqb - 1 - w / nrep; h = g * nrep + w % nrep;
@@ -626,8 +626,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, AttnOcc<HD>::kWgPerCu) attn_bwd_dq_kern
     int qbi, h, b, g;
     if (p.l2_map) {   // pair-major: (batch, kv head) -> query block (last = heaviest first) -> query head of the group
         const int nrep = p.nh / p.nkv, W = nrep * nqb;
-        const int v = attn_work_index((int)blockIdx.x, W * p.nkv * p.B, 1);
-        if (v >= W * p.nkv * p.B) return;
+        const int v = attn_pair_major_index((int)blockIdx.x, W, p.nkv * p.B);
+        if (v < 0) return;
         const int pr = v / W, w = v - pr * W;
         b = pr / p.nkv; g = pr - b * p.nkv;
         qbi = nqb - 1 - w / nrep; h = g * nrep + w % nrep;
@@ -781,7 +781,8 @@ extern "C" int sf_attn_fwd(const void* q, long ldq, const void* k0, long ldk, co
     p.l2_map = sf_knob("SF_ATTN_L2MAP", 1);
     SF_CHECK_ARG((long)S * ldk * 2 < (1L << 31), "sf_attn_fwd: S * ldk exceeds the 2 GiB range of a buffer descriptor");
     constexpr int NW = kAttnFwdWaves;
-    dim3 grid(attn_grid((long)((S + NW * 32 - 1) / (NW * 32)) * nh * B, p.l2_map));
+    const long nqb = (S + NW * 32 - 1) / (NW * 32);
+    dim3 grid(p.l2_map ? attn_pair_major_grid(nqb * (nh / nkv), (long)nkv * B) : (unsigned)(nqb * nh * B));
 #if defined(SF_ABLATE) && !defined(SF_EMU)
     if (sf_knob("SF_ATTN_FWD_W4", 0))   // tools build: the measured-and-rejected one-wave-per-SIMD variant
         return sfattn_w4::attn_fwd(q, ldq, k0, ldk, v0, kd, vd, ndiag, kv_len, o, ldo, lse, B, S, nh, nkv, hd, scale, stream);
@@ -911,7 +912,8 @@ extern "C" int sf_attn_bwd_dq(const void* q, long ldq, const void* dout, long ld
     SF_CHECK_ARG((long)S * ldk * 2 < (1L << 31) && (long)S * ldv * 2 < (1L << 31),
                  "sf_attn_bwd_dq: S * ld exceeds the 2 GiB range of a buffer descriptor");
     constexpr int NW = kAttnFwdWaves;
-    dim3 grid(attn_grid((long)((S + NW * 32 - 1) / (NW * 32)) * nh * B, p.l2_map));
+    const long nqb = (S + NW * 32 - 1) / (NW * 32);
+    dim3 grid(p.l2_map ? attn_pair_major_grid(nqb * (nh / nkv), (long)nkv * B) : (unsigned)(nqb * nh * B));
     if (hd == 256 && sf_knob("SF_ATTN_W1", 1)) return attn_bwd_dq_w1_launch(p, hd, stream);    // (sf_attn_w1.hip)
     SF_HD_DISPATCH(hd, SF_ALLOW_SMEM((attn_bwd_dq_kernel<HD, NW>), 2 * 128 * HD * 2);
                    SF_LAUNCH((attn_bwd_dq_kernel<HD, NW>), grid, dim3(NW * 64), 2 * 128 * HD * 2, stream, p));

@@ -29,6 +29,26 @@ SF_DEVICE int attn_work_index(int bid, int total, int l2_map) {
 }
 static inline unsigned attn_grid(long total, int l2_map) { return (unsigned)(l2_map ? 8 * ((total + 7) / 8) : total); }
 
+// The same for a list of P pairs x W items, heaviest item first INSIDE a pair (forward / dQ: the causal key range grows with the query
+// block).  Cutting that list into 8 contiguous ranges is balanced only when every XCD gets whole pairs.  With FEWER pairs than XCDs -- the
+// batch-1 recipes: 1 x 4 kv heads, 1 x 2 -- a pair is spread over X = 8 / P XCDs and contiguous ranges hand the first of them the heavy half
+// of the pair and the last the light one (P = 2, S 4096: 114 vs 18 key tiles per CU; the launch lasts as long as the heaviest XCD, measured
+// 1.45x the batch-8 time per flop).  Then the X XCDs of a pair take its items IN TURN instead: every XCD of the pair walks the same
+// heaviest-first profile, the pair's K / V are still shared by X L2s only.  -> index into the pair-major list, or -1 (no work)
+SF_DEVICE int attn_pair_major_index(int bid, int W, int P) {
+    const int xcd = bid & 7, pos = bid >> 3;
+    if (P < 8 && 8 % P == 0) {
+        const int X = 8 / P, w = pos * X + xcd % X;
+        return w < W ? (xcd / X) * W + w : -1;
+    }
+    const int total = W * P, v = xcd * ((total + 7) >> 3) + pos;
+    return v < total ? v : -1;
+}
+static inline unsigned attn_pair_major_grid(long W, long P) {
+    if (P < 8 && 8 % P == 0) return (unsigned)(8 * ((W + 8 / P - 1) / (8 / P)));
+    return (unsigned)(8 * ((W * P + 7) / 8));
+}
+
 struct AttnFwdArgs {
     const sf_bf16* q; long ldq;        // [B*S, nh*hd] view, row stride ldq
     const sf_bf16* k0; long ldk;       // step-0 keys [B*S, nkv*hd] view

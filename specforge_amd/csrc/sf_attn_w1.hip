@@ -192,8 +192,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_fwd_w1_kernel(AttnFwdArgs p) {
     int qbi, h, b, g;
     if (p.l2_map) {
         const int nrep = p.nh / p.nkv, W = nrep * nqb;
-        const int v = attn_work_index((int)blockIdx.x, W * p.nkv * p.B, 1);
-        if (v >= W * p.nkv * p.B) return;
+        const int v = attn_pair_major_index((int)blockIdx.x, W, p.nkv * p.B);
+        if (v < 0) return;
         const int pr = v / W, w = v - pr * W;
         b = pr / p.nkv; g = pr - b * p.nkv;
         qbi = nqb - 1 - w / nrep; h = g * nrep + w % nrep;
@@ -465,8 +465,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dq_w1_kernel(AttnBwdArgs p) {
     int qbi, h, b, g;
     if (p.l2_map) {   // pair-major: (batch, kv head) -> query block (last = heaviest first) -> query head of the group
         const int nrep = p.nh / p.nkv, W = nrep * nqb;
-        const int v = attn_work_index((int)blockIdx.x, W * p.nkv * p.B, 1);
-        if (v >= W * p.nkv * p.B) return;
+        const int v = attn_pair_major_index((int)blockIdx.x, W, p.nkv * p.B);
+        if (v < 0) return;
         const int pr = v / W, w = v - pr * W;
         b = pr / p.nkv; g = pr - b * p.nkv;
         qbi = nqb - 1 - w / nrep; h = g * nrep + w % nrep;
@@ -577,7 +577,8 @@ namespace sfattn {
 int attn_fwd_w1_launch(const AttnFwdArgs& p, int hd, void* stream) {
     SF_CHECK_ARG(hd == 256, "attn_fwd_w1: head_dim 256 only");
     constexpr int HD = 256;
-    dim3 grid(attn_grid((long)((p.S + 127) / 128) * p.nh * p.B, p.l2_map));   // 128 queries per workgroup
+    const long nqb = (p.S + 127) / 128;     // 128 queries per workgroup
+    dim3 grid(p.l2_map ? attn_pair_major_grid(nqb * (p.nh / p.nkv), (long)p.nkv * p.B) : (unsigned)(nqb * p.nh * p.B));
     SF_ALLOW_SMEM((attn_fwd_w1_kernel<HD>), 2 * 128 * HD * 2);
     SF_LAUNCH((attn_fwd_w1_kernel<HD>), grid, dim3(256), 2 * 128 * HD * 2, stream, p);
     return sf_check_launch("sf_attn_fwd");
@@ -586,7 +587,8 @@ int attn_fwd_w1_launch(const AttnFwdArgs& p, int hd, void* stream) {
 int attn_bwd_dq_w1_launch(const AttnBwdArgs& p, int hd, void* stream) {
     SF_CHECK_ARG(hd == 256, "attn_bwd_dq_w1: head_dim 256 only");
     constexpr int HD = 256;
-    dim3 grid(attn_grid((long)((p.S + 127) / 128) * p.nh * p.B, p.l2_map));
+    const long nqb = (p.S + 127) / 128;
+    dim3 grid(p.l2_map ? attn_pair_major_grid(nqb * (p.nh / p.nkv), (long)p.nkv * p.B) : (unsigned)(nqb * p.nh * p.B));
     SF_ALLOW_SMEM((attn_bwd_dq_w1_kernel<HD>), 2 * 128 * HD * 2);
     SF_LAUNCH((attn_bwd_dq_w1_kernel<HD>), grid, dim3(256), 2 * 128 * HD * 2, stream, p);
     return sf_check_launch("sf_attn_bwd_dq");

@@ -69,6 +69,8 @@ def main():
     dv = [torch.zeros(N, nkv * hd, device=dev) for _ in range(max(NDIAG) + 1)]
     dq = torch.empty(N, nh * hd, device=dev, dtype=torch.bfloat16)
     kw = dict(scale=1 / math.sqrt(hd), **shape)
+    nws = ops.attn_bwd_dkv_workspace_floats(B, S, nh, nkv, hd)      # (the engine's head-split workspace: small B * nkv)
+    dkv_ws = torch.empty(nws, device=dev) if nws else None
 
     def kernels(nd):
         return {
@@ -76,7 +78,7 @@ def main():
             "pre": (lambda: ops.attn_bwd_pre(q, o, do, kv[1:nd + 1], vv[1:nd + 1], dk[1:nd + 1], dv[1:nd + 1], lse, delta,
                                              dq_init if nd else None, **kw), 0.0),
             "dq": (lambda: ops.attn_bwd_dq(q, do, kv[0], vv[0], None, lse, delta, dq_init if nd else None, dq, **kw), 6.0),
-            "dkv": (lambda: ops.attn_bwd_dkv(q, do, kv[0], vv[0], None, lse, delta, dk[0], dv[0], **kw), 8.0),
+            "dkv": (lambda: ops.attn_bwd_dkv(q, do, kv[0], vv[0], None, lse, delta, dk[0], dv[0], workspace=dkv_ws, **kw), 8.0),
         }
 
     res = {}
