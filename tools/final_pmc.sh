@@ -2,8 +2,8 @@
 # WRITE_SIZE together exceed what one pass can collect: rocprofv3 aborts and then hangs in finalisation), each under timeout.
 # usage: bash tools/final_pmc.sh [rN] [commit]
 export TMPDIR=/tmp
-R=${1:-r4}; C=${2:-unknown}; O=gpurun_out/final; mkdir -p $O
-B="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dense-mask --no-feeds"
+R=${1:-r5}; C=${2:-unknown}; O=gpurun_out/final; mkdir -p $O
+B="python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dense-mask --no-feeds --no-configs"
 rm -rf /tmp/pmc_f /tmp/pmc_w /tmp/pmc_m /tmp/pmc_fw
 timeout 150 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmc_f --output-format csv -- $B > $O/pmc_f.log 2>&1
 timeout 150 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmc_w --output-format csv -- $B > $O/pmc_w.log 2>&1
