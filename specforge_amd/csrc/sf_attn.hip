@@ -419,6 +419,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_pre_kernel(AttnBwdPreArgs p) {
 //     read-modify-write.  A branch whose last contributor is this launch leaves as bf16 (one rounding), into the dqkv slot.
 // engine.py (diag_plan) builds the launches; bytes of the diagonal terms per token at ttt 7: 828 KB -> 516 KB.
 constexpr int kDiagRead = 6, kDiagAcc = 4, kDiagX = 8;
+// row sets per 4-wave workgroup of the diagonal-branch kernel: 1 (a wave per kv group, round-robin) unless there are fewer groups than waves
+SF_HD int attn_diag_row_sets(int nkv) { return nkv == 1 ? 4 : nkv == 2 ? 2 : 1; }
 struct AttnBwdDiagArgs {
     const sf_bf16* q; long ldq;        // own step (null: this launch only streams later steps into the accumulating branches)
     const sf_bf16* o; long ldo;
@@ -441,13 +443,16 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) attn_bwd_diag_kernel(AttnBwdDiagArgs p) 
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
     const int sub = lane / LPH, li = lane % LPH;
     const int N = p.B * p.S;
-    const int row_raw = (int)blockIdx.x * RPW + sub;
+    // wave w takes kv groups w, w + 4, ...; with FEWER than 4 groups (nkv 1 or 2: the head_dim-256 recipes) the spare waves take further
+    // rows instead of idling (half / three quarters of a workgroup did: 0.32 of the HBM rate at nkv 2 where nkv >= 4 reaches 0.58)
+    const int rsets = attn_diag_row_sets(p.nkv), gstep = 4 / rsets;
+    const int row_raw = ((int)blockIdx.x * rsets + wave / gstep) * RPW + sub;
     const bool live = row_raw < N;
     const int row = live ? row_raw : N - 1;   // dead lane groups shadow a valid row and skip every store
     const int b = row / p.S, t = row - b * p.S;
     const int nrep = p.nh / p.nkv;
     const int d0 = li * 8;
-    for (int g = wave; g < p.nkv; g += 4) {
+    for (int g = wave % gstep; g < p.nkv; g += gstep) {
         sf_v8s kv[NR], vv[NR];
         float dk[NA][8], dv[NA][8];
 #pragma unroll
@@ -871,7 +876,7 @@ extern "C" int sf_attn_bwd_diag(const void* q, long ldq, const void* o, long ldo
     }
     p.nx = nx;
     p.B = B; p.S = S; p.nh = nh; p.nkv = nkv; p.scale = scale;
-    const int rows_per_block = 64 / (hd / 8);
+    const int rows_per_block = 64 / (hd / 8) * attn_diag_row_sets(nkv);
     const dim3 grid((unsigned)((B * S + rows_per_block - 1) / rows_per_block));
     SF_HD_DISPATCH(hd, SF_LAUNCH((attn_bwd_diag_kernel<HD>), grid, dim3(256), 0, stream, p));
     return sf_check_launch("sf_attn_bwd_diag");
