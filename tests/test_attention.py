@@ -125,8 +125,7 @@ def test_ttt_attention_fwd_bwd(backend, hd, B, S, nh, nkv, lengths, nsteps):
     torch.testing.assert_close(dk_acc[0].cpu(), 2 * before.cpu(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("hd", [64, 128, 256])
-@pytest.mark.parametrize("grow", ["block1", "block0", "both"])
+@pytest.mark.parametrize("hd,grow", [(64, "both"), (128, "block1"), (128, "both"), (256, "block1"), (256, "block0"), (256, "both")])
 def test_forward_online_softmax_rescale_paths(backend, hd, grow):
     """Scores that keep growing along the keys, so the running row max rises by more than 2^8 again and again: in the SECOND 32-key block of
     a tile (the head_dim-256 kernel takes that block's exponentials speculatively and must redo them after draining the PV products
