@@ -210,14 +210,21 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
     // Every wave issues the same number of DMA pieces per tile (a counted vmcnt needs one immediate): its Q and dO pieces
     // plus ONE 4-byte-per-lane piece -- lse (wave 0), delta (wave 1), or a re-read of lse into the slot's padding.
     struct Src { SfBufB q, dout, aux; unsigned qoff, dooff, auxoff; char* dst; };
-    auto source = [&](int it) SF_LAMBDA_INLINE {
-        const int hh = it / per_head, qt = qt_first + (it - hh * per_head);
+    // Tile `it` of the head-major walk = (head hh, 64-query tile qt).  Two walkers -- the tile being computed and the one being staged two
+    // ahead -- advance by one tile per iteration with a compare and an add (round 5: `it / per_head` for each of them was ~100 scalar /
+    // vector instructions between two tile bodies, a fifth of a body's matrix-pipe time with nothing issued to the pipe)
+    struct Walk { int hh, qt, slot; };
+    auto advance = [&](Walk& w) SF_LAMBDA_INLINE {
+        if (++w.qt == nqt) { w.qt = qt_first; ++w.hh; }
+        if (++w.slot == NBUF) w.slot = 0;
+    };
+    auto source = [&](const Walk& w) SF_LAMBDA_INLINE {
         Src r;
-        r.q = rows_buf<HD>(qb_base + hh * HD, p.ldq, S);
-        r.dout = rows_buf<HD>(dob_base + hh * HD, p.lddo, S);
-        r.aux = sf_make_bufb((wave == 1 ? dlt_base : lse_base) + (long)hh * S, (unsigned)S * 4u);
-        r.qoff = (unsigned)qt * qtile; r.dooff = (unsigned)qt * dotile; r.auxoff = (unsigned)(qt * 64 + lane) * 4u;
-        r.dst = smem + (it % NBUF) * TILE;
+        r.q = rows_buf<HD>(qb_base + w.hh * HD, p.ldq, S);
+        r.dout = rows_buf<HD>(dob_base + w.hh * HD, p.lddo, S);
+        r.aux = sf_make_bufb((wave == 1 ? dlt_base : lse_base) + (long)w.hh * S, (unsigned)S * 4u);
+        r.qoff = (unsigned)w.qt * qtile; r.dooff = (unsigned)w.qt * dotile; r.auxoff = (unsigned)(w.qt * 64 + lane) * 4u;
+        r.dst = smem + w.slot * TILE;
         return r;
     };
     auto piece = [&](const Src& r, int k) SF_LAMBDA_INLINE {   // piece k of NDMA (compile-time k at every call site)
@@ -226,36 +233,35 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dkv_kernel(AttnBwdArgs p) {
         else if (k < 2 * NI) sf_bufb_glds16(r.dout, stdo.off[k - NI] + r.dooff, r.dst + 64 * HD * 2 + (stdo.piece0 + k - NI) * 1024);
         else sf_bufb_glds4(r.aux, r.auxoff, r.dst + 128 * HD * 2 + (wave < 2 ? wave : 2) * 256);
     };
-    auto stage_now = [&](int it) SF_LAMBDA_INLINE {
-        const Src r = source(it);
-        static_for<0, NDMA>([&](auto K) SF_LAMBDA_INLINE { piece(r, decltype(K)::value); });
+    // stage the walker's tile -- or, past the last tile, the same pieces against empty descriptors (zeros into a ring slot nobody reads any
+    // more): no branch inside the slot stream, and the counted wait at the top of the next iteration stays exact
+    auto src_or_empty = [&](const Walk& w, bool real) SF_LAMBDA_INLINE {
+        Src r = source(w);
+        if (!real) { sf_bufb_empty(r.q); sf_bufb_empty(r.dout); sf_bufb_empty(r.aux); }
+        return r;
     };
-    if (n_it > 0) stage_now(0);
-    if (n_it > 1) stage_now(1);
-    else if (n_it > 0) {                // keep the piece count of the counted wait: an empty stand-in for tile 1
-        Src r = source(0);
-        sf_bufb_empty(r.q); sf_bufb_empty(r.dout); sf_bufb_empty(r.aux);
-        r.dst = smem + TILE;
-        static_for<0, NDMA>([&](auto K) SF_LAMBDA_INLINE { piece(r, decltype(K)::value); });
+    Walk wc{0, qt_first, 0}, ws{0, qt_first, 0};        // the tile computed in this iteration; the tile staged next (two ahead in the loop)
+    if (n_it > 0) {
+        const Src r0 = src_or_empty(ws, true);
+        static_for<0, NDMA>([&](auto K) SF_LAMBDA_INLINE { piece(r0, decltype(K)::value); });
+        advance(ws);
+        const Src r1 = src_or_empty(ws, n_it > 1);      // (keeps the piece count of the counted wait: an empty stand-in for tile 1)
+        static_for<0, NDMA>([&](auto K) SF_LAMBDA_INLINE { piece(r1, decltype(K)::value); });
+        advance(ws);
     }
     for (int it = 0; it < n_it; ++it) {
-        const int hh = it / per_head, qt = qt_first + (it - hh * per_head);
-        const int q0 = qt * 64;
+        const int q0 = wc.qt * 64;
         sf_wait_vmcnt<NDMA>();          // tile `it` landed; the NDMA pieces of tile it+1 (or its empty stand-ins) may be in flight
         sf_syncthreads();               // ... for every wave; ring slot (it+2) % 3 == (it-1) % 3 is no longer being read
         const bool more = it + 2 < n_it;
-        const char* lds_q = smem + (it % NBUF) * TILE;
+        const char* lds_q = smem + wc.slot * TILE;
+        const Src nxt = src_or_empty(ws, more);          // the pieces of tile it+2 are fillers of this tile's first slots
+        advance(wc);
+        advance(ws);
         if (q0 + 63 < kw0) {            // every query of the tile is before this wave's keys: only the staging duty remains
-            Src r = source(more ? it + 2 : it);
-            if (!more) { sf_bufb_empty(r.q); sf_bufb_empty(r.dout); sf_bufb_empty(r.aux); r.dst = smem + ((it + 2) % NBUF) * TILE; }
-            static_for<0, NDMA>([&](auto K) SF_LAMBDA_INLINE { piece(r, decltype(K)::value); });
+            static_for<0, NDMA>([&](auto K) SF_LAMBDA_INLINE { piece(nxt, decltype(K)::value); });
             continue;
         }
-        // the pieces of tile it+2 are fillers of this tile's first slots.  Past the last tile the same pieces are issued
-        // against empty descriptors (zeros into a ring slot nobody reads any more): no branch inside the slot stream, and
-        // the counted wait at the top of the next iteration stays exact
-        Src nxt = source(more ? it + 2 : it);
-        if (!more) { sf_bufb_empty(nxt.q); sf_bufb_empty(nxt.dout); sf_bufb_empty(nxt.aux); nxt.dst = smem + ((it + 2) % NBUF) * TILE; }
         auto dma = [&](auto Sl) SF_LAMBDA_INLINE {       // filler: DMA piece (slot - 1) of tile it+2
             constexpr int k = decltype(Sl)::value - 1;
             if constexpr (k >= 0 && k < NDMA) piece(nxt, k);
