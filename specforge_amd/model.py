@@ -328,6 +328,16 @@ class Eagle3DraftMethods:
         if self._rope is None or self._rope[0].device != dev:
             cos, sin = rope_tables(c, torch.bfloat16)
             self._rope = (cos.to(dev), sin.to(dev))
+            self._rope_len = c.max_position_embeddings + 20
+        if S + lck > self._rope_len:
+            # the reference's rotary module rebuilds its cache for seq_len = q_len + lck when that exceeds it (llama3_eagle.py:303-306,
+            # 733) and keeps the rebuilt one: dynamic NTK re-derives its base from exactly that length, every other variant extends
+            rs = c.rope_scaling or {}
+            dyn = rs.get("rope_type", rs.get("type")) == "dynamic"
+            n = S + lck if dyn else max(S + lck, self._rope[0].shape[0] + 1024)
+            cos, sin = rope_tables(c, torch.bfloat16, n_pos=n)
+            self._rope = (cos.to(dev), sin.to(dev))
+            self._rope_len = n
         cos, sin = self._rope
         pos = (torch.arange(S, device=dev).repeat(B) if position_ids is None
                else position_ids.to(dev).expand(B, S).reshape(-1)).to(torch.int64).contiguous()

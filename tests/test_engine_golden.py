@@ -588,3 +588,35 @@ def test_mrope_ids_past_the_table_grow_it(backend, golden_dir):
         b.tensors["position_ids"] = b.tensors["position_ids"].to(backend)
         with pytest.raises(RuntimeError, match="position_ids"):
             strat.forward_loss(b).loss.backward()
+
+
+@pytest.mark.parametrize("rope_scaling", [None, dict(rope_type="dynamic", factor=2.0)])
+def test_draft_backbone_method_grows_its_rope_table_too(backend, rope_scaling):
+    """``backbone`` -- the forward-only draft method the reference's own ``OnlineEagle3Model`` calls on the plugin draft
+    (modeling/draft/base.py:80-109) -- at a sequence longer than max_position_embeddings + 20, two TTT steps, against the pinned oracle's
+    decoder layer with its ``RopeCache`` (= the reference's rotary-cache semantics, goldens ``eagle3_rope_grow*``)"""
+    kw = dict(hidden_size=64, intermediate_size=128, num_attention_heads=2, num_key_value_heads=1, vocab_size=96, draft_vocab_size=32,
+              head_dim=64, target_hidden_size=64, max_position_embeddings=16, rms_norm_eps=1e-5, rope_scaling=rope_scaling)
+    oc = O.DraftConfig(**kw)
+    bf = torch.bfloat16
+    params = {k: v.to(bf) for k, v in O.init_params(oc, seed=3).items()}
+    model = LlamaForCausalLMEagle3(DraftConfig(**kw), device=backend)
+    sd = dict(params)
+    g = torch.Generator().manual_seed(4)
+    sd["embed_tokens.weight"] = (torch.randn(96, 64, generator=g) * 0.05).to(bf)
+    sd["t2d"], sd["d2t"] = O.make_vocab_mapping(96, 32, seed=1)
+    model.load_state_dict(sd)
+    B, S = 2, 44
+    emb = [(torch.randn(B, S, 64, generator=g) * 0.5).to(bf) for _ in range(2)]
+    hid = (torch.randn(B, S, 64, generator=g) * 0.5).to(bf)
+    am = torch.ones(B, S, dtype=torch.long)
+    rope = O.RopeCache(oc, bf, "cpu")
+    add_mask = O.additive_attention_mask(am.bool(), S, bf)
+    pos = torch.arange(S).unsqueeze(0)
+    cache_o, cache_h = [[], []], [[], []]
+    ho, hh = hid, hid.to(backend)
+    for k in range(2):
+        ho = O.decoder_layer(params, oc, emb[k], ho, cache_o, add_mask, pos, rope)
+        hh = model.backbone(emb[k].to(backend), hh, cache_h, am, None)
+        torch.testing.assert_close(hh.float().cpu(), ho.float(), rtol=3e-2, atol=3e-2)
+    assert model._rope[0].shape[0] >= S + 1 and rope.len == S + 1
