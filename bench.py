@@ -52,6 +52,9 @@ DEEPSEEK_V3 = dict(hidden_size=7168, intermediate_size=40960, num_attention_head
 QWEN3_NEXT_80B_A3B = dict(hidden_size=2048, intermediate_size=16384, num_attention_heads=16, num_key_value_heads=2, vocab_size=151936,
                           draft_vocab_size=32000, head_dim=256, target_hidden_size=2048, max_position_embeddings=8192,
                           rms_norm_eps=1e-6, rope_theta=10000000.0)
+GEMMA3_1B = dict(hidden_size=1152, intermediate_size=6912, num_attention_heads=4, num_key_value_heads=1, vocab_size=262144,
+                 draft_vocab_size=32000, head_dim=256, target_hidden_size=1152, max_position_embeddings=32768, rms_norm_eps=1e-6,
+                 rope_theta=1000000.0)
 CONFIGS = {
     # name: (dims, default batch, default seq, label)
     "llama3-8b": (LLAMA3_8B, 8, 2048, "Llama-3-8B EAGLE3 offline draft"),
@@ -59,6 +62,7 @@ CONFIGS = {
     "qwen3-30b-a3b-eagle31": (QWEN3_30B_A3B_EAGLE31, 1, 4096, "Qwen3-30B-A3B EAGLE3.1 offline draft (fc_norm)"),
     "deepseek-v3": (DEEPSEEK_V3, 1, 2048, "DeepSeek-V3 671B EAGLE3 offline draft (H 7168, I 40960, Vt 129280)"),
     "qwen3-next-80b-a3b": (QWEN3_NEXT_80B_A3B, 8, 2048, "Qwen3-Next-80B-A3B EAGLE3 offline draft (head_dim 256, 16 / 2 heads)"),
+    "gemma3-1b": (GEMMA3_1B, 1, 4096, "Gemma3-1B EAGLE3 offline draft (head_dim 256, 4 / 1 heads, H 1152; configs/gemma3-1b-eagle3.json)"),
 }
 # The legs of the default line's `configs` object (every BASELINE.json configuration and the batch-1 recipe shape
 # under the driver's clock): (key, CONFIGS entry, batch, seq, what it is)

@@ -9,7 +9,7 @@ training/trainer.py:511), its loader, collator, ``TrainerCore``, ``BF16Optimizer
 file's own eager ``_compute_loss`` (the Triton kernel has no CPU driver), DDP over gloo at world size 1,
 ``torch.set_num_threads(ncores)``.  Inputs: the synthetic files of SURVEY 8d (``tests/test_runtime/_fixtures.py:95-149``
 at the config's dims).  Reported: the trainer's own ``perf/optimizer_step_time_s`` per logged step (log_interval 1; the first
-step is warm-up) and tokens/s = B*S / step time.  Appends one JSON line to profiles/old/r3_reference_cpu_trainer.jsonl."""
+step is warm-up) and tokens/s = B*S / step time.  Appends one JSON line to profiles/r5_reference_cpu_trainer.jsonl."""
 import json
 import os
 import sys

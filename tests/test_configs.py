@@ -175,6 +175,10 @@ REAL = {
     # (examples/configs/qwen3-next-80b-a3b-eagle3-online.yaml: batch 1, max_length 4096)
     "qwen3_next_80b_a3b_s4096": dict(H=2048, Ht=2048, I=16384, nh=16, nkv=2, hd=256, Vt=151936, Vd=32000, B=1, S=4096, ttt=7, eps=1e-6,
                                      max_pos=8192, rope_theta=10000000.0, lengths=[4096], prompt=700),
+    # configs/gemma3-1b-eagle3.json at its recipe's shape (examples/configs/gemma3-1b-eagle3-online.yaml: batch 1, max_length 4096): head_dim 256
+    # with 4 / 1 heads (nh * hd = 1024 != H), H = 1152 and I = 6912 -- 4.5 and 27 tiles of 256: edge tiles in every GEMM --, 262k vocabulary
+    "gemma3_1b_s4096": dict(H=1152, Ht=1152, I=6912, nh=4, nkv=1, hd=256, Vt=262144, Vd=32000, B=1, S=4096, ttt=7, eps=1e-6,
+                            max_pos=32768, rope_theta=1000000.0, lengths=[4096], prompt=512),
     # configs/qwen3.5-35b-a3b-eagle3.json (head_dim 256, 248k target vocabulary) at examples/configs/qwen3.5-35b-a3b-eagle3-online.yaml's
     # max_length 8192: the longest sequence any shipped EAGLE3 recipe trains at
     "qwen3_5_35b_a3b_s8192": dict(H=2048, Ht=2048, I=16384, nh=16, nkv=2, hd=256, Vt=248320, Vd=32000, B=1, S=8192, ttt=7, eps=1e-6,
