@@ -107,7 +107,7 @@ def main():
                total_wall_s=round(time.perf_counter() - t0, 1))
     print(json.dumps(rec))
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    with open(os.path.join(ROOT, "profiles", "r3_reference_cpu_trainer.jsonl"), "a") as f:
+    with open(os.path.join(ROOT, "profiles", "r5_reference_cpu_trainer.jsonl"), "a") as f:
         f.write(json.dumps(rec) + "\n")
 
 

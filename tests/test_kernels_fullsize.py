@@ -250,6 +250,40 @@ def test_ttt_attention_long_head_dim_256(S, lengths, nsteps):
     _attn_long(S, lengths, nsteps, 256)
 
 
+@pytest.mark.parametrize("hd", [128, 256])
+def test_attention_kernels_are_bitwise_reproducible(hd):
+    """forward (with diagonal branches), dQ and dK/dV six times over: identical bits (fixed work assignment, no atomics; the head_dim-256
+    dK/dV pair hands P over through LDS behind the workgroup barrier -- a race there would show up here)"""
+    from tests.test_attention import _mk
+
+    B, S, nh, nkv, nsteps, lengths = 2, 1024, 4, 2, 3, [1024, 777]
+    q, ks, vs, do = _mk(B, S, nh, nkv, hd, nsteps, seed=hd)
+    N, scale = B * S, 1.0 / math.sqrt(hd)
+    d = lambda t: t.to(DEV)
+    qv, dout = d(q.view(N, -1)), d(do.view(N, -1))
+    K, V = [d(t.view(N, -1)) for t in ks], [d(t.view(N, -1)) for t in vs]
+    kv_len = d(torch.tensor(lengths, dtype=torch.int32))
+    first = None
+    for run in range(6):
+        o = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B, nh, S, device=DEV)
+        ops.attn_fwd(qv, K[0], V[0], K[1:], V[1:], kv_len, o, lse, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+        delta = torch.empty(B, nh, S, device=DEV)
+        dq_init = torch.zeros(N, nh * hd, device=DEV)
+        dk = [torch.zeros(N, nkv * hd, device=DEV) for _ in range(nsteps)]
+        dv = [torch.zeros(N, nkv * hd, device=DEV) for _ in range(nsteps)]
+        ops.attn_bwd_pre(qv, o, dout, K[1:], V[1:], dk[1:], dv[1:], lse, delta, dq_init, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+        dq = torch.empty(N, nh * hd, dtype=torch.bfloat16, device=DEV)
+        ops.attn_bwd_dq(qv, dout, K[0], V[0], kv_len, lse, delta, dq_init, dq, B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+        ops.attn_bwd_dkv(qv, dout, K[0], V[0], kv_len, lse, delta, dk[0], dv[0], B=B, S=S, nh=nh, nkv=nkv, hd=hd, scale=scale)
+        got = [o, lse, dq, dk[0], dv[0]]
+        if first is None:
+            first = [t.clone() for t in got]
+        else:
+            for a, b_, what in zip(got, first, ("o", "lse", "dq", "dk", "dv")):
+                assert torch.equal(a, b_), (what, run)
+
+
 def _attn_long(S, lengths, nsteps, hd):
     from tests.test_attention import _mk, _oracle
 
