@@ -56,7 +56,7 @@ struct DkvBank : AgprBank<2 * (HD / 32), 2 * (HD / 16)> {
 //            P(0) element e in slot 18 + e * 14 / 16 (18..31), P(1) in 34..47; each element = 5 VALU (+3 when masked)
 template <int HD, bool MASK>
 struct DkvTile {
-    static constexpr int KS = HD / 16, DB = HD / 32, NA = 2 * KS, NG = 4 * DB, NSLOT = 2 * NA + 2 * NG, kAhead = 8;
+    static constexpr int KS = HD / 16, DB = HD / 32, NA = 2 * KS, NG = 4 * DB, NSLOT = 2 * NA + 2 * NG, kAhead = SF_ATTN_KAHEAD;
     static constexpr int P0 = NA + 2, P1 = 2 * NA + 2, PSPAN = NG - 2 < NA - 2 ? NG - 2 : NA - 2;
     static_assert(NA == NG, "the plan assumes the score and gradient phases have the same number of MFMAs");
 

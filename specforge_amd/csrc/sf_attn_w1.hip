@@ -54,7 +54,7 @@ struct Fwd1Bank : AgprBank<HD / 32, HD / 16> {
 //   P(1) beside G0: g0+2, +3 mask + row max | g0+4 check            | g0+5 .. g1-3 the 16 SPECULATIVE exponentials; fix-up at g1
 template <int HD, bool MASK>
 struct Fwd1Tile {
-    static constexpr int KS = HD / 16, DB = HD / 32, NG = 2 * DB, NSLOT = 2 * KS + 2 * NG, kAhead = 8;
+    static constexpr int KS = HD / 16, DB = HD / 32, NG = 2 * DB, NSLOT = 2 * KS + 2 * NG, kAhead = SF_ATTN_KAHEAD;
     static constexpr int a1 = KS, g0 = 2 * KS, g1 = g0 + NG;
     static constexpr int p0 = a1 + 2, e0lo = p0 + 3, e0n = (g0 - 2) - e0lo;      // exponentials of block 0: slots e0lo .. e0lo + e0n - 1
     static constexpr int p1 = g0 + 2, e1lo = p1 + 3, e1n = (g1 - 2) - e1lo;
@@ -390,7 +390,7 @@ struct Dq1Bank : AgprBank<HD / 32, 2 * (HD / 16)> {
 //   P(0) (dS of block 0: 16 elements) beside A1 from a1 + 3; P(1) beside G0 from g0 + 3
 template <int HD, bool MASK>
 struct Dq1Tile {
-    static constexpr int KS = HD / 16, DB = HD / 32, NA = 2 * KS, NG = 2 * DB, NSLOT = 2 * NA + 2 * NG, kAhead = 8;
+    static constexpr int KS = HD / 16, DB = HD / 32, NA = 2 * KS, NG = 2 * DB, NSLOT = 2 * NA + 2 * NG, kAhead = SF_ATTN_KAHEAD;
     static constexpr int a1 = NA, g0 = 2 * NA, g1 = g0 + NG;
     static constexpr int p0 = a1 + 3, p0n = NA - 6 < 16 ? NA - 6 : 16;
     static constexpr int p1 = g0 + 3, p1n = NG - 5;

@@ -35,7 +35,7 @@ struct PairBank : AgprBank<HD / 32, HD / 16> {       // a[0 : 16 DB) the wave's 
     template <int D> SF_DEVICE sf_v16f get_grad() { return Base::template get<D>(); }
 };
 
-constexpr int kAhead = 8;
+constexpr int kAhead = SF_ATTN_KAHEAD;
 
 // The first kAhead transposed fragments of a gradient phase (G-slot M: d = M % DB, rows 16 (M / DB) ..)
 template <int HD, int M>
