@@ -226,7 +226,7 @@ def cpu_baseline(cfg, S, ttt, threads):
                 sample=f"oracle/eagle3_oracle.py (a pinned restatement, NOT the reference trainer: no optimizer, no loader), "
                        f"1 micro-step fwd+bwd, B=1 x S={S} of the same model dims and ttt, fp32, {dt:.1f} s; the headline step is 8 "
                        f"such samples (x8 the work at the same rate).  The reference trainer itself, timed on the build "
-                       f"container's 8 cores: profiles/old/r3_reference_cpu_trainer.jsonl / BASELINE.md section 5")
+                       f"container's 8 cores: profiles/old/r3_reference_cpu_trainer.jsonl (re-timed: profiles/r5_reference_cpu_trainer.jsonl) / BASELINE.md section 5")
 
 
 def f_draft_per_token(cfg, S, ttt):
