@@ -266,7 +266,8 @@ def test_ce_fused(backend, dtype, tol, B, S, V, T, off):
     gtol = tol * float(grad.abs().max())
     torch.testing.assert_close(x.float().cpu(), grad, rtol=tol, atol=gtol)
     # masked rows carry exactly zero gradient (core/loss.py:160-170)
-    assert float(x.float().cpu()[sl(pos_pad) == 0].abs().max()) == 0.0
+    masked = x.float().cpu()[sl(pos_pad) == 0]
+    assert masked.numel() == 0 or float(masked.abs().max()) == 0.0
     # drop-in mode: tsum computed in-kernel, no pod/ids
     x2 = d(logits.clone())
     ops.ce_fused(x2, d(target_pad), S=S, Spad=Spad, off=off, pos_mask_pad=d(pos_pad), loss_mask_pad=d(lm_pad),
