@@ -5,7 +5,7 @@ import csv, glob, json, re, sys
 from collections import defaultdict
 
 FAMILIES = [("gemm256w4", r"gemm_nt_256w4_kernel"), ("gemm_tn", r"gemm_tn_256w4p?_kernel"), ("gemm256", r"gemm_nt_256_kernel|gemm_nt_256v2"), ("gemm128", r"gemm_nt_kernel"),
-            ("attn_fwd", r"attn_fwd_kernel"), ("attn_bwd_dq", r"attn_bwd_dq_kernel"), ("attn_bwd_dkv", r"attn_bwd_dkv_kernel|attn_bwd_dkv_rs_kernel"),
+            ("attn_fwd", r"attn_fwd_(w1_)?kernel"), ("attn_bwd_dq", r"attn_bwd_dq_(w1_)?kernel"), ("attn_bwd_dkv", r"attn_bwd_dkv_kernel|attn_bwd_dkv_rs_kernel|attn_bwd_dkv_pair_kernel"),
             ("attn_bwd_pre", r"attn_bwd_pre_kernel"), ("attn_bwd_diag", r"attn_bwd_diag_kernel"), ("transpose", r"transpose_kernel"), ("ce_fused", r"ce_fused_kernel"),
             ("swiglu_fwd", r"swiglu_fwd_kernel"), ("swiglu_bwd", r"swiglu_bwd_kernel"), ("adamw", r"adamw_kernel"),
             ("teacher_reduce", r"teacher_reduce_kernel"), ("rmsnorm_bwd", r"rmsnorm_bwd_kernel")]
