@@ -26,8 +26,12 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# dmabuf IPC is the only kind this stack's host driver supports: without it RCCL's buffer exchange between the ranks of a node fails
+# (hipIpcGetMemHandle: invalid argument).  Exported on the GPU boxes already; set here, before the runtime initialises, for any other launcher.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
