@@ -59,6 +59,8 @@ def main():
     def draw(i):
         B = rng.choice([1, 1, 2, 3, 4, 8])
         S = rng.choice([args.max_seq, rng.randint(16, args.max_seq), rng.randint(16, args.max_seq)])
+        if i < 40:      # the first optimizer steps see the LARGEST shape (dense and sparse): whatever is sized by shape has its final size early
+            B, S = 8, args.max_seq
         b = bench.make_batch(cfg, B, S, dev, 1000 + i)
         lens = [S] + [rng.randint(max(2, S // 3), S) for _ in range(B - 1)]
         valid = (torch.arange(S)[None, :] < torch.tensor(lens)[:, None]).long()
@@ -96,13 +98,13 @@ def main():
                        host_rss_gb=round(proc.memory_info().rss / 1e9, 3), elapsed_s=round(time.time() - t0, 1), tokens=tokens)
             samples.append(rec)
             print(json.dumps(rec), flush=True)
-    # verdict: memory flat after the first quarter of the run (everything has been sized by then), numbers finite throughout
-    q = [s for s in samples if s["step"] >= args.steps // 4]
-    growth = dict(gpu_allocated_gb=round(q[-1]["gpu_allocated_gb"] - q[0]["gpu_allocated_gb"], 3),
-                  gpu_reserved_gb=round(q[-1]["gpu_reserved_gb"] - q[0]["gpu_reserved_gb"], 3),
-                  host_rss_gb=round(q[-1]["host_rss_gb"] - q[0]["host_rss_gb"], 3))
-    ok = not bad and growth["gpu_allocated_gb"] <= 0.05 and growth["host_rss_gb"] <= 0.2
-    print(json.dumps(dict(verdict="ok" if ok else "FAILED", steps=args.steps, config=args.config, growth_after_first_quarter=growth, non_finite=bad,
+    # verdict: numbers finite throughout; memory level of the second half of the run not above the first half's (the samples fluctuate by
+    # the size of the last batch's derived tensors, which the engine keeps until the next step: compare the maxima, not two samples)
+    h1 = [s for s in samples if s["step"] <= args.steps // 2] or samples[:1]
+    h2 = [s for s in samples if s["step"] > args.steps // 2] or samples[-1:]
+    growth = {k: round(max(s[k] for s in h2) - max(s[k] for s in h1), 3) for k in ("gpu_allocated_gb", "gpu_reserved_gb", "host_rss_gb")}
+    ok = not bad and growth["gpu_allocated_gb"] <= 0.1 and growth["gpu_reserved_gb"] <= 0.1 and growth["host_rss_gb"] <= 0.1
+    print(json.dumps(dict(verdict="ok" if ok else "FAILED", steps=args.steps, config=args.config, second_half_max_minus_first_half_max=growth, non_finite=bad,
                           tokens_per_s=round(tokens / (time.time() - t0)))), flush=True)
     sys.exit(0 if ok else 1)
 
