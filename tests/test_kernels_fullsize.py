@@ -232,16 +232,18 @@ def test_gemm_bitwise_determinism(form, M, N, K):
         assert torch.equal(o, first), f"run {i + 1} differs from run 0"
 
 
-@pytest.mark.parametrize("S,lengths", [(1024, [1024, 651]), (2048, [2048, 1675]), (4096, [4096, 2817]), (8192, [8192, 5003])])
+@pytest.mark.parametrize("S,lengths", [(1024, [1024, 651]), (2048, [2048, 1675]), (4096, [4096, 2817]), (8192, [8192, 5003]), (16384, [16384, 9001])])
 @pytest.mark.parametrize("nsteps", [1, 7])
 def test_ttt_attention_long(S, lengths, nsteps):
     # S 4096 (cfg 4's recipe: bs 1 x 4096): 128 query blocks per (batch, kv head) -- twice what one XCD holds of the
     # pair-major forward / dQ work order, 64 key tiles per query row.  S 8192: the longest `max_length` among the reference's
-    # recipes (examples/configs/qwen3.5-35b-a3b-eagle3-online.yaml:11), 256 query blocks per pair, a ragged second sample
+    # recipes (examples/configs/qwen3.5-35b-a3b-eagle3-online.yaml:11), 256 query blocks per pair, a ragged second sample.  S 16384: twice
+    # that (the oracle's [B, nh, S, S + k] fp32 scores with autograd peak at 40 GB on the GPU; S 32768 -- 150 GB -- was run once by hand:
+    # profiles/r5_attn_long_s16384_s32768.log)
     _attn_long(S, lengths, nsteps, 128)
 
 
-@pytest.mark.parametrize("S,lengths", [(1024, [1024, 651]), (4096, [4096, 2817]), (8192, [8192, 5003])])
+@pytest.mark.parametrize("S,lengths", [(1024, [1024, 651]), (4096, [4096, 2817]), (8192, [8192, 5003]), (16384, [16384, 9001])])
 @pytest.mark.parametrize("nsteps", [1, 7])
 def test_ttt_attention_long_head_dim_256(S, lengths, nsteps):
     """head_dim 256 (gemma3-1b / qwen3-next-80b-a3b / qwen3.5-35b-a3b recipes): one workgroup per CU for forward / dQ, the
