@@ -265,6 +265,27 @@ SF_GLOBAL void colsum_accum_kernel(const float* partial, int nb, int H, float* a
     }
 }
 
+// The same sum over MANY partial rows (the engine reduces a norm weight's partials of all TTT steps in one launch: 7 x 1024 rows at the
+// headline shape): 16 columns x 64 row lanes per workgroup, H / 16 workgroups -- four times the workgroups and row lanes of the kernel
+// above, which is latency-bound on a long column (64 workgroups, each lane walking nb / 16 rows).  64-byte row segments: half a cache
+// line per row and workgroup, the neighbouring workgroup takes the other half.  Fixed order as above.
+SF_GLOBAL void colsum_accum_tall_kernel(const float* partial, int nb, int H, float* acc, int accumulate) {
+    SF_SHARED float red[64][16];
+    const int cl = (int)threadIdx.x & 15, rl = (int)threadIdx.x >> 4;
+    const int col = (int)blockIdx.x * 16 + cl;
+    float s = 0.f;
+    if (col < H)
+        for (int b = rl; b < nb; b += 64) s += partial[(long)b * H + col];
+    red[rl][cl] = s;
+    sf_syncthreads();
+    if (rl == 0 && col < H) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) t += red[i][cl];
+        acc[col] = accumulate ? acc[col] + t : t;
+    }
+}
+
 // --------------------------------------------------------------------- RoPE
 // In place on `nheads` consecutive heads of width hd starting at column 0 of row r (row stride ld).
 // forward : y1 = x1*c1 - x2*s1 ; y2 = x2*c2 + x1*s2     (q*cos + rotate_half(q)*sin, neox halves)
@@ -535,7 +556,10 @@ extern "C" int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* 
 // CU, so the side-stream kernel only delays its neighbours; the entry point stays for callers that schedule the column sum themselves.)
 extern "C" int sf_colsum_accum(const float* partial, int nb, int H, float* acc, int accumulate, void* stream) {
     SF_CHECK_ARG(partial && acc && nb >= 0 && H > 0, "sf_colsum_accum: bad args");
-    SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, partial, nb, H, acc, accumulate ? 1 : 0);
+    if (nb > 2048)      // (several launches' partials at once)
+        SF_LAUNCH(colsum_accum_tall_kernel, dim3((H + 15) / 16), dim3(1024), 0, stream, partial, nb, H, acc, accumulate ? 1 : 0);
+    else
+        SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, partial, nb, H, acc, accumulate ? 1 : 0);
     return sf_check_launch("sf_colsum_accum");
 }
 
@@ -549,15 +573,18 @@ extern "C" int sf_rmsnorm_bwd2(const void* dy1, long lddy1, const void* w1, floa
                  "sf_rmsnorm_bwd2: missing argument");
     if (rows == 0) return 0;
     const int rpb = 16, nb = (rows + rpb - 1) / rpb;
-    float* ws2 = workspace + (long)nb * H;      // (the workspace holds 2 x sf_rmsnorm_bwd_workspace_floats(rows, H))
+    // per-block partials of the two weight gradients: the two halves of the workspace (2 x sf_rmsnorm_bwd_workspace_floats(rows, H)) -- or,
+    // with dwX_accumulate == 2 and a non-null dwX_acc, [nb, H] at dwX_acc (a caller collecting the partials of many launches side by side)
+    float* ws1 = (dw1_accumulate == 2 && dw1_acc) ? dw1_acc : workspace;
+    float* ws2 = (dw2_accumulate == 2 && dw2_acc) ? dw2_acc : workspace + (long)nb * H;
 #define SF_NORM_BWD2(NV)                                                                                                     \
     SF_DISPATCH_T(dtype, SF_LAUNCH((rmsnorm_bwd2_kernel<T, NV>), dim3(nb), dim3(256), 0, stream, (const T*)dy1, lddy1, (const T*)w1, \
                                    (const T*)dy2, lddy2, (const T*)w2, (const T*)x, ldx, rstd, H, rows, rpb, (const T*)add, ldadd,  \
-                                   (T*)dx, lddx, workspace, ws2))
+                                   (T*)dx, lddx, ws1, ws2))
     if (H <= 2048) { SF_NORM_BWD2(1); } else { SF_NORM_BWD2(2); }
 #undef SF_NORM_BWD2
     if (dw1_accumulate != 2)
-        SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)workspace, nb, H, dw1_acc, dw1_accumulate);
+        SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)ws1, nb, H, dw1_acc, dw1_accumulate);
     if (dw2_accumulate != 2)
         SF_LAUNCH(colsum_accum_kernel, dim3((H + 63) / 64), dim3(1024), 0, stream, (const float*)ws2, nb, H, dw2_acc, dw2_accumulate);
     return sf_check_launch("sf_rmsnorm_bwd2");

@@ -67,6 +67,9 @@ def diag_plan(T: int, NA: int = ops.DIAG_ACC, NR: int = ops.DIAG_READ, NX: int =
 
 
 class Eagle3Engine:
+    # the norm weights every TTT step differentiates (input_layernorm sees the hoisted embedding rows once, fc_norm runs once)
+    _NORMS_PER_STEP = ("norm.weight", "midlayer.hidden_norm.weight", "midlayer.post_attention_layernorm.weight")
+
     def __init__(self, model: LlamaForCausalLMEagle3, *, ttt_length: int = 7, ploss_decay: float = 0.8,
                  teacher_rows: int = 4096, lk_loss_type: Optional[str] = None, kl_scale: float = 1.0,
                  kl_decay: float = 1.0):
@@ -89,6 +92,7 @@ class Eagle3Engine:
         self.T = int(ttt_length)
         self._diag_plan = diag_plan(self.T)      # launches of the blocked diagonal-branch backward, per sweep step
         self.blocked_diag = True                 # False (A/B, bench.py --diag-per-step): one sf_attn_bwd_pre per step, every pair at its step
+        self.norm_colsum_batched = True          # False (A/B): one column sum per norm backward launch instead of one per weight and sweep
         # Loss-row compaction (round 4): lm_head forward, the fused CE and the lm_head input / weight gradients -- a third of the step's
         # flops -- run only on the rows of a TTT step that carry a loss mask (real data: the assistant turns; padding never).  Needs the
         # per-step row counts on the HOST (forward(loss_counts=...): the ingest has the mask in host memory; no device read-back);
@@ -328,6 +332,9 @@ class Eagle3Engine:
             b["sin_rows"] = [cv(f"sin_rows_{k}", N, hd) for k in range(T)]
         b["nws"] = cv("nws", 2 * ops.rmsnorm_bwd_workspace(N, max(H, c.target_hidden_size)), dtype=f32)   # (x 2: sf_rmsnorm_bwd2)
         b["nws_e"] = cv("nws_e", ops.rmsnorm_bwd_workspace(Np, H), dtype=f32)
+        # per-block partials of the three norm weights every TTT step differentiates (final norm, hidden_norm, post-attention norm): the T
+        # launches of a sweep write side by side and ONE column sum per weight follows the sweep (norm_colsum_batched)
+        b["npart"] = {n: cv("npart_" + n.split(".")[-2], T * ops.rmsnorm_bwd_workspace(N, H), dtype=f32) for n in self._NORMS_PER_STEP}
         # fp32 partials for the 2-way split-K of weight-gradient GEMMs whose tile count fills the CUs badly (down, q|k|v)
         # (+ 4096 floats at the tail: pace-keeping counters of sf_gemm_tn)
         b["tn_ws"] = cv("tn_ws", 2 * max(H * I, self.QW * H) + 4096, dtype=f32)
@@ -877,11 +884,29 @@ class Eagle3Engine:
             first[name] = False
             return nm[name], acc
 
+        # norm_colsum_batched: the weight-gradient partials of each launch ([rows / 16, H] fp32) are kept, side by side per weight, and reduced
+        # by ONE column sum per weight after the sweep instead of one per launch (3 instead of 21 of the 22 launches of a 7-step sweep)
+        batched = self.norm_colsum_batched
+        part_rows = {n: 0 for n in self._NORMS_PER_STEP}
+
+        def part_slot(name, rows):
+            nbk = ops.rmsnorm_bwd_workspace(rows, H) // H
+            seg = b["npart"][name][part_rows[name] * H:(part_rows[name] + nbk) * H]
+            part_rows[name] += nbk
+            return seg
+
         def norm_bwd(name, dy, x, w, rstd, *, dx, add):
+            if batched and name in part_rows:
+                ops.rmsnorm_bwd(dy, x, w, rstd, dx=dx, add=add, partial_only=True, workspace=part_slot(name, dy.shape[0]))
+                return
             acc, a = nacc(name)
             ops.rmsnorm_bwd(dy, x, w, rstd, dx=dx, add=add, dw_acc=acc, dw_accumulate=a, workspace=ws)
 
         def norm_bwd2(name1, dy1, w1, name2, dy2, w2, x, rstd, *, dx, add):
+            if batched:
+                ops.rmsnorm_bwd2(dy1, w1, part_slot(name1, dy1.shape[0]), False, dy2, w2, part_slot(name2, dy1.shape[0]), False, x, rstd, dx=dx, add=add,
+                                 workspace=ws, partial_only=True)
+                return
             acc1, a1 = nacc(name1)
             acc2, a2 = nacc(name2)
             ops.rmsnorm_bwd2(dy1, w1, acc1, a1, dy2, w2, acc2, a2, x, rstd, dx=dx, add=add, workspace=ws)
@@ -1021,6 +1046,10 @@ class Eagle3Engine:
                 ops.gemm_tn(dy, x, gout, alpha=g, beta=beta, workspace=b["tn_ws"])
             if self.on_bucket_ready is not None:
                 self.on_bucket_ready(f.slices[first_name][0], f.slices[last_name][1])
+        if batched:
+            for n, rows_n in part_rows.items():
+                if rows_n:      # (a norm the forward does not read -- `norm` with norm_output = false -- has no partials and keeps its zeros)
+                    ops.colsum_accum(b["npart"][n], rows_n, H, nm[n], accumulate=False)
         # norm weights: fp32 running total over the window, then one cast into the flat gradient
         lo = f.slices[self._norm_names[0]][0]
         for n in self._norm_names:

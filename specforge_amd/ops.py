@@ -263,10 +263,14 @@ def rmsnorm_bwd2(dy1: torch.Tensor, w1: torch.Tensor, dw1_acc: torch.Tensor, dw1
                  dw2_acc: torch.Tensor, dw2_accumulate: bool, x: torch.Tensor, rstd: torch.Tensor, *, dx: torch.Tensor, add=None, workspace,
                  partial_only: bool = False):
     """dx = d_norm(dy1; w1) + d_norm(dy2; w2) (+ add) for two RMSNorms of the same rows x; dw*_acc (+)= their weight gradients.
-    workspace: >= 2 * rmsnorm_bwd_workspace(rows, H) floats."""
+    workspace: >= 2 * rmsnorm_bwd_workspace(rows, H) floats.  ``partial_only``: the weight gradients stop at the per-block partials [nb, H] --
+    in the two halves of ``workspace``, or at ``dw1_acc`` / ``dw2_acc`` where those are given (reduce them with ``colsum_accum``)."""
     L = _lib.lib()
     rows, H = dy1.shape[0], w1.numel()
     assert dy2.shape[0] == rows and w2.numel() == H and workspace.numel() >= 2 * rmsnorm_bwd_workspace(rows, H)
+    if partial_only:
+        need = rmsnorm_bwd_workspace(rows, H)
+        assert all(t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() >= need) for t in (dw1_acc, dw2_acc))
     m1, m2 = (2, 2) if partial_only else (1 if dw1_accumulate else 0, 1 if dw2_accumulate else 0)
     _lib.check(L.sf_rmsnorm_bwd2(_p(dy1), _rowmajor(dy1), _p(w1), _p(dw1_acc), m1, _p(dy2), _rowmajor(dy2), _p(w2),
                                  _p(dw2_acc), m2, _dt(dy1), _p(x), _rowmajor(x), _p(rstd), rows, H, _p(add),

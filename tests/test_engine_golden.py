@@ -150,6 +150,31 @@ def test_blocked_and_per_step_diagonal_backward_agree(backend, golden_dir):
     torch.testing.assert_close(grads[0], grads[1], rtol=2e-2, atol=4e-3 * float(grads[1].abs().max()))
 
 
+@pytest.mark.parametrize("golden", ["eagle31_gqa_fp32.pt", "eagle3_nonorm_fp32.pt"])
+def test_one_column_sum_per_norm_weight_equals_one_per_launch(backend, golden_dir, golden):
+    """engine.norm_colsum_batched (round 5): the per-block partials of the three norm weights that every TTT step differentiates are kept side
+    by side and reduced ONCE per weight after the sweep (3 column sums instead of 21) -- every other gradient bit-identical to the
+    per-launch form, the three norm gradients equal up to fp32 summation order; two accumulated micro-steps; bit-reproducible.
+    (second golden: norm_output = false, the final norm has no gradient and no partials)"""
+    blob = torch.load(os.path.join(golden_dir, golden), weights_only=False)
+    grads = []
+    for batched in (True, False, True):
+        cfg, model, eagle, strat = _build(blob, backend)
+        eagle.train()
+        eagle.engine.norm_colsum_batched = batched
+        for _ in range(2):
+            strat.forward_loss(_batch(blob, backend)).loss.backward()
+        grads.append(eagle.engine.flat.grad.float().cpu().clone())
+        eagle.engine.end_window()
+    assert torch.equal(grads[0], grads[2])
+    f = eagle.engine.flat
+    norm = torch.zeros(f.numel, dtype=torch.bool)
+    for n in eagle.engine._NORMS_PER_STEP:
+        norm[f.slices[n][0]:f.slices[n][1]] = True
+    assert torch.equal(grads[0][~norm], grads[1][~norm])
+    torch.testing.assert_close(grads[0][norm], grads[1][norm], rtol=2e-2, atol=1e-2 * float(grads[1][norm].abs().max()))     # (the flat gradient is bf16)
+
+
 @pytest.mark.parametrize("mask", ["random", "head_only", "all_zero"])
 def test_loss_row_compaction_equals_the_dense_form(backend, golden_dir, mask):
     """engine.compact_loss_rows (round 4): lm_head / CE / lm_head gradients over the rows with loss_mask[b, s + k] != 0 only, from

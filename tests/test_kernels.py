@@ -469,6 +469,31 @@ def test_rmsnorm_bwd_partials_then_colsum_equals_the_fused_call(backend, R, H):
         ops.colsum_accum(part[:n1], nb, H, d1, acc)
         ops.colsum_accum(part[n1:], nb, H, d2, acc)
         assert torch.equal(dxc.cpu(), dxd.cpu()) and torch.equal(c1.cpu(), d1.cpu()) and torch.equal(c2.cpu(), d2.cpu())
+        # ... with the two partial blocks at destinations of the caller's choosing (the engine's per-weight arenas), the workspace untouched
+        arena = torch.full((3 * n1 + 64,), float("nan"), device=backend)
+        dst1, dst2 = arena[2 * n1 + 64:3 * n1 + 64], arena[16:n1 + 16]
+        wsx = torch.full((2 * n1,), 7.0, device=backend)
+        dxe = torch.empty((R, H), dtype=dt, device=backend)
+        ops.rmsnorm_bwd2(dy1, w1, dst1, False, dy2, w2, dst2, False, x, rstd, dx=dxe, add=add, workspace=wsx, partial_only=True)
+        assert torch.equal(dxe.cpu(), dxd.cpu()) and torch.equal(dst1.cpu(), part[:n1].cpu()) and torch.equal(dst2.cpu(), part[n1:].cpu())
+        assert float((wsx - 7.0).abs().max()) == 0.0 and bool(torch.isnan(arena[n1 + 16:2 * n1 + 64]).all())
+
+
+@pytest.mark.parametrize("nb,H", [(2049, 128), (7 * 1024, 200), (2600, 4096)])
+def test_colsum_accum_over_many_partial_rows(backend, nb, H):
+    """the partials of several launches reduced at once (nb > 2048: the 16-column x 64-row-lane kernel), = and +=, against an fp64 sum;
+    run twice: same bits (fixed order)"""
+    part = _rand((nb, H), torch.float32, 3).to(backend)
+    ref = part.double().sum(0).cpu()
+    acc = torch.full((H,), 0.5, device=backend)
+    ops.colsum_accum(part, nb, H, acc, False)
+    first = acc.clone()
+    torch.testing.assert_close(acc.double().cpu(), ref, rtol=1e-5, atol=1e-3)
+    ops.colsum_accum(part, nb, H, acc, True)
+    torch.testing.assert_close(acc.double().cpu(), 2 * ref, rtol=1e-5, atol=2e-3)
+    again = torch.empty(H, device=backend)
+    ops.colsum_accum(part, nb, H, again, False)
+    assert torch.equal(again.cpu(), first.cpu())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
