@@ -176,8 +176,9 @@ int sf_rmsnorm_fwd2(const void* x, int dtype, long ldx, const void* w1, void* y1
 long sf_rmsnorm_bwd_workspace_floats(int rows, int H);
 /* dx (optional) = add (optional) + d/dx; dw_acc[H] (optional, fp32) = or += d/dw.
  * dw_accumulate == 2 (ABI 5, here and in sf_rmsnorm_bwd2): only the per-block partials are written -- workspace[nb, H] with
- * nb = sf_rmsnorm_bwd_workspace_floats(rows, H) / H -- and the column sum is the caller's (sf_colsum_accum, any stream, any time).  Mode 2 is NOT used by the engine (the side-stream
- * experiment of round 4 was measured and removed); it stays for callers that schedule the column sum themselves. */
+ * nb = sf_rmsnorm_bwd_workspace_floats(rows, H) / H -- and the column sum is the caller's (sf_colsum_accum).  The engine uses it for the
+ * three norm weights that every TTT step differentiates: the T launches of a sweep write their partials side by side and ONE column sum per
+ * weight follows the sweep (engine.norm_colsum_batched). */
 int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* x, long ldx, const long long* ids_pad, int S,
                    int Spad, int off, const void* w, const float* rstd, int rows, int H, const void* add,
                    long ldadd, void* dx, long lddx, float* dw_acc, int dw_accumulate, float* workspace,
@@ -186,13 +187,16 @@ int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* x, long ldx
 /* Two RMSNorm backwards of the SAME rows x in one pass (ABI 4): dx = d_norm(dy1; w1) + d_norm(dy2; w2) + add (optional), dw1_acc (+)=
  * d/dw1, dw2_acc (+)= d/dw2 (fp32).  H <= 4096; workspace = 2 x sf_rmsnorm_bwd_workspace_floats(rows, H) floats.  In the TTT sweep the
  * hidden state of step k feeds the final norm of step k - 1 (llama3_eagle.py:1772-1777) and the hidden_norm of step k (1625-1630): autograd
- * sums the two input gradients; run apart they read x twice and round the first partial sum to bf16. */
+ * sums the two input gradients; run apart they read x twice and round the first partial sum to bf16.
+ * With dwX_accumulate == 2 the partials [nb, H] of weight X go to dwX_acc when that is non-null (a destination of the caller's choosing: the
+ * engine's per-weight arenas), else to the X-th half of the workspace. */
 int sf_rmsnorm_bwd2(const void* dy1, long lddy1, const void* w1, float* dw1_acc, int dw1_accumulate, const void* dy2, long lddy2,
                     const void* w2, float* dw2_acc, int dw2_accumulate, int dtype, const void* x, long ldx, const float* rstd, int rows,
                     int H, const void* add, long ldadd, void* dx, long lddx, float* workspace, void* stream);
 
 /* acc[H] (= or +=) the column sums of partial[nb, H] in a fixed order (deterministic) -- the second half of a norm backward's weight
- * gradient when it ran with dw_accumulate == 2 (ABI 5). */
+ * gradient when it ran with dw_accumulate == 2 (ABI 5).  nb may span the partials of many launches (nb > 2048: a kernel with four times
+ * the workgroups and row lanes). */
 int sf_colsum_accum(const float* partial, int nb, int H, float* acc, int accumulate, void* stream);
 
 /* ---- RoPE in place on `nheads` consecutive heads (llama3_eagle.py:133-142; positions

@@ -551,9 +551,11 @@ extern "C" int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* 
 }
 
 // The column sum of a norm backward's per-block partials as a call of its own (ABI 5): with dw_accumulate == 2 the two entry points above
-// only WRITE their partials (workspace: sf_rmsnorm_bwd_workspace_floats per weight vector) and the caller reduces them when and where it
-// likes.  (The engine does NOT use this mode: reducing on a side stream was measured in round 4 and removed -- the persistent GEMMs hold every
-// CU, so the side-stream kernel only delays its neighbours; the entry point stays for callers that schedule the column sum themselves.)
+// only WRITE their partials (workspace: sf_rmsnorm_bwd_workspace_floats per weight vector, or the caller's destinations in sf_rmsnorm_bwd2)
+// and the caller reduces them when it likes.  The engine keeps the partials of a sweep's T launches side by side per weight and reduces them
+// once after the sweep (round 5: 3 column sums instead of 21 per 7-step sweep, -0.2 ... -0.4 ms per step in the same-process A/B,
+// profiles/r5_norm_colsum_batched_ab.jsonl).  Reducing on a SIDE STREAM was measured in round 4 and rejected: the persistent GEMMs hold
+// every CU, so a side-stream kernel only delays its neighbours.
 extern "C" int sf_colsum_accum(const float* partial, int nb, int H, float* acc, int accumulate, void* stream) {
     SF_CHECK_ARG(partial && acc && nb >= 0 && H > 0, "sf_colsum_accum: bad args");
     if (nb > 2048)      // (several launches' partials at once)

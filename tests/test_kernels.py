@@ -440,7 +440,7 @@ def test_rmsnorm_bwd2_equals_the_sum_of_two_backwards(backend, dtype, tol, R, H)
 @pytest.mark.parametrize("R,H", [(20, 128), (70, 4096)])
 def test_rmsnorm_bwd_partials_then_colsum_equals_the_fused_call(backend, R, H):
     """dw_accumulate == 2 (ABI 5): the norm backwards stop at their per-block partials and sf_colsum_accum finishes the weight gradient
-    (the engine runs it on a side stream) -- dx and dw bit-identical to the one-call form, = and += alike, for both entry points"""
+    (the engine reduces the partials of a whole sweep at once: norm_colsum_batched) -- dx and dw bit-identical to the one-call form, = and += alike, for both entry points"""
     dt = torch.bfloat16
     x, dy1, dy2, add = (_rand((R, H), dt, i).to(backend) for i in (1, 2, 3, 4))
     w1 = (1 + 0.1 * _rand((H,), torch.float32, 5)).to(dt).to(backend)
