@@ -149,8 +149,16 @@ class Eagle3Engine:
         self.g_gu = self.flat.fused("midlayer.mlp.gate_proj.weight", "midlayer.mlp.up_proj.weight", 2 * I, H, grad=True)
         # fp32 running totals of the norm-weight gradients over the accumulation window
         self._norm_names = [n for n in self.flat.names if n.endswith("norm.weight") or "layernorm" in n or "fc_norm" in n]
-        self._norm_total = {n: torch.zeros(self.flat.params[n].numel(), device=self.dev) for n in self._norm_names}
-        self._norm_micro = {n: torch.zeros(self.flat.params[n].numel(), device=self.dev) for n in self._norm_names}
+        # (one buffer each, the weights in flat order: when they are also contiguous in the flat gradient -- they are its tail -- the fold at the end
+        # of a micro-step is two launches for all of them instead of two per weight)
+        sl = [self.flat.slices[n] for n in self._norm_names]
+        self._norm_contig = all(sl[i][1] == sl[i + 1][0] for i in range(len(sl) - 1)) and sl[-1][1] == self.flat.numel and sl[0][0] % 8 == 0
+        tot = sum(hi - lo for lo, hi in sl)
+        self._norm_total_all, self._norm_micro_all = torch.zeros(tot, device=self.dev), torch.zeros(tot, device=self.dev)
+        o0 = sl[0][0]
+        view = lambda buf: ({n: buf[lo - o0:hi - o0] for n, (lo, hi) in zip(self._norm_names, sl)} if self._norm_contig else
+                            {n: torch.zeros(hi - lo, device=self.dev) for n, (lo, hi) in zip(self._norm_names, sl)})
+        self._norm_total, self._norm_micro = view(self._norm_total_all), view(self._norm_micro_all)
 
     # ------------------------------------------------------------------ buffers
     def _e(self, *shape, dtype=torch.bfloat16):
@@ -1052,9 +1060,13 @@ class Eagle3Engine:
                     ops.colsum_accum(b["npart"][n], rows_n, H, nm[n], accumulate=False)
         # norm weights: fp32 running total over the window, then one cast into the flat gradient
         lo = f.slices[self._norm_names[0]][0]
-        for n in self._norm_names:
-            ops.axpy_f32(g, nm[n], self._norm_total[n], accumulate=self.micro_in_window > 0)
-            ops.cast_from_f32(self._norm_total[n].view(1, -1), f.gview(n).view(1, -1))
+        if self._norm_contig:
+            ops.axpy_f32(g, self._norm_micro_all, self._norm_total_all, accumulate=self.micro_in_window > 0)
+            ops.cast_from_f32(self._norm_total_all.view(1, -1), f.grad[lo:].view(1, -1))
+        else:
+            for n in self._norm_names:
+                ops.axpy_f32(g, nm[n], self._norm_total[n], accumulate=self.micro_in_window > 0)
+                ops.cast_from_f32(self._norm_total[n].view(1, -1), f.gview(n).view(1, -1))
         if self.on_bucket_ready is not None:
             self.on_bucket_ready(lo, f.numel)
         self.micro_in_window += 1
