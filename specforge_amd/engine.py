@@ -27,7 +27,7 @@ Design notes (MI355X-first, 288 GB HBM):
 from __future__ import annotations
 
 import math
-from typing import Callable, Dict, List, Optional
+from typing import Callable, Dict, Optional
 
 import torch
 
