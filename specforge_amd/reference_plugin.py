@@ -333,14 +333,16 @@ def uninstall() -> None:
 uninstall_backend = uninstall
 
 
-def main(argv=None) -> int:
+def main(argv=None, *, worker_prefix=None) -> int:
     """``python -m specforge_amd.reference_plugin train -c run.yaml [--role ...] [--node-rank N] [--plan] [overrides ...]`` --
     ``specforge train`` (cli.py:167-268) on the HIP path with the SAME run YAML / draft JSON: the reference's own ``load_config``,
     ``resolve_run`` (handed the catalogue whose ``eagle3`` entry is the HIP registration), ``build_launch_plan`` and ``_train``,
     with ``install(override=True)`` in every process.  Multi-GPU topologies launch their workers through this module again
     (``worker_prefix`` / ``torchrun_prefix`` of ``build_launch_plan``, launch_plan.py:646-768), so each rank of
     ``torch.distributed.run`` installs the plugin before it builds its trainer.  Every other sub-command (``export``,
-    ``benchmark``) is the reference's, untouched."""
+    ``benchmark``) is the reference's, untouched.  ``worker_prefix``: the argv prefix that re-enters this function in a spawned worker
+    (default: ``python -m specforge_amd.reference_plugin``; the test suite's harness entry passes itself).  Single-node launches
+    rendezvous on 127.0.0.1 (``--local-addr``: container host names need not resolve)."""
     import argparse
     import os
     import sys
@@ -365,10 +367,10 @@ def main(argv=None) -> int:
     install(override=True)
     cfg = load_config(args.config, args.overrides)
     resolved = resolve_run(cfg, registry=registry(override=True))
-    me = (sys.executable, "-m", "specforge_amd.reference_plugin")
+    me = tuple(worker_prefix) if worker_prefix else (sys.executable, "-m", "specforge_amd.reference_plugin")
     plan = build_launch_plan(resolved.config, algorithm=resolved.algorithm, config_path=args.config, overrides=args.overrides,
                              requested_role=args.role, node_rank=args.node_rank, worker_prefix=me,
-                             torchrun_prefix=(sys.executable, "-m", "torch.distributed.run", "--no-python"))
+                             torchrun_prefix=(sys.executable, "-m", "torch.distributed.run", "--no-python", "--local-addr", "127.0.0.1"))
     if args.plan:
         print(plan.render())
         return 0
