@@ -304,6 +304,9 @@ def main():
     ap.add_argument("--feeds", action="store_true", help="run the feed comparison legs also when world > 1")
     ap.add_argument("--feed-steps", type=int, default=None, help="steps per feed leg (default: min(steps, 6))")
     ap.add_argument("--dp-single", action="store_true", help="one gradient all-reduce after the sweep instead of overlapped buckets (A/B)")
+    ap.add_argument("--dp-early-lm-head", action="store_true",
+                    help="A/B: the lm_head weight gradient (the largest bucket) and its all-reduce BEFORE the data-gradient sweep "
+                         "(engine.early_lm_head_wgrad; costs one host wait for the upstream gradient)")
     ap.add_argument("--force-dp", action="store_true", help="run the gradient collectives even at world size 1 (RCCL path on a 1-GPU box)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the product path) | gloo (launcher smoke test)")
     ap.add_argument("--share-gpu", action="store_true", help="TEST ONLY: all ranks on cuda:0 (with --dist-backend gloo)")
@@ -374,6 +377,7 @@ def main():
     backend.prepare_model(eagle)
     eagle.engine.materialise_soft_targets = args.materialise_targets
     eagle.engine.blocked_diag = not args.diag_per_step
+    eagle.engine.early_lm_head_wgrad = args.dp_early_lm_head
     eagle.engine.compact_loss_rows = not args.no_compact
     from specforge_amd.eagle3 import loss_mask_suffix_counts
 
@@ -471,7 +475,9 @@ def main():
     timed(main_strat, args.warmup, next_batch=main_next)          # untimed warm-up
     timer = KernelTimer()
     backend.comm_wait_events = []                    # (N > 1) event pairs around the waits for the bucket all-reduces
+    backend.bucket_events = [] if dist.is_initialized() else None      # (N > 1) per bucket: gradient complete -> all-reduce finished
     elapsed, out = timed(main_strat, args.steps, timer, next_batch=main_next)
+    bucket_rec, backend.bucket_events = backend.bucket_events, None     # (the legs below must not append to the timed region's record)
     main_close()
     main_spread = dict(rank_spread)
     hbm_peak_main = torch.cuda.max_memory_allocated(dev) / 1e9
@@ -567,7 +573,18 @@ def main():
                     # inside the timed steps: how long the compute stream sat in front of the optimizer waiting for the bucket
                     # all-reduces that were launched from inside the weight-gradient phase (0 = fully overlapped)
                     "exposed_wait_ms_per_step": (sum(waits) / max(1, len(waits))) if waits else None,
-                    "no_sync_backwards": backend.no_sync_backwards, "single_collective": backend._single_collective}
+                    "no_sync_backwards": backend.no_sync_backwards, "single_collective": backend._single_collective,
+                    "early_lm_head_wgrad": bool(eagle.engine.early_lm_head_wgrad)}
+            # per bucket, inside the timed steps: from "its weight gradient is complete" to "its all-reduce has finished" (mean over the steps),
+            # beside the same all-reduce alone (`buckets[i].ms`): the difference is the wait for a CU (a persistent TN workgroup owns its CU
+            # for a whole tile) plus the slowdown of sharing the chip with the next weight-gradient GEMM
+            tl = backend.bucket_timeline(bucket_rec)
+            nb = len(bounds)
+            if tl and len(tl) % nb == 0:
+                for i in range(nb):
+                    xs = [tl[j][1] for j in range(i, len(tl), nb)]
+                    per[i]["ready_to_done_ms_in_step"] = sum(xs) / len(xs)
+                    per[i]["in_step_minus_alone_ms"] = per[i]["ready_to_done_ms_in_step"] - per[i]["ms"]
         except Exception as e:      # the evidence leg runs AFTER the timed region: a failure here must not cost the line
             rccl = {"backend": args.dist_backend, "rccl_ranks": world, "error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -587,7 +604,7 @@ def main():
         torch.cuda.empty_cache()
         for key, cname, Bc, Sc, what in CONFIG_LEGS:
             try:
-                configs_out[key] = config_leg(CONFIGS[cname][0], Bc, Sc, args.ttt, args.config_steps, dev, rank, world, timed, KernelTimer, ops,
+                configs_out[key] = config_leg(SMALL if args.small else CONFIGS[cname][0], Bc, Sc, args.ttt, args.config_steps, dev, rank, world, timed, KernelTimer, ops,
                                               dict(Eagle3TrainStrategy=Eagle3TrainStrategy, OnlineEagle3Model=OnlineEagle3Model, TargetHead=TargetHead,
                                                    TrainBatch=TrainBatch, DraftConfig=DraftConfig, LlamaForCausalLMEagle3=LlamaForCausalLMEagle3,
                                                    BF16Optimizer=BF16Optimizer, HipDPTrainingBackend=HipDPTrainingBackend,
@@ -668,7 +685,17 @@ def main():
                          "launches_per_step": nlaunch / st,
                          "fused_swiglu_dgrad": {"launches_per_step": fus.get("launches_per_step"), "ms_per_step": fus.get("ms_per_step"),
                                                 "gemm_tflops": fus.get("achieved")},
-                         "gemm_ms_per_step": gemm_ms / st},
+                         "gemm_ms_per_step": gemm_ms / st,
+                         # (the driver's record keeps `roofline` whole: every hot kernel and every `configs` leg in short form)
+                         "by_kernel": dict({"gemm_nt": [round(ach / PEAK_BF16_TFLOPS, 4), round(gemm_ms / st, 3)]},
+                                           **{k: [round(v["frac"], 4), round(v["ms_per_step"], 3)] for k, v in kernels.items() if v is not None}),
+                         "by_kernel_fields": "[fraction of the bound's peak (2500 TFLOP/s MFMA or 8000 GB/s HBM), ms per step], HIP-event timed over the timed region",
+                         "by_config": ({k: [round(v["ms_per_step"], 2), round(v["tokens_per_s"], 1), round(v["draft_frac"], 4),
+                                            round(v["nt_frac"], 4) if v.get("nt_frac") else None,
+                                            {kk: round(vv["frac"], 3) for kk, vv in v.get("kernels", {}).items() if kk != "gemm_nt"}]
+                                        for k, v in configs_out.items() if isinstance(v, dict) and v.get("ms_per_step")}
+                                       if configs_out is not None else None),
+                         "by_config_fields": "[ms per optimizer step, tokens/s, draft fwd+bwd fraction of the MFMA peak, plain NT GEMM fraction, {other MFMA kernels: fraction}]"},
             # every other hot kernel of the step, same method (HIP events on the launch stream over the timed region)
             "kernels": {k: v for k, v in kernels.items() if v is not None},
             "roofline_hbm": kernels["ce_fused_zt"] or kernels["ce_fused"],

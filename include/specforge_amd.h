@@ -29,7 +29,9 @@ extern "C" {
 #define SF_BF16 0
 #define SF_F32 1
 
-#define SF_ABI_VERSION 5
+/* 6: sf_rmsnorm_bwd2 with dwX_accumulate == 2 WRITES [nb, H] partials to a non-null dwX_acc (ABI 5 ignored the pointer in that mode: an
+ * ABI-5 caller passing its H-sized accumulator there must pass NULL or move to mode 0 / 1) */
+#define SF_ABI_VERSION 6
 
 int sf_abi_version(void);
 /* 1 if this library is the SIMT-emulator test build, 0 for the gfx950 product build */
@@ -188,7 +190,8 @@ int sf_rmsnorm_bwd(const void* dy, int dtype, long lddy, const void* x, long ldx
  * d/dw1, dw2_acc (+)= d/dw2 (fp32).  H <= 4096; workspace = 2 x sf_rmsnorm_bwd_workspace_floats(rows, H) floats.  In the TTT sweep the
  * hidden state of step k feeds the final norm of step k - 1 (llama3_eagle.py:1772-1777) and the hidden_norm of step k (1625-1630): autograd
  * sums the two input gradients; run apart they read x twice and round the first partial sum to bf16.
- * With dwX_accumulate == 2 the partials [nb, H] of weight X go to dwX_acc when that is non-null (a destination of the caller's choosing: the
+ * With dwX_accumulate == 2 (ABI 6) the partials [nb, H] of weight X go to dwX_acc when that is non-null (a destination of the caller's choosing,
+ * which must hold nb * H floats, NOT H: the
  * engine's per-weight arenas), else to the X-th half of the workspace. */
 int sf_rmsnorm_bwd2(const void* dy1, long lddy1, const void* w1, float* dw1_acc, int dw1_accumulate, const void* dy2, long lddy2,
                     const void* w2, float* dw2_acc, int dw2_accumulate, int dtype, const void* x, long ldx, const float* rstd, int rows,

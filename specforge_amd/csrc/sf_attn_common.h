@@ -11,12 +11,12 @@ namespace sfattn {
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kNegBig = -1.0e30f;
-constexpr int kMaxDiag = 32;
+constexpr int kMaxDiag = 32;   // diagonal branches per launch = earlier TTT steps (ttt_length <= 33)
 // fragment reads in flight ahead of their MFMA in the slot-planned kernels (sf_attn_dkv.hip, sf_attn_w1*.hip); 8 slots = 256 matrix-pipe
 // cycles of lead (a build-time constant so that another depth can be A/B-ed as a second library: tools/attn_bench.py --lib=...)
 #ifndef SF_ATTN_KAHEAD
 #define SF_ATTN_KAHEAD 8
-#endif   // diagonal branches per launch = earlier TTT steps (ttt_length <= 33)
+#endif
 
 // ---- L2-aware work order ----------------------------------------------------
 // Workgroup ids are handed to the 8 XCDs round-robin (block b runs on XCD b % 8: observed, relied on for speed only) and

@@ -129,6 +129,12 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 2) gemm_nt_kernel(GemmArgs p) {
 int sf_gemm_nt_256_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, void* stream);
 int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, void* stream);
 int sf_gemm_nt_128_launch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype, void* stream);
+#ifdef SF_ABLATE
+// TOOLS BUILD ONLY (measured and rejected, round 6; DESIGN section 4 "Round 6"): the pair-resident 256 x 128 kernel -- two 4-wave workgroups
+// per CU so that one's epilogue runs under the other's K loop (tools/experiments/sf_gemm_p2.inc; tools/p2_ab.py).  SF_GEMM_P2=<bits> per call:
+// bit 0 = plain bf16, bit 1 = row-addend, bit 2 = fused d(SwiGLU); -1 from the launcher = the shape / epilogue does not qualify.
+#include "../../tools/experiments/sf_gemm_p2.inc"
+#endif
 // tools build only (-DSF_ABLATE): SF_GEMM_TILE=128 pins the 128x128 kernel
 static bool sf_gemm_use_256() {
     static const bool use = sf_knob("SF_GEMM_TILE", 256) != 128;
@@ -149,6 +155,15 @@ static int sf_gemm_cus() {
 static int sf_gemm_dispatch(const void* A, long lda, const void* B, long ldb, int K, const SfGemmEpi& e, int c_dtype,
                             void* stream) {
     const int M = e.M, N = e.N;
+#ifdef SF_ABLATE
+    {
+        const int p2 = sf_knob("SF_GEMM_P2", 0);
+        if ((e.Cadd ? (p2 & 2) : (p2 & 1)) && !e.sw_gu && !e.sw_dgu && !e.red_part) {
+            const int st = sf_gemm_nt_p2_launch(A, lda, B, ldb, K, e, c_dtype, stream);
+            if (st != -1) return st;
+        }
+    }
+#endif
     // chip-filling shapes (>= one 256x256 tile per CU, long K: every GEMM of the training step) take the 4-wave
     // software-pipelined kernel; smaller ones the 8-wave ping-pong kernel, whose prologue/epilogue is shorter.
     // (tools build: SF_GEMM_W4=0 pins the ping-pong kernel, =1 forces the 4-wave kernel for every 256-tile shape)
@@ -266,6 +281,15 @@ extern "C" int sf_gemm_nt_swiglu_bwd(const void* A, long lda, const void* B, lon
 #endif
     static const int fuse = sf_knob("SF_GEMM_SWIGLU_FUSE", 1);
     const bool aligned = ((size_t)gu & 15) == 0 && ((size_t)dgu & 15) == 0 && ((size_t)dact & 15) == 0;
+#ifdef SF_ABLATE
+    if (fuse && aligned && (sf_knob("SF_GEMM_P2", 0) & 4)) {
+        SfGemmEpi ef = e;
+        ef.sw_gu = (const sf_bf16*)gu; ef.sw_ldgu = ldgu;
+        ef.sw_dgu = (sf_bf16*)dgu; ef.sw_lddgu = lddgu;
+        const int st = sf_gemm_nt_p2_launch(A, lda, B, ldb, K, ef, SF_BF16, stream);
+        if (st != -1) return st;
+    }
+#endif
     if (fuse && big && aligned && M >= 256 && I % 256 == 0 && K % 64 == 0 && sf_gemm_use_256()) {
         // ragged M (real data: the collator pads a batch to its own longest sample): the whole 256-row tiles take the fused kernel,
         // the last M % 256 rows the two steps -- same bits either way, so the split is invisible

@@ -114,6 +114,8 @@ class Eagle3Engine:
         self._rope_len = c.max_position_embeddings + 20
         # device-side input checks whose verdict is read back with the upstream gradient at the END of the backward sweep (no host
         # sync in the step): slot 0 = loss_counts disagree with the loss mask, slot 1 = position ids outside the reference's range
+        self.early_lm_head_wgrad = False         # see backward(): the lm_head weight gradient + its bucket before the data-gradient sweep
+        self.max_rope_positions = 1 << 20        # upper bound for a RoPE table grown from host-known mrope ids (see forward)
         self._flags = torch.zeros(2, dtype=torch.float32, device=self.dev)
         self._flags_set = False
         # multimodal rope (llama3_eagle.py:389-427, 145-182): [3, B, S] position ids; rotary channel d of a head takes its
@@ -568,6 +570,11 @@ class Eagle3Engine:
                 lo, hi = position_span
                 if lo < 0:
                     raise ValueError(f"mrope position_ids must be >= 0 (got {lo})")
+                # a corrupt sample (an int64 garbage id) must fail here, not while building a [hi, head_dim] table on the host
+                cap = max(self.max_rope_positions, 64 * (c.max_position_embeddings + 20))
+                if hi + T > cap:
+                    raise ValueError(f"mrope position_ids span [{lo}, {hi}] is beyond {cap} positions (64 x max_position_embeddings; "
+                                     "raise Eagle3Engine.max_rope_positions if the data really is that long)")
                 self._grow_rope(hi + T)
                 rope = [(self.cos, self.sin)] * T
             pos3 = position_ids.to(self.dev).long().reshape(3, N)
@@ -884,6 +891,22 @@ class Eagle3Engine:
         plan = self._diag_plan if (nat and self.blocked_diag) else None
         for t in (b["dk"][:1] + b["dv"][:1]) if plan is not None else (b["dk"] + b["dv"]):   # (blocked form: the branch sums are
             t.zero_()                                              # first-touch writes of sf_attn_bwd_diag, only block 0's accumulate)
+        # early_lm_head_wgrad (A/B option for multi-GPU boxes, default off): both operands of the lm_head weight gradient -- d(logits) of all
+        # T steps (the fused CE wrote them during the FORWARD sweep) and the normed hidden states -- exist before the backward starts, and its
+        # bucket is the largest (Vd x H: 262 MB at the headline).  Issued here, its all-reduce has the whole data-gradient sweep to hide in
+        # instead of the rest of the weight-gradient phase.  Price: the upstream gradient g is the GEMM's alpha, so a callable g is resolved
+        # NOW -- one host wait for the forward to drain, where the default path reads it at the end of the sweep for free.
+        early_lm = None
+        if self.early_lm_head_wgrad:
+            if callable(g):
+                g = float(g())
+            early_lm = g
+            ln_e = b["ln_s"] if c.norm_output else b["h_s"]
+            K_e = self._lm_compact_K
+            ops.gemm_tn(b["logits_s"] if K_e is None else b["logits_s"][:K_e], ln_e if K_e is None else ln_e[:K_e], f.gview("lm_head.weight"),
+                        alpha=g, beta=0.0 if self.micro_in_window == 0 else 1.0, workspace=b["tn_ws"])
+            if self.on_bucket_ready is not None:
+                self.on_bucket_ready(f.slices["lm_head.weight"][0], f.slices["lm_head.weight"][1])
         nm = self._norm_micro
         first = {n: True for n in nm}
 
@@ -1034,7 +1057,12 @@ class Eagle3Engine:
         # ---- deferred weight gradients: dW = dY^T . X over all T*N token rows of the natural-layout stashes
         # (sf_gemm_tn), bf16 straight into flat.grad in all-reduce bucket order
         if callable(g):
-            g = float(g())
+            g = float(g())          # (eagle3._TTTStep: the callable reads the flags from the same pinned copy as the upstream gradient)
+        elif self._flags_set:
+            # a caller driving forward(train=True) / backward() directly (no autograd wrapper): the device-side input checks of the forward
+            # (row counts vs mask, position ids in range) must not go unread -- out-of-range ids were clamped, the step would train on wrong
+            # angles.  One small read-back at the end of the data-gradient sweep, only for batches that were checked on the device.
+            self.check_flags(self._flags.tolist())
         beta = 0.0 if self.micro_in_window == 0 else 1.0
         ln_s = b["ln_s"] if c.norm_output else b["h_s"]
         jobs = [
@@ -1049,6 +1077,8 @@ class Eagle3Engine:
              [(b["dh1_s"], b["o_s"], f.gview("midlayer.self_attn.o_proj.weight"))]),
             ("fc.weight", "fc.weight", [(fc_dy, self._fc_x, f.gview("fc.weight"))]),
         ]
+        if early_lm is not None:
+            jobs = jobs[1:]          # (early_lm_head_wgrad: the first bucket went out before the data-gradient sweep)
         for first_name, last_name, gemms in jobs:
             for dy, x, gout in gemms:
                 ops.gemm_tn(dy, x, gout, alpha=g, beta=beta, workspace=b["tn_ws"])

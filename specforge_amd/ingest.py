@@ -302,6 +302,12 @@ class HiddenStateIngest:
         # pinned slots before this call refills them (a filled-but-never-consumed slot has no `released` event to wait on)
         old = getattr(self, "_loader_thread", None)
         if old is not None and old.is_alive():
+            # a suspended-but-referenced iterator (kept in a variable, held by a traceback) leaves its loader blocked in free.get(), not
+            # reading: tell it to stop and wake it; what can still be alive after that is a loader in the middle of a file read
+            ctl = getattr(self, "_loader_ctl", None)
+            if ctl is not None:
+                ctl[0].set()
+                ctl[1].put(None)
             old.join(timeout=120.0)
             if old.is_alive():
                 raise RuntimeError("HiddenStateIngest.stream: the loader thread of an abandoned iterator is still reading (slow "
@@ -313,6 +319,7 @@ class HiddenStateIngest:
         free: "queue.Queue[int]" = queue.Queue()
         ready: "queue.Queue" = queue.Queue()
         stop = threading.Event()
+        self._loader_ctl = (stop, free)
         for i in range(nslots):
             free.put(i)
 

@@ -248,8 +248,21 @@ class HipDPTrainingBackend:
             return
         # async SUM over RCCL: enqueued behind the wgrad GEMM that produced the bucket, runs on the
         # communicator's stream while the compute stream continues with the next GEMM
-        self._handles.append(dist.all_reduce(self.module.engine.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                             async_op=True))
+        ev = getattr(self, "bucket_events", None)     # telemetry (bench.py --gpus N): see bucket_timeline()
+        if ev is not None and torch.cuda.is_available():
+            ready = torch.cuda.Event(enable_timing=True)
+            ready.record()                            # fires when the bucket's last weight-gradient GEMM has finished
+        h = dist.all_reduce(self.module.engine.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._handles.append(h)
+        if ev is not None and torch.cuda.is_available():
+            # when did the collective END: a probe stream that waits for nothing but this Work, then stamps an event
+            if getattr(self, "_probe_stream", None) is None:
+                self._probe_stream = torch.cuda.Stream()
+            done = torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(self._probe_stream):
+                h.wait()
+                done.record()
+            ev.append((lo, hi, ready, done))
 
     def backward(self, loss: torch.Tensor, *, is_boundary: bool = True) -> None:
         self._sync_this_backward = bool(is_boundary)
@@ -279,6 +292,16 @@ class HipDPTrainingBackend:
             ev.append((e0, e1))
         self._handles.clear()
         return reduced
+
+    def bucket_timeline(self, events=None):
+        """[(mbytes, ready_to_done_ms)] of the bucket all-reduces recorded while ``bucket_events`` was a list: the time from "this bucket's
+        weight gradient is complete" (an event right behind its last GEMM on the compute stream) to "its all-reduce has finished".  Beside the same all-reduce timed alone this is the wait for a CU (a persistent TN workgroup holds its
+        CU for a whole tile) plus the slowdown from sharing the chip with the next weight-gradient GEMM."""
+        out = []
+        for lo, hi, ready, done in (events if events is not None else getattr(self, "bucket_events", None)) or []:
+            done.synchronize()
+            out.append(((hi - lo) * 2 / 1e6, ready.elapsed_time(done)))
+        return out
 
     def step(self):
         reduced = self.synchronize_gradients()

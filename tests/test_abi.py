@@ -27,7 +27,7 @@ def test_hip_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libsfhip.so lacks {n}"
     assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
     lib.sf_abi_version.restype = ctypes.c_int
-    assert lib.sf_abi_version() == 5
+    assert lib.sf_abi_version() == 6
     assert lib.sf_is_emulated() == 0
 
 

@@ -94,6 +94,14 @@ def test_default_line_carries_the_configs_legs():
         assert leg.get("error") is None, leg
         assert leg["batch"] == B and leg["seq_len"] == S and leg["ms_per_step"] > 0 and 0 < leg["draft_frac"] < 1 and 0 < leg["nt_frac"] < 1
         assert abs(leg["tokens_per_s"] - B * S / (leg["ms_per_step"] / 1e3)) <= 1e-6 * leg["tokens_per_s"]
+    # the short forms inside `roofline` (the object the driver's record keeps whole): every kernel of `kernels`, every leg of `configs`
+    rf = line["roofline"]
+    assert set(rf["by_kernel"]) == set(line["kernels"]) | {"gemm_nt"}
+    for k, (frac, ms) in rf["by_kernel"].items():
+        assert 0 < frac < 1.5 and ms > 0, (k, frac, ms)
+    assert set(rf["by_config"]) == {k for k, *_ in bench.CONFIG_LEGS}
+    for k, (ms, tps, dfrac, ntfrac, others) in rf["by_config"].items():
+        assert abs(ms - cf[k]["ms_per_step"]) < 0.01 and abs(dfrac - cf[k]["draft_frac"]) < 1e-3 and isinstance(others, dict)
 
 
 def test_driver_command_line_torchrun_rccl_world1():

@@ -78,6 +78,7 @@ def _oracle_bf16(blob):
                                   "eagle3_rope_grow_fp32", "eagle3_rope_grow_dynamic_fp32"])
 def test_micro_step_matches_reference_run(backend, golden_dir, name):
     blob = torch.load(os.path.join(golden_dir, f"{name}.pt"), weights_only=False)
+    raw = blob
     if "fp32" in name:
         blob = _oracle_bf16(blob)
     cfg, model, eagle, strat = _build(blob, backend)
@@ -85,6 +86,19 @@ def test_micro_step_matches_reference_run(backend, golden_dir, name):
     out = strat.forward_loss(_batch(blob, backend))
     out.loss.backward()
     T = blob["cfg"]["ttt"]
+    if raw is not blob:
+        # first against the RAW values the reference itself produced in fp32 -- no port in between.  The HIP path ran on the bf16-ROUNDED
+        # weights and inputs (the fp32 goldens' tensors are not bf16-representable), and rounding the teacher head breaks argmax near-ties
+        # (2 of 64 positions in the tiny case); one flipped id moves a row's whole soft target, i.e. a `ploss` by ~0.1.  So: ids >= 95 %, and
+        # where NO id flipped the losses meet the raw reference numbers at north_star's bf16 bar.  (bit-exact ids / 5e-3 losses against the
+        # reference's own run on bf16-representable inputs at REAL dims: tests/test_reference_realdims.py; against this golden's inputs in
+        # bf16: right below.)
+        ids_raw = eagle.last_artifacts["target_token_ids"].cpu()
+        assert float((ids_raw == raw["target_token_ids"]).float().mean()) >= 0.95
+        if torch.equal(ids_raw, raw["target_token_ids"]):
+            torch.testing.assert_close(torch.stack(out.metrics["plosses"]).float().cpu(), raw["plosses"], rtol=2e-2, atol=2e-2)
+            torch.testing.assert_close(out.loss.detach().float().cpu(), raw["loss"], rtol=2e-2, atol=2e-2)
+            assert torch.equal(torch.stack(out.metrics["acc_denoms"]).cpu(), raw["acc_denoms"])
     # integer artefacts: bit-exact
     ids = eagle.last_artifacts["target_token_ids"].cpu()
     pm = eagle.last_artifacts["position_mask"].cpu()
@@ -96,7 +110,8 @@ def test_micro_step_matches_reference_run(backend, golden_dir, name):
     torch.testing.assert_close(pl, blob["plosses"], rtol=tol, atol=tol)
     torch.testing.assert_close(out.loss.detach().float().cpu(), blob["loss"], rtol=tol, atol=tol)
     acc = torch.stack(out.metrics["acces"]).float().cpu()
-    torch.testing.assert_close(acc, blob["acces"], rtol=0, atol=0.1)   # argmax near-ties under bf16 logits
+    # accuracy = correct / denominator: the draft's argmax may resolve a bf16 near-tie differently on at most ONE token per step
+    assert float(((acc - blob["acces"]).abs() * blob["acc_denoms"]).max()) <= 1.0 + 1e-3, (acc, blob["acces"])
     ar = torch.stack(out.metrics["acceptance_rates"]).float().cpu()
     torch.testing.assert_close(ar, blob["acceptance_rates"], rtol=tol, atol=tol)
     assert torch.stack(out.metrics["metric_loss_denoms"]).cpu().tolist() == [float(blob["batch"]["input_ids"].numel())] * T
@@ -645,3 +660,27 @@ def test_draft_backbone_method_grows_its_rope_table_too(backend, rope_scaling):
         hh = model.backbone(emb[k].to(backend), hh, cache_h, am, None)
         torch.testing.assert_close(hh.float().cpu(), ho.float(), rtol=3e-2, atol=3e-2)
     assert model._rope[0].shape[0] >= S + 1 and rope.len == S + 1
+
+
+def test_early_lm_head_weight_gradient_equals_the_deferred_one(backend, golden_dir):
+    """engine.early_lm_head_wgrad (bench.py --dp-early-lm-head): the lm_head weight gradient taken BEFORE the data-gradient
+    sweep -- its operands are complete after the forward -- is the same GEMM on the same operands: every gradient bit-identical, also over an
+    accumulation window and with the loss-row compaction on; the bucket hook fires first for the lm_head range"""
+    blob = torch.load(os.path.join(golden_dir, "eagle3_tiny_bf16.pt"), weights_only=False)
+    res = {}
+    for early in (False, True):
+        cfg, model, eagle, strat = _build(blob, backend)
+        eagle.train()
+        eagle.engine.early_lm_head_wgrad = early
+        seen = []
+        eagle.engine.on_bucket_ready = lambda lo, hi: seen.append((lo, hi))
+        for scale in (0.5, 0.25):           # two micro-steps of one window, different upstream gradients
+            b = _batch(blob, backend)
+            b.tensors["loss_mask"] = b.tensors["loss_mask"].clone()
+            b.tensors["loss_mask"][:, :5] = 0
+            out = strat.forward_loss(b)
+            (out.loss * scale).backward()
+        res[early] = (eagle.engine.flat.grad.clone().cpu(), list(seen))
+        assert seen[0] == eagle.engine.bucket_bounds()[0] and len(seen) == 2 * len(eagle.engine.bucket_bounds())
+    assert torch.equal(res[True][0], res[False][0])
+    assert res[True][1] == res[False][1]

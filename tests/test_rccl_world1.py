@@ -48,8 +48,11 @@ def _build(golden_dir, dev, **backend_kw):
     return eagle, TrainerCore(strat, backend, accumulation_steps=2), backend, batch
 
 
-def _run(golden_dir, dev, **kw):
+def _run(golden_dir, dev, early_lm_head=False, record_buckets=False, **kw):
     eagle, core, backend, batch = _build(golden_dir, dev, **kw)
+    eagle.engine.early_lm_head_wgrad = early_lm_head
+    if record_buckets:
+        backend.bucket_events = []
     norms = []
     for _ in range(4):                      # 2 optimizer steps, each = a non-boundary + a boundary micro-step
         r = core.train_step(batch)
@@ -72,5 +75,13 @@ def test_rccl_world1_paths_match_the_single_process_run(golden_dir):
             assert be.module.engine.on_bucket_ready is not None   # the hook is live: collectives were issued
             assert torch.equal(w, ref_w), f"single_collective={single}: weights differ from the run without collectives"
             assert n == ref_n
+        # the lm_head weight gradient + its bucket BEFORE the data-gradient sweep (bench.py --dp-early-lm-head), with the per-bucket event
+        # record on: same weights bit for bit; every boundary backward left one (gradient complete -> all-reduce finished) pair per bucket
+        w, n, be = _run(golden_dir, dev, early_lm_head=True, record_buckets=True, force_collectives=True)
+        assert torch.equal(w, ref_w) and n == ref_n
+        tl = be.bucket_timeline()
+        nb = len(be.module.engine.bucket_bounds())
+        assert len(tl) == 2 * nb and all(mb > 0 and ms >= 0 for mb, ms in tl)
+        assert tl[0][0] == max(mb for mb, _ in tl)          # the early bucket is the largest one (lm_head)
     finally:
         dist.destroy_process_group()
