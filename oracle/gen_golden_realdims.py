@@ -52,12 +52,23 @@ CASES = {
     # cfg 1 -- the reference's own CPU-runnable case, at FULL model dimensions and its own batch shape (1 x 256)
     "cfg1_qwen2.5-0.5b_1x256": dict(H=896, Ht=896, I=4864, nh=14, nkv=2, hd=64, Vt=151936, Vd=16000, B=1, S=256, ttt=7,
                                     lengths=[256], prompt=9, eps=1e-6, max_pos=2048, seed=101),
-    # cfg 2 dims (Llama-3-8B draft), two ragged samples of 512
+    # cfg 2 dims (Llama-3-8B draft, llama3 rope scaling as in configs/llama3-8B-eagle3.json), two ragged samples of 512
     "cfg2_llama3-8b_2x512": dict(H=4096, Ht=4096, I=14336, nh=32, nkv=8, hd=128, Vt=128256, Vd=32000, B=2, S=512, ttt=7,
-                                 lengths=[512, 389], prompt=17, eps=1e-5, max_pos=2048, seed=102),
+                                 lengths=[512, 389], prompt=17, eps=1e-5, max_pos=2048, seed=102, rope_theta=500000.0,
+                                 rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                                   original_max_position_embeddings=8192)),
+    # cfg 3 dims (Qwen3-8B draft: I 12288, 152 k vocabulary, rope theta 1e6)
+    "cfg3_qwen3-8b_1x640": dict(H=4096, Ht=4096, I=12288, nh=32, nkv=8, hd=128, Vt=151936, Vd=32000, B=1, S=640, ttt=7,
+                                lengths=[640], prompt=11, eps=1e-6, max_pos=40960, seed=103, rope_theta=1000000.0),
     # cfg 4 dims (Qwen3-30B-A3B EAGLE3.1: fc_norm, nh * hd != H)
     "cfg4_qwen3-30b-a3b-eagle31_1x384": dict(H=2048, Ht=2048, I=12288, nh=32, nkv=4, hd=128, Vt=151936, Vd=32000, B=1, S=384,
                                              ttt=7, lengths=[384], prompt=5, eps=1e-6, max_pos=2048, fc_norm=True, seed=104),
+    # cfg 5 dims (DeepSeek-V3 draft: H 7168, I 40960, 56 / 8 heads, 21504-wide hidden-state fusion)
+    "cfg5_deepseek-v3_1x256": dict(H=7168, Ht=7168, I=40960, nh=56, nkv=8, hd=128, Vt=129280, Vd=32000, B=1, S=256, ttt=7,
+                                   lengths=[256], prompt=7, eps=1e-5, max_pos=4096, seed=105),
+    # head_dim 256 (configs/qwen3-next-80b-a3b-eagle3.json: 16 / 2 heads, nh * hd = 2 H)
+    "qwen3-next-80b-a3b_1x320": dict(H=2048, Ht=2048, I=16384, nh=16, nkv=2, hd=256, Vt=151936, Vd=32000, B=1, S=320, ttt=7,
+                                     lengths=[320], prompt=13, eps=1e-6, max_pos=8192, seed=106, rope_theta=10000000.0),
 }
 
 
@@ -65,7 +76,9 @@ def run_reference(c, case, dtype):
     params, embed, head_w, t2d, d2t, batch = case
     cfg = LlamaConfig(hidden_size=c["H"], intermediate_size=c["I"], num_attention_heads=c["nh"], num_key_value_heads=c["nkv"],
                       num_hidden_layers=1, vocab_size=c["Vt"], max_position_embeddings=c["max_pos"], rms_norm_eps=c["eps"],
-                      pad_token_id=0, head_dim=c["hd"], rope_theta=10000.0)
+                      pad_token_id=0, head_dim=c["hd"], rope_theta=c.get("rope_theta", 10000.0))
+    if c.get("rope_scaling") is not None:
+        cfg.rope_parameters = dict(c["rope_scaling"], rope_theta=c.get("rope_theta", 10000.0))
     cfg.draft_vocab_size = c["Vd"]
     cfg.target_hidden_size = c["Ht"]
     cfg.fc_norm = bool(c.get("fc_norm"))

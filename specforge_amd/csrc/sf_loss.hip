@@ -618,6 +618,13 @@ teacher_reduce_perm_kernel(const T* z, long ldz, int Vz, int Vd, const int* perm
     float ts = 0.f;
     constexpr int GU = 2;
     int j = tid;
+    if (!tp) {
+        // Nothing to write: the only other product of the pass below is the probabilities' sum, which is sd * inv = 1 up to one rounding
+        // (round 5 re-summed the Vd exponentials here only to keep `tsum` bit-identical with the materialised form -- half of this
+        // VALU-bound kernel's exponentials for the last ulp of a number the reference itself only knows to fp32 summation order)
+        j = D8;
+        ts = (tid == 0) ? sd * inv : 0.f;
+    }
     for (; j + (GU - 1) * nt < D8; j += GU * nt) {
         SfRaw8<T> raw[GU];
 #pragma unroll

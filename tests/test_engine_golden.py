@@ -458,7 +458,7 @@ def test_sequence_length_not_a_multiple_of_8(backend, B, S, lengths):
 def test_unmaterialised_soft_targets_equal_the_materialised_path(backend):
     """A shape the reduced teacher-head GEMM takes (>= 192 rows, target hidden size 512, Vt past roundup(Vd, 256)): the engine keeps
     the teacher's draft logits + (max, 1 / sum-exp) per row and the fused CE re-forms target_p from them; [B, S, Vd] fp32 never exists.
-    Same micro-step with that path switched off (materialised target_p): every metric and every gradient bit for bit; ids vs the oracle."""
+    Same micro-step with that path switched off (materialised target_p): ids bit for bit, metrics 2e-6, gradients equal up to rare last-ulp roundings; ids vs the oracle."""
     from specforge_amd import ops
     kw = dict(hidden_size=64, intermediate_size=96, num_attention_heads=2, num_key_value_heads=1, vocab_size=640,
               draft_vocab_size=256, head_dim=64, target_hidden_size=512, max_position_embeddings=128, rms_norm_eps=1e-5)
@@ -499,9 +499,13 @@ def test_unmaterialised_soft_targets_equal_the_materialised_path(backend):
     kind_b, met_b, grad_b, ids_b, tp_b = run(True)
     if str(backend) == "cpu":          # (the interpreter takes the reduced GEMM for every long-K shape; a GPU only for chip-filling ones)
         assert (kind_a, kind_b) == ("zt", "tp")
-    assert torch.equal(ids_a, ids_b) and torch.equal(grad_a, grad_b)
+    # (round 6: the un-materialised form takes sum(target_p) as sd * (1 / sd) instead of re-summing Vd terms, so the two forms differ in the
+    #  last bits of that row scalar: integer artefacts exact, metrics to 1e-6, bf16 gradients equal except for a rare last-ulp rounding)
+    assert torch.equal(ids_a, ids_b)
+    dg = (grad_a.float() - grad_b.float()).abs()
+    assert float((dg > 0).float().mean()) <= 2e-3 and float(dg.max()) <= 2 ** -7 * float(grad_b.float().abs().max())
     for k in met_a:
-        assert torch.equal(met_a[k], met_b[k]), k
+        torch.testing.assert_close(met_a[k], met_b[k], rtol=2e-6, atol=1e-7, msg=k)
     torch.testing.assert_close(tp_a, tp_b, rtol=1e-6, atol=1e-9)         # (torch.exp vs the kernels' v_exp_f32 in the inspection helper)
     p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     ref = O.eagle3_forward(p, oc, embed_weight=embed, target_head_weight=head_w, t2d=t2d, d2t=d2t, input_ids=batch["input_ids"],

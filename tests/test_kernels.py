@@ -580,6 +580,9 @@ def test_ce_fused_from_teacher_logits_equals_materialised_targets(backend, dtype
     zmd2, zinv2 = torch.zeros_like(zmd), torch.zeros_like(zinv)
     ops.teacher_reduce_perm(d(zp), target_p_pad=None, zmd_pad=zmd2, zinv_pad=zinv2, **kw, **o2)      # no materialised probabilities
     for k in o:
+        if k == "tsum_pad":     # not materialised: the probabilities' sum is sd * (1 / sd), not the sum of Vd rounded terms
+            torch.testing.assert_close(o[k].cpu()[:, :S], o2[k].cpu()[:, :S], rtol=2e-6, atol=0)
+            continue
         assert torch.equal(o[k].cpu()[:, :S], o2[k].cpu()[:, :S]), k
     assert torch.equal(zmd.cpu(), zmd2.cpu()) and torch.equal(zinv.cpu(), zinv2.cpu())
     zd = torch.zeros(B * S, Vd + 8, dtype=torch.bfloat16)                                             # the stored draft logits (wider rows)

@@ -4,7 +4,8 @@
 the build container (``oracle/gen_golden_realdims.py``: imported from /root/reference, eager-loss shim, draft in fp32 = truth and in
 bf16 = yardstick, teacher head in bf16) on inputs that ``oracle/seeded_case.py`` regenerates bit-identically from a seed (checksums in
 the fixture are verified first).  Cases: cfg 1 at full dims and its own batch shape (Qwen2.5-0.5B, 1 x 256), cfg 2 dims (Llama-3-8B,
-2 x 512 ragged, prompt region), cfg 4 dims (Qwen3-30B-A3B EAGLE3.1: fc_norm, 1 x 384).
+llama3 rope scaling, 2 x 512 ragged, prompt region), cfg 3 dims (Qwen3-8B, 1 x 640), cfg 4 dims (Qwen3-30B-A3B EAGLE3.1: fc_norm, 1 x 384), cfg 5 dims
+(DeepSeek-V3 draft: H 7168, I 40960, 1 x 256) and a head_dim-256 recipe (Qwen3-Next-80B-A3B dims, 1 x 320).
 
 Bars (BASELINE.json north_star: tree indices bit-exact, loss 2e-2 for the bf16 path -- held at 5e-3 here):
   * target ids / position mask: the teacher logits are one bf16 GEMM on either side (CPU fp32-accumulate vs MFMA): a 1-ulp rounding
@@ -26,7 +27,8 @@ from oracle import eagle3_oracle as O
 from oracle import seeded_case as SC
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = ["cfg1_qwen2.5-0.5b_1x256", "cfg2_llama3-8b_2x512", "cfg4_qwen3-30b-a3b-eagle31_1x384"]
+CASES = ["cfg1_qwen2.5-0.5b_1x256", "cfg2_llama3-8b_2x512", "cfg3_qwen3-8b_1x640", "cfg4_qwen3-30b-a3b-eagle31_1x384", "cfg5_deepseek-v3_1x256",
+         "qwen3-next-80b-a3b_1x320"]
 
 
 def _load(golden_dir, name):
@@ -109,7 +111,8 @@ def test_hip_path_matches_the_reference_run_at_real_dims(golden_dir, name):
     model = LlamaForCausalLMEagle3(DraftConfig(hidden_size=c["H"], intermediate_size=c["I"], num_attention_heads=c["nh"],
                                                num_key_value_heads=c["nkv"], vocab_size=c["Vt"], draft_vocab_size=c["Vd"], head_dim=c["hd"],
                                                target_hidden_size=c["Ht"], max_position_embeddings=c["max_pos"], rms_norm_eps=c["eps"],
-                                               fc_norm=bool(c.get("fc_norm"))), device=dev)
+                                               fc_norm=bool(c.get("fc_norm")), rope_theta=c.get("rope_theta", 10000.0),
+                                               rope_scaling=c.get("rope_scaling")), device=dev)
     sd = dict(params)
     sd["embed_tokens.weight"], sd["t2d"], sd["d2t"] = embed, t2d, d2t
     model.load_state_dict(sd)
