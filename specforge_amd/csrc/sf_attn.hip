@@ -258,18 +258,11 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, AttnOcc<HD>::kWgPerCu) attn_fwd_kernel(
             }
         }
     }
-    if (!qok) return;
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     sf_bf16* orow = p.o + qrow * p.ldo + h * HD;
 #pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sf_v4s ov;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) ov[t] = (short)sf_f2bf(acc_o[d][4 * j + t] * inv);
-            *reinterpret_cast<sf_v4s*>(orow + d * 32 + 8 * j + 4 * hi) = ov;
-        }
+    for (int d = 0; d < DB; ++d) store_row32_bf16(orow + d * 32, hi, qok, [&](int i) { return acc_o[d][i] * inv; });
+    if (!qok) return;
     if (hi == 0) p.lse[((long)b * p.nh + h) * S + qi] = l > 0.f ? (m + log2f(l)) * kLn2 : kNegBig;
 }
 
@@ -733,7 +726,6 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, AttnOcc<HD>::kWgPerCu) attn_bwd_dq_kern
                     acc[d] = sf_mfma32(frag_tr<HD>(lds_k, d, kb * 32 + 16 * jp, fo), df, acc[d]);
             }
     }
-    if (!qok) return;
     sf_bf16* orow = p.dq + qrow * p.lddq + h * HD;
     // the diagonal branches' share of dQ (attn_bwd_pre): all 16 vector loads in flight at once (a per-element
     // `if (init) v += init[i]` compiled to 64 dependent dword loads, each behind its own vmcnt(0))
@@ -750,13 +742,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(NW * 64, AttnOcc<HD>::kWgPerCu) attn_bwd_dq_kern
     }
 #pragma unroll
     for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sf_v4s ov;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) ov[t] = (short)sf_f2bf(acc[d][4 * j + t] * p.scale + init[d * 4 + j][t]);
-            *reinterpret_cast<sf_v4s*>(orow + d * 32 + 8 * j + 4 * hi) = ov;
-        }
+        store_row32_bf16(orow + d * 32, hi, qok, [&](int i) { return acc[d][i] * p.scale + init[d * 4 + (i >> 2)][i & 3]; });
 }
 
 }  // namespace

@@ -197,6 +197,28 @@ SF_DEVICE sf_v8s pack_bf16x8(const sf_v16f& p, int r0) {      // four v_cvt_pk_b
     for (int i = 0; i < 4; ++i) o[i] = sf_pack2_bf16(p[r0 + 2 * i], p[r0 + 2 * i + 1]);
     return __builtin_bit_cast(sf_v8s, o);
 }
+// Store one 32-column block of a row-per-lane 32x32 MFMA result as bf16: lane (c, hi) holds, for j = 0..3, the 4 columns 8 j + 4 hi .. + 3
+// of its row -- natural stores are four 8-byte pieces per lane.  Two half-wave exchanges per column-group pair (v_permlane32_swap) give
+// the lower lanes columns 16 p .. + 7 and the upper lanes 16 p + 8 .. + 15: TWO 16-byte stores per lane instead of four 8-byte ones, same
+// bytes, same addresses (the epilogue is store-ISSUE-bound: MI355X_MICROARCH.md "attention epilogue store tail", guide T21).
+// `v(i)` = value i (0..15) of the block in the accumulator's register order.  Every lane of the wave must call it (lane exchange);
+// `live` masks the stores.
+template <class F>
+SF_DEVICE void store_row32_bf16(sf_bf16* dst, int hi, bool live, F&& v) {
+    unsigned w[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w[j][0] = sf_pack2_bf16(v(4 * j), v(4 * j + 1));
+        w[j][1] = sf_pack2_bf16(v(4 * j + 2), v(4 * j + 3));
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        sf_swap_halves(w[2 * pr][0], w[2 * pr + 1][0]);
+        sf_swap_halves(w[2 * pr][1], w[2 * pr + 1][1]);
+        if (live)
+            *reinterpret_cast<sf_v4i*>(dst + 16 * pr + 8 * hi) = sf_v4i{(int)w[2 * pr][0], (int)w[2 * pr][1], (int)w[2 * pr + 1][0], (int)w[2 * pr + 1][1]};
+    }
+}
 // row index inside a 32x32 MFMA result tile held by this lane in register r
 SF_DEVICE int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 

@@ -353,20 +353,14 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_fwd_w1_kernel(AttnFwdArgs p) {
         sf_wait_vm0();          // (the stand-in pieces of the last branch: LDS must not be released under them)
         bank.drain();
     }
-    if (!qok) return;
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     sf_bf16* orow = p.o + qrow * p.ldo + h * HD;
     static_for<0, DB>([&](auto D) SF_LAMBDA_INLINE {
         constexpr int d = decltype(D)::value;
         const sf_v16f a = bank.template get_o<d>();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sf_v4s ov;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) ov[t] = (short)sf_f2bf(a[4 * j + t] * inv);
-            *reinterpret_cast<sf_v4s*>(orow + d * 32 + 8 * j + 4 * hi) = ov;
-        }
+        store_row32_bf16(orow + d * 32, hi, qok, [&](int i) { return a[i] * inv; });
     });
+    if (!qok) return;
     if (hi == 0) p.lse[((long)b * p.nh + h) * S + qi] = l > 0.f ? (m + log2f(l)) * kLn2 : kNegBig;
 }
 
@@ -548,8 +542,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dq_w1_kernel(AttnBwdArgs p) {
     }
     sf_wait_vm0();   // (the stand-in pieces of the last iteration may still be in flight: LDS must not be released under them)
     bank.drain();
-    if (!qok) return;
-    sf_bf16* orow = p.dq + qrow * p.lddq + h * HD;
+    sf_bf16* orow = p.dq + qrow * p.lddq + h * HD;     // (dead lanes shadow a valid row and skip the stores: store_row32_bf16 exchanges lanes)
     const float* irow = p.dq_init ? p.dq_init + qrow * ((long)p.nh * HD) + h * HD : nullptr;
     // the diagonal branches' share of dQ (attn_bwd_diag / attn_bwd_pre) joins here; a 32-column block at a time (the accumulators
     // come out of the bank 16 registers at a time: no 128-register staging)
@@ -560,13 +553,7 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) attn_bwd_dq_w1_kernel(AttnBwdArgs p) {
         for (int j = 0; j < 4; ++j)
             init[j] = irow ? *reinterpret_cast<const sf_v4f*>(irow + d * 32 + 8 * j + 4 * hi) : sf_v4f{0.f, 0.f, 0.f, 0.f};
         const sf_v16f a = bank.template get_dq<d>();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sf_v4s ov;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) ov[t] = (short)sf_f2bf(a[4 * j + t] * p.scale + init[j][t]);
-            *reinterpret_cast<sf_v4s*>(orow + d * 32 + 8 * j + 4 * hi) = ov;
-        }
+        store_row32_bf16(orow + d * 32, hi, qok, [&](int i) { return a[i] * p.scale + init[i >> 2][i & 3]; });
     });
 }
 
