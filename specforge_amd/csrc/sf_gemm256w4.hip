@@ -49,6 +49,7 @@ int sf_gemm_nt_256w4_launch(const void* A, long lda, const void* B, long ldb, in
     // ragged M: the last row tile is shifted up to end at row M (GemmW4Args::mshift) unless the epilogue reads what it writes
     p.mshift = (M > TM && M % TM != 0 && p.e.beta == 0.f && (const void*)p.e.R != (const void*)p.e.C &&
                 (!p.e.sw_gu || (const void*)p.e.sw_gu != (const void*)p.e.sw_dgu) && sf_knob("SF_GEMM_MSHIFT", 1)) ? 1 : 0;
+    p.epi_direct = sf_knob("SF_GEMM_EPI_DIRECT", 1);
     // the 32-bit per-lane byte offsets of the buffer-descriptor DMA cover one 256-row tile of either operand
     SF_CHECK_ARG(256L * lda * 2 < (1L << 31) && 256L * ldb * 2 < (1L << 31), "sf_gemm_nt: row stride too large for the 256-tile kernel");
     if (p.e.Cadd) SF_CHECK_ARG(p.e.alpha == 1.0f, "sf_gemm_nt_rowadd: the 4-wave kernel needs alpha == 1");

@@ -75,6 +75,9 @@ struct GemmW4Args {
     // neighbour, every tile is whole (fast / fused epilogues, no bounds), and the rows computed twice get the same bits twice (a row's
     // accumulation order does not depend on the tile it is in).  Set by the launcher for M >= 256, beta == 0, no in-place residual.
     int mshift = 0;
+    // round 6: 1 = whole tiles of the bf16 residual form transpose in REGISTERS (v_permlane16_swap of packed column-block pairs: a lane ends
+    // up with 8 consecutive columns = 16 bytes of residual in, 16 bytes out) instead of taking the general store; 0 (tools build A/B) = as before
+    int epi_direct = 0;
 #ifdef SF_ABLATE
     int stagger;
     int cyc;   // tools build: wave 0 of every workgroup overwrites C[m0][n0..n0+1] with its K-loop cycle count (fp32 bits)
@@ -442,7 +445,8 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
     // the interior-tile fast path of the epilogue (workgroup-uniform; 16-byte row segments need 16-byte aligned rows)
     // (split-K partials live in a workspace laid out in WHOLE row tiles: an edge tile stores all 256 rows there -- the rows past M come
     //  from re-read operand rows and are never read back)
-    const bool fast = SF_W4_FAST_EPI && (mc + TM <= p.M || p.ksplit > 1) && nc + TN <= p.N && p.e.beta == 0.f && !p.e.R && (p.e.ldc & 7) == 0 &&
+    const bool direct_r = !OUT_F32 && ADD == 0 && p.epi_direct && p.e.R && (p.e.ldr & 7) == 0 && ((size_t)p.e.R & 15) == 0;   // residual: direct form only
+    const bool fast = SF_W4_FAST_EPI && (mc + TM <= p.M || p.ksplit > 1) && nc + TN <= p.N && p.e.beta == 0.f && (!p.e.R || direct_r) && (p.e.ldc & 7) == 0 &&
                       ((size_t)p.e.C & 15) == 0;
     // Row-addend form (round 3): the fp32 addend joins the accumulator in the EPILOGUE, before the single bf16 rounding.  Round 2
     // started the accumulators from it: 256 KiB of loads per tile in front of the first MFMA, every workgroup of a round at
@@ -618,6 +622,51 @@ SF_GLOBAL void SF_LAUNCH_BOUNDS(256, 1) gemm_nt_256w4_kernel(GemmW4Args p) {
                     }
                     sf_wave_lockstep();
                 }
+            } else if (direct_r) {
+            // Residual form (round 6; o_proj and down_proj of the forward: 14 launches per step, which took the general store below until
+            // then -- 8-byte residual loads and 8-byte stores, 16 row fragments of 32 B per instruction).  No LDS staging: a lane holds columns
+            // 4 q .. 4 q + 3 of each 16-column block j; two v_permlane16_swap per block PAIR (2 jp, 2 jp + 1) exchange the packed halves
+            // between lane rows q and q ^ 1, after which lane (q, r) holds 8 consecutive columns of row r -- block 2 jp + (q & 1), columns
+            // 8 (q >> 1) .. + 7: the residual comes in and the sum leaves as 16 bytes per lane, 64 contiguous bytes per row and instruction.
+            // round(round(acc) + residual), as sf_gemm_store4 does.  Measured against the general store: 0.459 -> 0.409 ms at 16384 x 4096 x
+            // 4096, 1.339 -> 1.300 at K = 14336.  The same register transposition for the forms WITHOUT a second operand is a wash against
+            // the staged whole lines (+-1 %), and 4 - 7 % slower for d(SwiGLU): profiles/r6_epi_direct_ab.jsonl -- they keep the staging.
+            const int colq = (q & 1) * 16 + (q >> 1) * 8;
+            const long drow = mc + wr * 128 + r;
+            const int dcol = nc + wc * 128 + colq;
+            sf_bf16* cdir = (sf_bf16*)p.e.C + drow * p.e.ldc + dcol;
+            const sf_bf16* rdir = p.e.R + drow * p.e.ldr + dcol;
+            sf_v8s rq[2][4];                // residual of the lane's 8 columns: m-tile i + 1 requested while m-tile i is converted
+            auto res_load = [&](int i, int bufi) SF_INLINE_LAMBDA {
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) rq[bufi][jp] = *reinterpret_cast<const sf_v8s*>(rdir + (long)(i * 16) * p.e.ldr + jp * 32);
+            };
+            res_load(0, 0);
+            auto tile_out_res = [&](auto UNIT) SF_INLINE_LAMBDA {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i + 1 < 8) res_load(i + 1, (i + 1) & 1);
+                w4_fence();
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    sf_v4f v0 = acc[i][2 * jp], v1 = acc[i][2 * jp + 1];
+                    if constexpr (!decltype(UNIT)::value) { v0 = v0 * alpha; v1 = v1 * alpha; }
+                    unsigned d8[4] = {sf_pack2_bf16(v0[0], v0[1]), sf_pack2_bf16(v0[2], v0[3]), sf_pack2_bf16(v1[0], v1[1]), sf_pack2_bf16(v1[2], v1[3])};
+                    sf_swap_rows16(d8[0], d8[2]);
+                    sf_swap_rows16(d8[1], d8[3]);
+                    sf_v4i o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = __builtin_bit_cast(float, d8[e] << 16) + sf_bf2f((sf_bf16)rq[i & 1][jp][2 * e]);
+                        const float hi = __builtin_bit_cast(float, d8[e] & 0xffff0000u) + sf_bf2f((sf_bf16)rq[i & 1][jp][2 * e + 1]);
+                        o[e] = (int)sf_pack2_bf16(lo, hi);
+                    }
+                    *reinterpret_cast<sf_v4i*>(cdir + (long)(i * 16) * p.e.ldc + jp * 32) = o;
+                }
+            }
+            };
+            if (p.e.alpha != 1.0f) tile_out_res(std::false_type{});
+            else tile_out_res(std::true_type{});
             } else {
             // (UNIT: alpha == 1, every GEMM of the training step -- its own copy of the loop: a per-value select costs more than the multiply)
             // d(SwiGLU) form: gate / up of m-tile i + 1 are requested before m-tile i is staged and converted -- with the lean staging

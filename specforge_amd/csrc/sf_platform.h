@@ -110,6 +110,12 @@ SF_DEVICE void sf_swap_halves(unsigned& a, unsigned& b) {
     const unsigned from_a = sfemu::shfl(a, l ^ 32), from_b = sfemu::shfl(b, l ^ 32);
     if (l < 32) b = from_a; else a = from_b;
 }
+// v_permlane16_swap_b32 a, b: the odd 16-lane rows of a (lanes 16..31, 48..63) exchange with the even rows of b (lanes 0..15, 32..47)
+SF_DEVICE void sf_swap_rows16(unsigned& a, unsigned& b) {
+    const int l = sfemu::lane_id();
+    const unsigned from_a = sfemu::shfl(a, l ^ 16), from_b = sfemu::shfl(b, l ^ 16);
+    if (l & 16) a = from_b; else b = from_a;
+}
 SF_DEVICE bool sf_all(bool pred) {
     int v = pred ? 1 : 0;
     for (int m = 32; m >= 1; m >>= 1) v &= sfemu::shfl_xor(v, m);
@@ -213,6 +219,8 @@ SF_DEVICE bool sf_all(bool pred) { return __all(pred ? 1 : 0) != 0; }
 // v_permlane32_swap_b32 a, b: lanes 32..63 of a exchange with lanes 0..31 of b (the other two halves stay).  s_nop 1: the
 // VALU-write -> permlane-read hazard (both operands usually come straight out of a v_cvt_pk)
 SF_DEVICE void sf_swap_halves(unsigned& a, unsigned& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+// v_permlane16_swap_b32 a, b: the odd 16-lane rows of a exchange with the even rows of b (same hazard)
+SF_DEVICE void sf_swap_rows16(unsigned& a, unsigned& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 // ds_read_b64_tr_b16: per 16-lane group, lane i passes the address of 8-byte piece i of a 4x16 bf16 block
 // (piece i = row i/4, columns 4*(i%4)..+3; any row stride) and receives column i (rows 0..3).  Verified on
 // MI355X by tools/probes/tr_probe.hip.

@@ -191,6 +191,38 @@ def test_gemm_nt_split_k_for_under_filled_grids(backend, M, N, K, ks, out_dtype)
     assert torch.equal(again.cpu(), out.cpu())             # run-to-run identical, whatever the workspace held
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256),      # whole tiles: the register-transposed epilogue with the residual read at the lane's 16 bytes
+                                   (520, 768, 128),      # ragged M: the shifted last row tile (the rows computed twice get the residual once each time)
+                                   (512, 600, 128),      # an edge column tile takes the general store
+                                   (1100, 608, 192)])    # persistent walk: interior + edge tiles per workgroup
+def test_gemm_nt_residual_is_the_plain_output_plus_the_residual(backend, M, N, K):
+    """bf16 output with a residual = round(round(a . b^T) + residual): bit for bit the plain GEMM's output followed by a bf16 add, whichever
+    epilogue a tile takes (round 6: whole tiles transpose in registers and read the residual as 16 bytes per lane; edge tiles the general
+    store); also through column slices of wider buffers (row strides that are not the width) and in place (residual == out)."""
+    a, b = _rand((M, K), torch.bfloat16, 11), _rand((N, K), torch.bfloat16, 12)
+    res = _rand((M, N), torch.bfloat16, 13, scale=4.0)
+    d = lambda t: _dev(backend, t)
+    plain = torch.empty((M, N), dtype=torch.bfloat16, device=backend)
+    ops.gemm_nt(d(a), d(b), plain)
+    want = (plain.cpu() + res)
+    out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=backend)
+    ops.gemm_nt(d(a), d(b), out, residual=d(res))
+    assert torch.equal(out.cpu(), want)
+    wide_c = torch.zeros((M, N + 24), dtype=torch.bfloat16, device=backend)
+    wide_r = torch.zeros((M, N + 40), dtype=torch.bfloat16, device=backend)
+    wide_r[:, 16:16 + N] = d(res)
+    ops.gemm_nt(d(a), d(b), wide_c[:, 8:8 + N], residual=wide_r[:, 16:16 + N])
+    assert torch.equal(wide_c[:, 8:8 + N].cpu(), want)
+    assert float(wide_c[:, :8].abs().max()) == 0 and float(wide_c[:, 8 + N:].abs().max()) == 0
+    wide_r[:, 4:4 + N] = d(res)                       # a residual that is only 8-byte aligned: the general store
+    out.fill_(7.0)
+    ops.gemm_nt(d(a), d(b), out, residual=wide_r[:, 4:4 + N])
+    assert torch.equal(out.cpu(), want)
+    inplace = d(res).clone()
+    ops.gemm_nt(d(a), d(b), inplace, residual=inplace)
+    assert torch.equal(inplace.cpu(), want)
+
+
 def test_gemm_nt_peeled_last_round_epilogues(backend):
     """the peeled column tile of a partly filled last round (interpreter: 2 x 5 tiles on 8 "CUs") carries the same epilogue:
     residual after the rounding (bf16), alpha / beta (fp32)"""
