@@ -79,6 +79,7 @@ CONFIG_LEGS = [
 SMALL = dict(hidden_size=512, intermediate_size=1024, num_attention_heads=4, num_key_value_heads=2, vocab_size=4096,
              draft_vocab_size=1024, head_dim=128, target_hidden_size=512, max_position_embeddings=2048, rms_norm_eps=1e-5)
 PEAK_BF16_TFLOPS = 2500.0
+MFMA_ONLY_SUSTAINED_TFLOPS = 2038.0     # measured: back-to-back 16x16x32 bf16 MFMAs, random operands, 256 CUs (tools/probes/mfma_power_probe.hip, profiles/r6_mfma_power_probe.jsonl)
 PEAK_HBM_GBS = 8000.0          # spec; ~6300 GB/s is what a float4 copy reaches (MI355X_MICROARCH.md)
 GEMM_KERNEL_NAME = "gemm_nt_256w4_kernel (bf16 MFMA GEMM, 256x256x64, 4 waves x 128x128, plan-scheduled: one filler per MFMA slot, counted vmcnt)"
 
@@ -686,6 +687,11 @@ def main():
                          "fused_swiglu_dgrad": {"launches_per_step": fus.get("launches_per_step"), "ms_per_step": fus.get("ms_per_step"),
                                                 "gemm_tflops": fus.get("achieved")},
                          "gemm_ms_per_step": gemm_ms / st,
+                         # what back-to-back v_mfma_f32_16x16x32_bf16 on random bf16 operands sustain on this part with nothing else in the loop
+                         # (power-limited clock 1.94 GHz, not the 2.4 GHz `peak` assumes): the practical ceiling of any bf16 GEMM here.  A measured
+                         # constant (tools/probes/mfma_power_probe.hip), NOT the `peak` this line is priced against.
+                         "mfma_only_sustained": {"tflops": MFMA_ONLY_SUSTAINED_TFLOPS, "frac_of_it": ach / MFMA_ONLY_SUSTAINED_TFLOPS,
+                                                 "source": "profiles/r6_mfma_power_probe.jsonl"},
                          # (the driver's record keeps `roofline` whole: every hot kernel and every `configs` leg in short form)
                          "by_kernel": dict({"gemm_nt": [round(ach / PEAK_BF16_TFLOPS, 4), round(gemm_ms / st, 3)]},
                                            **{k: [round(v["frac"], 4), round(v["ms_per_step"], 3)] for k, v in kernels.items() if v is not None}),

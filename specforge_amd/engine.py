@@ -71,7 +71,7 @@ class Eagle3Engine:
     _NORMS_PER_STEP = ("norm.weight", "midlayer.hidden_norm.weight", "midlayer.post_attention_layernorm.weight")
 
     def __init__(self, model: LlamaForCausalLMEagle3, *, ttt_length: int = 7, ploss_decay: float = 0.8,
-                 teacher_rows: int = 4096, lk_loss_type: Optional[str] = None, kl_scale: float = 1.0,
+                 teacher_rows: int = 16384, lk_loss_type: Optional[str] = None, kl_scale: float = 1.0,
                  kl_decay: float = 1.0):
         self.model = model
         self.cfg: DraftConfig = getattr(model, "draft_config", None) or model.config   # (the plugin class keeps the HF config in .config)
@@ -106,6 +106,9 @@ class Eagle3Engine:
         self.decay = float(ploss_decay)
         self.flat = FlatParams(model)
         self.dev = self.flat.data.device
+        # rows per teacher-head launch.  Round 6: 16384 (was 4096) -- at the headline one launch of 64 x 501 tiles (125.25 rounds of 256) instead of
+        # four of 31.3 rounds each: three partly filled last rounds and three reduce launches fewer, -0.35 ms per step (profiles/r6_teacher_rows_ab.jsonl);
+        # the per-row block records grow to 12 KB x rows (197 MB), the full-vocabulary scratch of the materialised forms to 2 x Vt x rows bytes
         self.teacher_rows = teacher_rows
         cos, sin = rope_tables(c, torch.bfloat16)
         self.cos, self.sin = cos.to(self.dev), sin.to(self.dev)

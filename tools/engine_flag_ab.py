@@ -1,6 +1,7 @@
 """Same-process, same-box A/B of a boolean engine attribute inside the real optimizer step (alternating legs, medians):
 
     python tools/engine_flag_ab.py --flag norm_colsum_batched [--config llama3-8b] [--batch 8 --seq 2048] [--steps 10] [--rounds 5]     (GPU box)
+    python tools/engine_flag_ab.py --flag teacher_rows --values 16384,4096          (an integer attribute: "on" = the first value)
 
 One model, one batch resident in HBM, the product path (strategy -> autograd node -> backend.step()); the flag is flipped between legs.
 """
@@ -28,6 +29,7 @@ def main():
     ap.add_argument("--seq", type=int, default=None)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--values", default=None, help="A,B: two integer values of a non-boolean engine attribute (e.g. --flag teacher_rows --values 16384,4096)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg, B0, S0, _ = bench.CONFIGS[args.config]
@@ -46,7 +48,12 @@ def main():
     backend = HipDPTrainingBackend(optimizer_factory=lambda m: BF16Optimizer(m, lr=1e-4, max_grad_norm=0.5, total_steps=10_000_000, warmup_ratio=0.0))
     backend.prepare_model(eagle)
     eng = eagle.engine
-    assert isinstance(getattr(eng, args.flag), bool), f"engine.{args.flag} is not a boolean attribute"
+    if args.values:
+        on, off = (int(x) for x in args.values.split(","))
+        assert isinstance(getattr(eng, args.flag), int), f"engine.{args.flag} is not an integer attribute"
+    else:
+        on, off = True, False
+        assert isinstance(getattr(eng, args.flag), bool), f"engine.{args.flag} is not a boolean attribute"
     tb = TrainBatch(bench.make_batch(cfg, B, S, dev, 100), {"target_repr": "hidden_state"})
 
     def step():
@@ -62,18 +69,18 @@ def main():
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t0) / n
 
-    for v in (True, False):
+    for v in (on, off):
         setattr(eng, args.flag, v)
         timed(3)
-    acc = {True: [], False: []}
+    acc = {on: [], off: []}
     for r in range(args.rounds):
-        for v in ((True, False) if r % 2 == 0 else (False, True)):      # alternate which leg goes first
+        for v in ((on, off) if r % 2 == 0 else (off, on)):      # alternate which leg goes first
             setattr(eng, args.flag, v)
             timed(2)
             acc[v].append(timed(args.steps))
     med = {v: sorted(x)[len(x) // 2] for v, x in acc.items()}
-    print(json.dumps(dict(flag=args.flag, config=args.config, batch=B, seq=S, steps_per_leg=args.steps, rounds=args.rounds, on_ms=med[True], off_ms=med[False],
-                          on_minus_off_ms=med[True] - med[False], on_all=[round(x, 2) for x in acc[True]], off_all=[round(x, 2) for x in acc[False]])), flush=True)
+    print(json.dumps(dict(flag=args.flag, values=[on, off], config=args.config, batch=B, seq=S, steps_per_leg=args.steps, rounds=args.rounds, on_ms=med[on], off_ms=med[off],
+                          on_minus_off_ms=med[on] - med[off], on_all=[round(x, 2) for x in acc[on]], off_all=[round(x, 2) for x in acc[off]])), flush=True)
 
 
 if __name__ == "__main__":
