@@ -81,6 +81,10 @@ def case_nt(rng, seed):
         res = rnd((M, N), seed + 2)
         ops.gemm_nt(a, b, out, residual=res, workspace=ws)
         ref = ref + res.float()
+        if ws is None:      # round(round(a . b^T) + residual): bit for bit the plain output followed by a bf16 add, whichever epilogue a tile takes
+            plain = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+            ops.gemm_nt(a, b, plain)
+            assert torch.equal(out, plain + res), (desc, "residual form != plain output + residual")
     elif mode == "alpha_beta":
         ops.gemm_nt(a, b, out, alpha=0.5, beta=2.0)
         ref = 0.5 * ref + 14.0
