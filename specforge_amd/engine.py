@@ -110,6 +110,7 @@ class Eagle3Engine:
         # four of 31.3 rounds each: three partly filled last rounds and three reduce launches fewer, -0.35 ms per step (profiles/r6_teacher_rows_ab.jsonl);
         # the per-row block records grow to 12 KB x rows (197 MB), the full-vocabulary scratch of the materialised forms to 2 x Vt x rows bytes
         self.teacher_rows = teacher_rows
+        self.teacher_compact_rows = 4096
         cos, sin = rope_tables(c, torch.bfloat16)
         self.cos, self.sin = cos.to(self.dev), sin.to(self.dev)
         # the reference's rotary module REBUILDS its cos / sin cache when a step's seq_len = S + k exceeds the cached length
@@ -190,7 +191,9 @@ class Eagle3Engine:
         return self._arena[name][:n].view(*shape)
 
     def reserve(self, B: int, S: int) -> None:
-        """size every buffer for batches up to [B, S] now (one allocation per buffer; smaller batches are views)"""
+        """size every buffer for batches up to [B, S] now (one allocation per buffer; smaller batches are views).  The teacher's scratch is
+        carved at the first forward (the head's vocabulary is an argument of the call, not of the engine) -- for these many rows at once."""
+        self._reserved_rows = max(getattr(self, "_reserved_rows", 0), B * S)
         self._buffers(B, S)
 
     def arena_bytes(self) -> int:
@@ -486,7 +489,9 @@ class Eagle3Engine:
         target id 0 (nothing reads its soft target; ``last_artifacts`` are meaningful where the loss mask is set).  -> False when a chunk
         would not take the reduced GEMM form (the caller runs the dense teacher)."""
         Vd, Vt, Ht = self.cfg.draft_vocab_size, head.shape[0], th.shape[1]
-        cap = min(self.teacher_rows, part.shape[0])        # (the head GEMM's per-row partials were carved for the dense teacher's chunk)
+        # (the head GEMM's per-row partials were carved for the dense teacher's chunk; the gathered form keeps chunks of <= 4096 rows: its scratch --
+        #  [chunk, roundup(Vd, 256)] logits -- is sized by the largest count seen, and a long run on sparse masks should reach its floor early)
+        cap = min(self.teacher_compact_rows, self.teacher_rows, part.shape[0])
         nch = max(1, -(-Nm // cap))
         m = -(-Nm // nch)
         sizes = [min(m, Nm - i * m) for i in range(nch)] if Nm else []
@@ -648,7 +653,10 @@ class Eagle3Engine:
             perm, head, ordered = self._permuted_teacher_head(target_head_weight)
             # per-block partials of the columns the head GEMM reduces instead of storing (only when ties inside a block resolve
             # to the lowest ORIGINAL index by column order alone, i.e. the mapping is ascending)
-            part = self._carve("teacher_part", min(cb, B) * S, (Vt - Vd + 127) // 128, 4, dtype=torch.float32, invalidate=False) if ordered else None
+            prow = min(cb, B) * S
+            if ordered:      # (capacity for the reserved shape at once: a long run's arena stops growing at its first step, not at its largest batch)
+                self._carve("teacher_part", max(prow, min(self.teacher_rows, getattr(self, "_reserved_rows", 0))), (Vt - Vd + 127) // 128, 4, dtype=torch.float32, invalidate=False)
+            part = self._carve("teacher_part", prow, (Vt - Vd + 127) // 128, 4, dtype=torch.float32, invalidate=False) if ordered else None
             chunks = [(b0, min(cb, B - b0)) for b0 in range(0, B, cb)]
             # The usual case -- every chunk takes the reduced head GEMM, no LK objective: the GEMM writes the draft logits of its rows
             # straight into a persistent [N, roundup(Vd, 256)] bf16 array, the reduce kernel adds (max, 1 / sum-exp) per row, and the
