@@ -28,6 +28,7 @@
 #include <cstring>
 #include <functional>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #if defined(__has_feature)
@@ -36,6 +37,38 @@
 extern "C" void __sanitizer_start_switch_fiber(void** fake_stack_save, const void* bottom, size_t size);
 extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const void** bottom_old, size_t* size_old);
 #endif
+#endif
+
+// Fiber switch.  glibc's swapcontext saves and restores the signal mask: two rt_sigprocmask system calls per switch, and a 256-thread
+// workgroup switches fibers ~10^5 times per launch -- a third of the CPU time of the interpreter tests was spent in the kernel.  On x86-64
+// (outside AddressSanitizer builds, which need the ucontext path for their fiber annotations) a switch is the System V callee-saved state:
+// rbx, rbp, r12 - r15, the stack pointer, MXCSR and the x87 control word.
+#if defined(__x86_64__) && !defined(SFEMU_ASAN)
+#define SFEMU_FASTSWITCH 1
+__attribute__((naked, noinline, unused)) static void sfemu_switch(void** /*save_sp: rdi*/, void* /*load_sp: rsi*/) {
+    __asm__ volatile(
+        "pushq %rbp\n\t"
+        "pushq %rbx\n\t"
+        "pushq %r12\n\t"
+        "pushq %r13\n\t"
+        "pushq %r14\n\t"
+        "pushq %r15\n\t"
+        "subq $8, %rsp\n\t"
+        "stmxcsr (%rsp)\n\t"
+        "fnstcw 4(%rsp)\n\t"
+        "movq %rsp, (%rdi)\n\t"
+        "movq %rsi, %rsp\n\t"
+        "ldmxcsr (%rsp)\n\t"
+        "fldcw 4(%rsp)\n\t"
+        "addq $8, %rsp\n\t"
+        "popq %r15\n\t"
+        "popq %r14\n\t"
+        "popq %r13\n\t"
+        "popq %r12\n\t"
+        "popq %rbx\n\t"
+        "popq %rbp\n\t"
+        "ret\n\t");
+}
 #endif
 
 namespace sfemu {
@@ -51,7 +84,11 @@ struct dim3 {
 enum FiberState { RUNNABLE = 0, AT_BLOCK_BARRIER = 1, AT_WAVE_SYNC = 2, DONE = 3 };
 
 struct Fiber {
+#ifdef SFEMU_FASTSWITCH
+    void* sp = nullptr;         // saved stack pointer (sfemu_switch)
+#else
     ucontext_t ctx;
+#endif
     char* stack = nullptr;
     int state = RUNNABLE;
     uint3e tid{0, 0, 0};
@@ -70,7 +107,11 @@ struct Wave {
 struct BlockCtx {
     std::vector<Fiber> fibers;
     std::vector<Wave> waves;
+#ifdef SFEMU_FASTSWITCH
+    void* sched_sp = nullptr;
+#else
     ucontext_t sched;
+#endif
     void* sched_asan_fake = nullptr;
     const void* sched_stack_bottom = nullptr;
     size_t sched_stack_size = 0;
@@ -80,8 +121,35 @@ struct BlockCtx {
     dim3 bdim, gdim;
     const std::function<void()>* body = nullptr;
     std::vector<char> dyn_smem;
-    std::vector<char> stack_pool;
+    char* stack_pool = nullptr;     // nthreads x kStackBytes, from the process-wide pool below (not zeroed: a launch's workers used to
+                                    // allocate and clear 16 MiB each)
+    size_t stack_pool_bytes = 0;
 };
+
+// stack arenas are recycled across launches (workers are fresh OS threads per launch, so a thread_local would not survive)
+struct StackPool {
+    std::atomic_flag lock = ATOMIC_FLAG_INIT;
+    std::vector<std::pair<char*, size_t>> free_list;
+    char* take(size_t bytes) {
+        while (lock.test_and_set(std::memory_order_acquire)) {}
+        char* p = nullptr;
+        for (size_t i = 0; i < free_list.size(); ++i)
+            if (free_list[i].second == bytes) { p = free_list[i].first; free_list[i] = free_list.back(); free_list.pop_back(); break; }
+        lock.clear(std::memory_order_release);
+        if (!p && posix_memalign((void**)&p, 64, bytes) != 0) { fprintf(stderr, "[sfemu] out of memory (fiber stacks)\n"); abort(); }
+        return p;
+    }
+    void give(char* p, size_t bytes) {
+        while (lock.test_and_set(std::memory_order_acquire)) {}
+        if (free_list.size() < 64) { free_list.emplace_back(p, bytes); p = nullptr; }
+        lock.clear(std::memory_order_release);
+        if (p) free(p);
+    }
+};
+inline StackPool& stack_pool() {
+    static StackPool sp;
+    return sp;
+}
 
 inline BlockCtx*& tls_ctx() {
     static thread_local BlockCtx* c = nullptr;
@@ -94,7 +162,11 @@ inline void switch_to_sched() {
 #ifdef SFEMU_ASAN
     __sanitizer_start_switch_fiber(f->state == DONE ? nullptr : &f->asan_fake, c->sched_stack_bottom, c->sched_stack_size);
 #endif
+#ifdef SFEMU_FASTSWITCH
+    sfemu_switch(&f->sp, c->sched_sp);
+#else
     swapcontext(&f->ctx, &c->sched);
+#endif
 #ifdef SFEMU_ASAN
     __sanitizer_finish_switch_fiber(f->asan_fake, nullptr, nullptr);
 #endif
@@ -117,11 +189,27 @@ inline void run_block(BlockCtx* c) {
         f.state = RUNNABLE;
         f.coll_ops = 0;
         f.asan_fake = nullptr;
+#ifdef SFEMU_FASTSWITCH
+        // the frame sfemu_switch pops on the first switch into this fiber: [mxcsr | x87 cw][r15 r14 r13 r12 rbx rbp][return = fiber_entry][0];
+        // after its `ret` the stack pointer is top - 8, i.e. what the ABI promises a function at entry (rsp + 8 a multiple of 16)
+        uintptr_t top = ((uintptr_t)f.stack + kStackBytes) & ~(uintptr_t)15;
+        void** q = (void**)top;
+        *--q = nullptr;                          // fiber_entry's (never used) return address
+        *--q = (void*)&fiber_entry;
+        for (int r = 0; r < 6; ++r) *--q = nullptr;
+        --q;
+        unsigned csr = 0x1f80;                   // MXCSR default: all exceptions masked, round to nearest
+        unsigned short cw = 0x037f;              // x87 control word default
+        std::memcpy((char*)q, &csr, 4);
+        std::memcpy((char*)q + 4, &cw, 2);
+        f.sp = (void*)q;
+#else
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack;
         f.ctx.uc_stack.ss_size = kStackBytes;
         f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+#endif
     }
     const int nwaves = (n + 63) / 64;
     for (;;) {
@@ -134,7 +222,11 @@ inline void run_block(BlockCtx* c) {
 #ifdef SFEMU_ASAN
             __sanitizer_start_switch_fiber(&c->sched_asan_fake, f.stack, kStackBytes);
 #endif
+#ifdef SFEMU_FASTSWITCH
+            sfemu_switch(&c->sched_sp, f.sp);
+#else
             swapcontext(&c->sched, &f.ctx);
+#endif
 #ifdef SFEMU_ASAN
             __sanitizer_finish_switch_fiber(c->sched_asan_fake, nullptr, nullptr);
 #endif
@@ -190,14 +282,15 @@ inline void launch(dim3 grid, dim3 block, size_t smem, const std::function<void(
         ctx.nthreads = nthreads;
         ctx.fibers.resize(nthreads);
         ctx.waves.resize((nthreads + 63) / 64);
-        ctx.stack_pool.resize((size_t)nthreads * kStackBytes);
+        ctx.stack_pool_bytes = (size_t)nthreads * kStackBytes;
+        ctx.stack_pool = stack_pool().take(ctx.stack_pool_bytes);
         ctx.dyn_smem.resize(smem + 64);
         ctx.bdim = block;
         ctx.gdim = grid;
         ctx.body = &body;
         for (int i = 0; i < nthreads; ++i) {
             Fiber& f = ctx.fibers[i];
-            f.stack = ctx.stack_pool.data() + (size_t)i * kStackBytes;
+            f.stack = ctx.stack_pool + (size_t)i * kStackBytes;
             f.linear = i;
             f.tid.x = i % block.x;
             f.tid.y = (i / block.x) % block.y;
@@ -213,6 +306,7 @@ inline void launch(dim3 grid, dim3 block, size_t smem, const std::function<void(
             run_block(&ctx);
         }
         tls_ctx() = nullptr;
+        stack_pool().give(ctx.stack_pool, ctx.stack_pool_bytes);
     };
     int nt = (int)std::min<long>(emu_threads(), nblocks);
     if (nt <= 1) {
